@@ -1,0 +1,91 @@
+"""ORACLE tooling: the seeded parity cases shared by oracle/make_goldens.py (which runs the
+imported reference on them) and tests/ (which run the oracle and the HIP path on them).
+Inputs are regenerated from seeds (numpy legacy RandomState: version-stable), so fixtures hold
+only the reference's *outputs*."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from conditional_score_diffusion_amd.config_dict import ConfigDict  # noqa: E402
+
+
+def make_config(name='ddpm_paired_SR3', nf=32, ch_mult=(1, 2, 2), num_res_blocks=2,
+                attn_resolutions=(10, 5), image_size=20, x_ch=3, y_ch=3, num_scales=1000,
+                sigma_min_x=5e-3, sigma_max_x=None, sigma_min_y=5e-3, sigma_max_y=1.0, snr=0.15):
+    """A reference-style config carrying exactly the keys the hot path reads
+    (cf. configs/ve/inverse_problems/super_resolution/celebA_SR3_160.py:6-161)."""
+    c = ConfigDict()
+    c.training = ConfigDict(continuous=True, sde='vesde', likelihood_weighting=True, reduce_mean=True,
+                            conditioning_approach='sr3' if name.endswith('SR3') else 'ours_NDV')
+    c.sampling = ConfigDict(method='pc', predictor='conditional_reverse_diffusion',
+                            corrector='conditional_langevin', n_steps_each=1, noise_removal=True,
+                            probability_flow=False, snr=snr)
+    if name == 'ddpm':
+        c.sampling.predictor, c.sampling.corrector = 'reverse_diffusion', 'langevin'
+    c.data = ConfigDict(image_size=image_size, effective_image_size=image_size, centered=False,
+                        shape_x=[x_ch, image_size, image_size], shape_y=[y_ch, image_size, image_size],
+                        num_channels=x_ch + y_ch)
+    if sigma_max_x is None:
+        sigma_max_x = float(np.sqrt(np.prod(c.data.shape_x)))
+    paired = name != 'ddpm'
+    c.model = ConfigDict(name=name, nf=nf, ch_mult=tuple(ch_mult), num_res_blocks=num_res_blocks,
+                         attn_resolutions=tuple(attn_resolutions), dropout=0.1, resamp_with_conv=True,
+                         conditional=True, nonlinearity='swish', num_scales=num_scales,
+                         sigma_min_x=sigma_min_x, sigma_max_x=sigma_max_x,
+                         sigma_min_y=sigma_min_y, sigma_max_y=sigma_max_y,
+                         sigma_min=sigma_min_x, sigma_max=sigma_max_x,
+                         input_channels=(x_ch + y_ch) if paired else x_ch,
+                         output_channels=x_ch if name != 'ddpm_paired' else x_ch + y_ch,
+                         embedding_type='positional', scale_by_sigma=True)
+    return c
+
+
+CASES = {
+    # name: (config kwargs, batch)
+    'sr3_tiny': (dict(name='ddpm_paired_SR3'), 2),
+    'cmde_tiny': (dict(name='ddpm_paired'), 2),
+    'uncond_tiny': (dict(name='ddpm', ch_mult=(1, 1, 2), num_res_blocks=1, attn_resolutions=(8,),
+                         image_size=16), 2),
+}
+
+
+def case_config(case):
+    kw, B = CASES[case]
+    return make_config(**kw), B
+
+
+def case_y(case, B=None):
+    """Synthetic condition image y in [0,1): SR-style (nearest x4 of a low-res draw) for SR3
+    (mirrors lightning_data_modules/SRFLOWDataset.py:141-146), masked square for CMDE (:321-325)."""
+    cfg, B0 = case_config(case)
+    B = B or B0
+    S = cfg.data.image_size
+    rs = np.random.RandomState(123)
+    if case.startswith('sr3'):
+        lr = rs.uniform(0, 1, size=(B, 3, S // 4, S // 4)).astype(np.float32)
+        y = np.repeat(np.repeat(lr, 4, axis=2), 4, axis=3)
+    else:
+        y = rs.uniform(0, 1, size=(B, 3, S, S)).astype(np.float32)
+        y[:, :, S // 4:S // 4 + S // 2, S // 4:S // 4 + S // 2] = 0.
+    return torch.from_numpy(y)
+
+
+def tape(shapes, seed=42):
+    """List of standard-normal fp32 tensors with the given shapes, in draw order."""
+    rs = np.random.RandomState(seed)
+    return [torch.from_numpy(rs.standard_normal(s).astype(np.float32)) for s in shapes]
+
+
+def pc_tape_shapes(case, p_steps, B=None):
+    cfg, B0 = case_config(case)
+    B = B or B0
+    xs = (B,) + tuple(cfg.data.shape_x)
+    ys = (B,) + tuple(cfg.data.shape_y)
+    shapes = [xs]
+    per_phase = [ys, xs] if cfg.model.name == 'ddpm_paired' else [xs]
+    for _ in range(p_steps):
+        shapes += per_phase + per_phase
+    return shapes

@@ -1,0 +1,192 @@
+"""ORACLE tooling (build container only): run the IMPORTED REFERENCE on the seeded cases of
+oracle/cases.py and write its outputs to tests/golden/*.npz.
+
+    python oracle/make_goldens.py            # regenerates every fixture
+
+The fixtures pin oracle/score_oracle.py (tests/test_oracle_golden.py) and are also compared
+directly with the HIP path (tests/test_gpu_*.py).  Only inputs-by-seed and reference OUTPUTS are
+stored - no reference source text.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import cases  # noqa: E402
+import ref_import  # noqa: E402
+import score_oracle as so  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+
+
+def build_ref_model(ref, cfg, seed=0):
+    model = ref['models.utils'].create_model(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    # the oracle's own shape table must agree with the reference's state_dict exactly
+    mine = so.ddpm_param_shapes(so.NetCfg.from_config(cfg))
+    assert mine == shapes, set(mine.items()) ^ set(shapes.items())
+    params = so.synth_params(shapes, seed)
+    model.load_state_dict(params)
+    model.eval()
+    return model, params
+
+
+def sdes_for(ref, cfg):
+    sl = ref['sde_lib']
+    m = cfg.model
+    if m.name == 'ddpm_paired':
+        return {'x': sl.cVESDE(m.sigma_min_x, m.sigma_max_x, m.num_scales),
+                'y': sl.VESDE(m.sigma_min_y, m.sigma_max_y, m.num_scales)}
+    if m.name == 'ddpm':
+        return sl.VESDE(m.sigma_min_x, m.sigma_max_x, m.num_scales)
+    return sl.cVESDE(m.sigma_min_x, m.sigma_max_x, m.num_scales)
+
+
+def gen_network_case(ref, case):
+    cfg, B = cases.case_config(case)
+    model, _ = build_ref_model(ref, cfg)
+    sde = sdes_for(ref, cfg)
+    y = cases.case_y(case)
+    xs = (B,) + tuple(cfg.data.shape_x)
+    out = {}
+    rs = np.random.RandomState(7)
+    name = cfg.model.name
+    with torch.no_grad():
+        # G3: whole-network forward + score at three times
+        for j, tval in enumerate([1.0, 0.5, 1e-5]):
+            sig = float(cfg.model.sigma_min_x * (cfg.model.sigma_max_x / cfg.model.sigma_min_x) ** tval)
+            x = torch.from_numpy((rs.standard_normal(xs) * sig + 0.5).astype(np.float32))
+            t = torch.ones(B) * tval
+            labels = t * (cfg.model.num_scales - 1)
+            if name == 'ddpm':
+                # DDPM has no ``embedding_type`` attribute, which the unconditional continuous VESDE
+                # branch reads (models/utils.py:251); set it on the instance (as NCSN++ defines it).
+                model.embedding_type = 'positional'
+                sfn = ref['models.utils'].get_score_fn(sde, model, conditional=False, train=False,
+                                                       continuous=True)
+                score = sfn(x, t)
+                net = model(x, sde.marginal_prob(x, t)[1])   # label = sigma(t) in this branch
+                out['net%d' % j] = net.numpy()
+            else:
+                net = model({'x': x, 'y': y}, labels)
+                sfn = ref['models.utils'].get_score_fn(sde, model, conditional=True, train=False, continuous=True)
+                sfn = ref['models.utils'].get_conditional_score_fn(sfn, target_domain='x')
+                score = sfn(x, y, t)
+                if isinstance(net, dict):
+                    out['net%d' % j] = torch.cat([net['x'], net['y']], 1).numpy()
+                else:
+                    out['net%d' % j] = net.numpy()
+            out['x%d' % j] = x.numpy()
+            out['score%d' % j] = score.numpy()
+        # G5/G6: PC trajectories with a noise tape
+        for p_steps in (1, 10, 50):
+            tp = cases.tape(cases.pc_tape_shapes(case, p_steps))
+            with ref_import.TapeRandn(tp) as tr:
+                if name == 'ddpm':
+                    un = ref['sampling.unconditional']
+                    pred = ref['sampling.predictors'].get_predictor('reverse_diffusion')
+                    corr = ref['sampling.correctors'].get_corrector('langevin')
+                    sampler = un.get_pc_sampler(sde, xs, pred, corr, snr=cfg.sampling.snr, p_steps=p_steps,
+                                                c_steps=1, probability_flow=False, continuous=True,
+                                                denoise=True, eps=1e-5)
+                    res, info = sampler(model, show_evolution=(p_steps == 10))
+                else:
+                    co = ref['sampling.conditional']
+                    pred = ref['sampling.predictors'].get_predictor(cfg.sampling.predictor)
+                    corr = ref['sampling.correctors'].get_corrector(cfg.sampling.corrector)
+                    sampler = co.get_pc_conditional_sampler(sde, xs, pred, corr, snr=cfg.sampling.snr,
+                                                            p_steps=p_steps, c_steps=1, probability_flow=False,
+                                                            continuous=True, denoise=True, use_path=False, eps=1e-5)
+                    res, info = sampler(model, y, show_evolution=(p_steps == 10))
+                assert tr.i == len(tp), (tr.i, len(tp))
+            out['pc%d' % p_steps] = res.numpy()
+            if p_steps == 10:
+                ev = info['evolution']
+                ev = ev['x'] if isinstance(ev, dict) else ev
+                out['pc10_evolution'] = ev.numpy()
+    np.savez_compressed(os.path.join(OUT, case + '.npz'), **out)
+    print(case, {k: v.shape for k, v in out.items()})
+
+
+def gen_modules(ref):
+    """G1/G2: individual reference modules on seeded inputs (NCHW fp32)."""
+    L = ref['models.layers']
+    rs = np.random.RandomState(11)
+    out = {}
+
+    def rnd(*s):
+        return torch.from_numpy(rs.standard_normal(s).astype(np.float32))
+
+    act = torch.nn.SiLU()
+    with torch.no_grad():
+        for tag, cin, cout, hw in [('res_same', 32, 32, 10), ('res_proj', 96, 64, 5)]:
+            blk = L.ResnetBlockDDPM(act, cin, cout, temb_dim=128, dropout=0.1).eval()
+            shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+            blk.load_state_dict(so.synth_params(shapes, 3))
+            x, temb = rnd(2, cin, hw, hw) * 2 + 0.3, rnd(2, 128)
+            out[tag + '_x'], out[tag + '_temb'], out[tag + '_out'] = x.numpy(), temb.numpy(), blk(x, temb).numpy()
+        for tag, c, hw in [('attn25', 64, 5), ('attn100', 32, 10)]:
+            blk = L.AttnBlock(c).eval()
+            shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+            blk.load_state_dict(so.synth_params(shapes, 4))
+            x = rnd(2, c, hw, hw) * 1.5
+            out[tag + '_x'], out[tag + '_out'] = x.numpy(), blk(x).numpy()
+        for tag, mod, hw in [('down', L.Downsample(32, True), 10), ('up', L.Upsample(32, True), 5)]:
+            mod = mod.eval()
+            shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+            mod.load_state_dict(so.synth_params(shapes, 5))
+            x = rnd(2, 32, hw, hw)
+            out[tag + '_x'], out[tag + '_out'] = x.numpy(), mod(x).numpy()
+        t = torch.tensor([999.0, 978.6124, 500.25, 0.00999], dtype=torch.float32)
+        out['temb_t'], out['temb_out'] = t.numpy(), L.get_timestep_embedding(t, 96).numpy()
+    np.savez_compressed(os.path.join(OUT, 'modules.npz'), **out)
+    print('modules', {k: v.shape for k, v in out.items()})
+
+
+def gen_sde_tables(ref):
+    """G4: sigma tables, timestep-index sequences, per-t scalars of the VE SDEs."""
+    sl = ref['sde_lib']
+    out = {}
+    smax = float(np.sqrt(3 * 160 * 160))
+    sde = sl.cVESDE(5e-3, np.sqrt(np.prod([3, 160, 160])), 1000)
+    out['discrete_sigmas'] = sde.discrete_sigmas.numpy()
+    for p_steps in (50, 1000):
+        ts = torch.linspace(sde.T, 1e-5, p_steps)
+        out['timesteps%d' % p_steps] = ts.numpy()
+        out['index%d' % p_steps] = (ts * (sde.N - 1) / sde.T).long().numpy()
+        out['labels%d' % p_steps] = (ts * (sde.N - 1)).numpy()
+        x = torch.zeros(p_steps, 1, 1, 1)
+        out['G%d' % p_steps] = sde.discretize(x, ts)[1].numpy()
+        out['std%d' % p_steps] = sde.marginal_prob(x, ts)[1].numpy()
+        out['g%d' % p_steps] = sde.sde(x, ts)[1].numpy()
+    vy = sl.VESDE(5e-3, 1.0, 1000)
+    ts = torch.linspace(1, 1e-5, 8)
+    x0, x1 = torch.ones(8, 1, 2, 2) * 0.3, torch.ones(8, 1, 2, 2) * 0.7
+    m, s = vy.compute_backward_kernel(x0, x1, ts, torch.ones(8) * 0.02)
+    out['bk_mean'], out['bk_std'] = m.numpy(), s.numpy()
+    out['vy_g'] = vy.sde(x0, ts)[1].numpy()
+    vp = sl.VPSDE(0.1, 20., 1000)
+    out['vp_mean'], out['vp_std'] = [a.numpy() for a in vp.marginal_prob(x0, ts)]
+    out['vp_f'], out['vp_G'] = [a.numpy() for a in vp.discretize(x0, ts)]
+    out['vp_drift'], out['vp_diff'] = [a.numpy() for a in vp.sde(x0, ts)]
+    assert abs(smax - sde.sigma_max) < 1e-9
+    np.savez_compressed(os.path.join(OUT, 'sde_tables.npz'), **out)
+    print('sde_tables', {k: v.shape for k, v in out.items()})
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ref = ref_import.modules()
+    gen_sde_tables(ref)
+    gen_modules(ref)
+    for case in cases.CASES:
+        gen_network_case(ref, case)
+
+
+if __name__ == '__main__':
+    main()

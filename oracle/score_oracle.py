@@ -1,0 +1,425 @@
+"""ORACLE (test infrastructure - NOT product code).
+
+CPU restatement, in plain functional PyTorch fp32, of the reference's score network
+(DDPM-family U-Net) and of its predictor-corrector sampling loop.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this file; the
+product path (conditional_score_diffusion_amd/) never does.
+
+Pinning: the reference holds no golden vectors for this path, so this
+oracle is pinned by fixtures generated from the *imported reference itself* in the build
+container (oracle/make_goldens.py -> tests/golden/*.npz; checked by tests/test_oracle_golden.py).
+
+Every function cites the reference lines it follows (paths relative to /root/reference).
+Parameters are passed as a flat dict with the reference's ``state_dict`` keys
+(``all_modules.{i}.Conv_0.weight`` ...), conv weights OIHW, NIN ``W`` [in,out], Linear [out,in].
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------
+# configuration view
+# ------------------------------------------------------------------------------------------
+class NetCfg:
+    """The handful of values DDPM.__init__ reads (models/ddpm.py:82-147)."""
+
+    def __init__(self, nf, ch_mult, num_res_blocks, attn_resolutions, image_size,
+                 input_channels, output_channels, resamp_with_conv=True, conditional=True,
+                 centered=False, act='swish'):
+        self.nf = nf
+        self.ch_mult = tuple(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.attn_resolutions = tuple(attn_resolutions)
+        self.image_size = image_size
+        self.input_channels = input_channels
+        self.output_channels = output_channels
+        self.resamp_with_conv = resamp_with_conv
+        self.conditional = conditional
+        self.centered = centered
+        self.act = act
+
+    @staticmethod
+    def from_config(config):
+        m, d = config.model, config.data
+        return NetCfg(m.nf, m.ch_mult, m.num_res_blocks, m.attn_resolutions,
+                      d.effective_image_size, m.input_channels, m.output_channels,
+                      m.resamp_with_conv, m.conditional, d.centered, m.nonlinearity.lower())
+
+
+def ddpm_module_list(cfg):
+    """Module sequence of DDPM.all_modules (models/ddpm.py:96-147): list of
+    (kind, idx, dict) in construction order - which is also execution order."""
+    mods = []
+
+    def add(kind, **kw):
+        mods.append((kind, len(mods), kw))
+
+    nf = cfg.nf
+    if cfg.conditional:
+        add('linear', cin=nf, cout=4 * nf)
+        add('linear', cin=4 * nf, cout=4 * nf)
+    add('conv3', cin=cfg.input_channels, cout=nf)
+    nres = len(cfg.ch_mult)
+    res = [cfg.image_size // (2 ** i) for i in range(nres)]
+    hs_c = [nf]
+    in_ch = nf
+    for lvl in range(nres):
+        for _ in range(cfg.num_res_blocks):
+            out_ch = nf * cfg.ch_mult[lvl]
+            add('res', cin=in_ch, cout=out_ch)
+            in_ch = out_ch
+            if res[lvl] in cfg.attn_resolutions:
+                add('attn', ch=in_ch)
+            hs_c.append(in_ch)
+        if lvl != nres - 1:
+            add('down', ch=in_ch)
+            hs_c.append(in_ch)
+    add('res', cin=in_ch, cout=in_ch)
+    add('attn', ch=in_ch)
+    add('res', cin=in_ch, cout=in_ch)
+    for lvl in reversed(range(nres)):
+        for _ in range(cfg.num_res_blocks + 1):
+            out_ch = nf * cfg.ch_mult[lvl]
+            add('res', cin=in_ch + hs_c.pop(), cout=out_ch)
+            in_ch = out_ch
+        if res[lvl] in cfg.attn_resolutions:
+            add('attn', ch=in_ch)
+        if lvl != 0:
+            add('up', ch=in_ch)
+    assert not hs_c
+    add('gn', ch=in_ch)
+    add('conv3', cin=in_ch, cout=cfg.output_channels)
+    return mods
+
+
+def ddpm_param_shapes(cfg):
+    """{state_dict key: shape} for the DDPM family."""
+    shapes = {}
+    temb = 4 * cfg.nf
+    for kind, i, kw in ddpm_module_list(cfg):
+        p = 'all_modules.%d.' % i
+        if kind == 'linear':
+            shapes[p + 'weight'] = (kw['cout'], kw['cin'])
+            shapes[p + 'bias'] = (kw['cout'],)
+        elif kind == 'conv3':
+            shapes[p + 'weight'] = (kw['cout'], kw['cin'], 3, 3)
+            shapes[p + 'bias'] = (kw['cout'],)
+        elif kind == 'gn':
+            shapes[p + 'weight'] = (kw['ch'],)
+            shapes[p + 'bias'] = (kw['ch'],)
+        elif kind in ('down', 'up'):
+            if cfg.resamp_with_conv:
+                shapes[p + 'Conv_0.weight'] = (kw['ch'], kw['ch'], 3, 3)
+                shapes[p + 'Conv_0.bias'] = (kw['ch'],)
+        elif kind == 'attn':
+            c = kw['ch']
+            shapes[p + 'GroupNorm_0.weight'] = (c,)
+            shapes[p + 'GroupNorm_0.bias'] = (c,)
+            for j in range(4):
+                shapes[p + 'NIN_%d.W' % j] = (c, c)
+                shapes[p + 'NIN_%d.b' % j] = (c,)
+        elif kind == 'res':
+            ci, co = kw['cin'], kw['cout']
+            shapes[p + 'GroupNorm_0.weight'] = (ci,)
+            shapes[p + 'GroupNorm_0.bias'] = (ci,)
+            shapes[p + 'Conv_0.weight'] = (co, ci, 3, 3)
+            shapes[p + 'Conv_0.bias'] = (co,)
+            if cfg.conditional:
+                shapes[p + 'Dense_0.weight'] = (co, temb)
+                shapes[p + 'Dense_0.bias'] = (co,)
+            shapes[p + 'GroupNorm_1.weight'] = (co,)
+            shapes[p + 'GroupNorm_1.bias'] = (co,)
+            shapes[p + 'Conv_1.weight'] = (co, co, 3, 3)
+            shapes[p + 'Conv_1.bias'] = (co,)
+            if ci != co:
+                shapes[p + 'NIN_0.W'] = (ci, co)
+                shapes[p + 'NIN_0.b'] = (co,)
+    return shapes
+
+
+def synth_params(shapes, seed=0):
+    """Deterministic NON-DEGENERATE synthetic weights: every >=2-D tensor is
+    U(+-sqrt(3/fan_avg)) (the reference's ``default_init(1.0)``, models/layers.py:54-91), biases
+    and GroupNorm affine parameters are perturbed so those code paths are exercised.
+    numpy's legacy RandomState is version-stable, so fixtures need not store the weights."""
+    out = {}
+    for k in sorted(shapes):
+        shp = shapes[k]
+        rs = np.random.RandomState((seed * 1000003 + _stable_hash(k)) % (2 ** 31 - 1))
+        if len(shp) >= 2:
+            if k.endswith('.W'):  # NIN: [in, out]
+                fan_in, fan_out = shp[0], shp[1]
+            else:  # conv OIHW / linear [out,in]
+                rf = int(np.prod(shp[2:])) if len(shp) > 2 else 1
+                fan_in, fan_out = shp[1] * rf, shp[0] * rf
+            lim = math.sqrt(3.0 / ((fan_in + fan_out) / 2.0))
+            v = rs.uniform(-lim, lim, size=shp)
+        elif 'GroupNorm' in k and k.endswith('weight') or (k.count('.') == 2 and k.endswith('weight')):
+            v = 1.0 + 0.1 * rs.standard_normal(shp)
+        else:
+            v = 0.05 * rs.standard_normal(shp)
+        out[k] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return out
+
+
+def _stable_hash(s):
+    h = 2166136261
+    for ch in s.encode():
+        h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+    return h
+
+
+# ------------------------------------------------------------------------------------------
+# layers
+# ------------------------------------------------------------------------------------------
+def _act(name):
+    return {'swish': F.silu, 'relu': F.relu, 'elu': F.elu,
+            'lrelu': lambda v: F.leaky_relu(v, 0.2)}[name]
+
+
+def timestep_embedding(t, dim, max_positions=10000):
+    """models/layers.py:524-538."""
+    half = dim // 2
+    w = math.log(max_positions) / (half - 1)
+    w = torch.exp(torch.arange(half, dtype=torch.float32) * -w)
+    e = t.float()[:, None] * w[None, :]
+    e = torch.cat([torch.sin(e), torch.cos(e)], dim=1)
+    if dim % 2 == 1:
+        e = F.pad(e, (0, 1))
+    return e
+
+
+def nin(x, W, b):
+    """models/layers.py:555-564: NHWC matmul [.., Cin] @ W[Cin, Cout] + b."""
+    return (x.permute(0, 2, 3, 1) @ W + b).permute(0, 3, 1, 2)
+
+
+def attn_block(p, pre, x, groups=32):
+    """models/layers.py:567-590."""
+    B, C, H, W = x.shape
+    h = F.group_norm(x, groups, p[pre + 'GroupNorm_0.weight'], p[pre + 'GroupNorm_0.bias'], eps=1e-6)
+    q = nin(h, p[pre + 'NIN_0.W'], p[pre + 'NIN_0.b'])
+    k = nin(h, p[pre + 'NIN_1.W'], p[pre + 'NIN_1.b'])
+    v = nin(h, p[pre + 'NIN_2.W'], p[pre + 'NIN_2.b'])
+    w = torch.einsum('bchw,bcij->bhwij', q, k) * (int(C) ** (-0.5))
+    w = F.softmax(w.reshape(B, H, W, H * W), dim=-1).reshape(B, H, W, H, W)
+    h = torch.einsum('bhwij,bcij->bchw', w, v)
+    h = nin(h, p[pre + 'NIN_3.W'], p[pre + 'NIN_3.b'])
+    return x + h
+
+
+def res_block(p, pre, x, temb, act, cout, groups=32):
+    """ResnetBlockDDPM.forward in eval mode - dropout is identity (models/layers.py:658-675)."""
+    cin = x.shape[1]
+    h = act(F.group_norm(x, groups, p[pre + 'GroupNorm_0.weight'], p[pre + 'GroupNorm_0.bias'], eps=1e-6))
+    h = F.conv2d(h, p[pre + 'Conv_0.weight'], p[pre + 'Conv_0.bias'], padding=1)
+    if temb is not None:
+        h = h + F.linear(act(temb), p[pre + 'Dense_0.weight'], p[pre + 'Dense_0.bias'])[:, :, None, None]
+    h = act(F.group_norm(h, groups, p[pre + 'GroupNorm_1.weight'], p[pre + 'GroupNorm_1.bias'], eps=1e-6))
+    h = F.conv2d(h, p[pre + 'Conv_1.weight'], p[pre + 'Conv_1.bias'], padding=1)
+    if cin != cout:
+        x = nin(x, p[pre + 'NIN_0.W'], p[pre + 'NIN_0.b'])
+    return x + h
+
+
+def downsample(p, pre, x, with_conv):
+    """models/layers.py:619-629: pad (0,1,0,1) then 3x3 stride-2 conv, or 2x2 avg-pool."""
+    if with_conv:
+        return F.conv2d(F.pad(x, (0, 1, 0, 1)), p[pre + 'Conv_0.weight'], p[pre + 'Conv_0.bias'], stride=2)
+    return F.avg_pool2d(x, 2, 2)
+
+
+def upsample(p, pre, x, with_conv):
+    """models/layers.py:600-604: nearest x2 then 3x3 conv."""
+    h = F.interpolate(x, scale_factor=2, mode='nearest')
+    if with_conv:
+        h = F.conv2d(h, p[pre + 'Conv_0.weight'], p[pre + 'Conv_0.bias'], padding=1)
+    return h
+
+
+def ddpm_forward(p, cfg, x, labels):
+    """DDPM.forward (models/ddpm.py:149-213). x: [B, input_channels, H, W] NCHW fp32."""
+    act = _act(cfg.act)
+    mods = ddpm_module_list(cfg)
+    it = iter(mods)
+
+    def nxt(kind):
+        k, i, kw = next(it)
+        assert k == kind, (k, kind)
+        return 'all_modules.%d.' % i, kw
+
+    temb = None
+    if cfg.conditional:
+        pre, _ = nxt('linear')
+        temb = F.linear(timestep_embedding(labels, cfg.nf), p[pre + 'weight'], p[pre + 'bias'])
+        pre, _ = nxt('linear')
+        temb = F.linear(act(temb), p[pre + 'weight'], p[pre + 'bias'])
+    h = x if cfg.centered else 2 * x - 1.
+    pre, _ = nxt('conv3')
+    hs = [F.conv2d(h, p[pre + 'weight'], p[pre + 'bias'], padding=1)]
+    nres = len(cfg.ch_mult)
+    for lvl in range(nres):
+        for _ in range(cfg.num_res_blocks):
+            pre, kw = nxt('res')
+            h = res_block(p, pre, hs[-1], temb, act, kw['cout'])
+            if h.shape[-1] in cfg.attn_resolutions:
+                pre, _ = nxt('attn')
+                h = attn_block(p, pre, h)
+            hs.append(h)
+        if lvl != nres - 1:
+            pre, _ = nxt('down')
+            hs.append(downsample(p, pre, hs[-1], cfg.resamp_with_conv))
+    h = hs[-1]
+    pre, kw = nxt('res')
+    h = res_block(p, pre, h, temb, act, kw['cout'])
+    pre, _ = nxt('attn')
+    h = attn_block(p, pre, h)
+    pre, kw = nxt('res')
+    h = res_block(p, pre, h, temb, act, kw['cout'])
+    for lvl in reversed(range(nres)):
+        for _ in range(cfg.num_res_blocks + 1):
+            pre, kw = nxt('res')
+            h = res_block(p, pre, torch.cat([h, hs.pop()], dim=1), temb, act, kw['cout'])
+        if h.shape[-1] in cfg.attn_resolutions:
+            pre, _ = nxt('attn')
+            h = attn_block(p, pre, h)
+        if lvl != 0:
+            pre, _ = nxt('up')
+            h = upsample(p, pre, h, cfg.resamp_with_conv)
+    assert not hs
+    pre, _ = nxt('gn')
+    h = act(F.group_norm(h, 32, p[pre + 'weight'], p[pre + 'bias'], eps=1e-6))
+    pre, _ = nxt('conv3')
+    return F.conv2d(h, p[pre + 'weight'], p[pre + 'bias'], padding=1)
+
+
+def paired_forward(p, cfg, x, y, labels, sr3):
+    """DDPM_paired_SR3 / DDPM_paired forward (models/ddpm.py:275-298)."""
+    out = ddpm_forward(p, cfg, torch.cat((x, y), dim=1), labels)
+    if sr3:
+        return out
+    c = x.shape[1]
+    return {'x': out[:, :c], 'y': out[:, c:]}
+
+
+# ------------------------------------------------------------------------------------------
+# VE SDE scalars (fp32, exactly the reference's expressions)
+# ------------------------------------------------------------------------------------------
+class VE:
+    """sigma table + per-t scalars of (c)VESDE (sde_lib.py:290-418)."""
+
+    def __init__(self, sigma_min, sigma_max, N=1000):
+        self.sigma_min, self.sigma_max, self.N, self.T = sigma_min, sigma_max, N, 1
+        self.discrete_sigmas = torch.exp(torch.linspace(np.log(sigma_min), np.log(sigma_max), N))
+
+    def std(self, t):
+        smin = torch.tensor(self.sigma_min).type_as(t)
+        smax = torch.tensor(self.sigma_max).type_as(t)
+        return smin * (smax / smin) ** t
+
+    def G(self, t):
+        i = (t * (self.N - 1) / self.T).long()
+        sig = self.discrete_sigmas[i]
+        adj = torch.where(i == 0, torch.zeros_like(t), self.discrete_sigmas[i - 1])
+        return torch.sqrt(sig ** 2 - adj ** 2)
+
+
+def _b(v):
+    return v[:, None, None, None]
+
+
+def score_sr3(p, cfg, ve_x, x, y, t):
+    """cVESDE continuous branch of get_score_fn (models/utils.py:210-215) + divide_by_sigmas."""
+    labels = t * (ve_x.N - 1)
+    out = paired_forward(p, cfg, x, y, labels, sr3=True)
+    return out / _b(ve_x.std(t))
+
+
+def score_paired_x(p, cfg, ve_x, ve_y, x, y, t):
+    """dict-SDE branch (models/utils.py:173-180); conditional wrapper keeps ['x'] (:270-278)."""
+    labels = t * (ve_x.N - 1)
+    out = paired_forward(p, cfg, x, y, labels, sr3=False)
+    return out['x'] / _b(ve_x.std(t))
+
+
+class NoiseTape:
+    """Serves pre-drawn standard-normal tensors in call order."""
+
+    def __init__(self, tensors):
+        self.t, self.i = list(tensors), 0
+
+    def __call__(self, like):
+        z = self.t[self.i]
+        self.i += 1
+        assert z.shape == like.shape
+        return z
+
+
+def langevin_update(score, x, z, snr, batch_reduce=None):
+    """conditionalLangevinCorrector.update_fn, VE (alpha=1) (sampling/correctors.py:88-108).
+    ``batch_reduce`` lets the multi-GPU "global-norm" mode all-reduce the two batch means."""
+    g = torch.norm(score.reshape(score.shape[0], -1), dim=-1).mean()
+    n = torch.norm(z.reshape(z.shape[0], -1), dim=-1).mean()
+    if batch_reduce is not None:
+        g, n = batch_reduce(g, n)
+    step = (snr * n / g) ** 2 * 2 * torch.ones(x.shape[0])
+    x_mean = x + _b(step) * score
+    return x_mean + _b(torch.sqrt(step * 2)) * z, x_mean
+
+
+def reverse_diffusion_update(score, x, z, G):
+    """conditionalReverseDiffusionPredictor.update_fn with cVESDE.discretize
+    (sampling/predictors.py:97-102; sde_lib.py:135-140,410-418): f=0, rev_f=-G^2*score."""
+    rev_f = torch.zeros_like(x) - _b(G) ** 2 * score
+    x_mean = x - rev_f
+    return x_mean + _b(G) * z, x_mean
+
+
+def pc_sample_conditional(p, cfg, y, noise, sigma_x, sigma_y=None, sr3=True, p_steps=1000,
+                          snr=0.15, eps=1e-5, denoise=True, N=1000, record=None):
+    """Default (non-use_path) loop of get_pc_conditional_sampler (sampling/conditional.py:180-226).
+
+    noise: NoiseTape; draw order = prior, then per step [z_y(corr)], z_corr, [z_y(pred)], z_pred
+    (bracketed draws only for the dict-SDE estimators CMDE / VS-CMDE).
+    sigma_x / sigma_y: (sigma_min, sigma_max) tuples. Corrector THEN predictor, c_steps=1."""
+    ve_x = VE(*sigma_x, N=N)
+    ve_y = VE(*sigma_y, N=N) if sigma_y is not None else None
+    B = y.shape[0]
+    xshape = (B, cfg.output_channels if sr3 else y.shape[1]) + tuple(y.shape[2:])
+    x = noise(torch.empty(xshape)) * ve_x.sigma_max
+    timesteps = torch.linspace(ve_x.T, eps, p_steps)
+    x_mean = x
+    for i in range(p_steps):
+        vec_t = torch.ones(B) * timesteps[i]
+        for phase in ('corrector', 'predictor'):
+            if ve_y is not None:
+                y_in = y + noise(y) * _b(ve_y.std(vec_t))
+                s = score_paired_x(p, cfg, ve_x, ve_y, x, y_in, vec_t)
+            else:
+                s = score_sr3(p, cfg, ve_x, x, y, vec_t)
+            z = noise(x)
+            if phase == 'corrector':
+                x, x_mean = langevin_update(s, x, z, snr)
+            else:
+                x, x_mean = reverse_diffusion_update(s, x, z, ve_x.G(vec_t))
+        if record is not None:
+            record.append(x.clone())
+    return x_mean if denoise else x
+
+
+def pc_sample_unconditional(score_fn, shape, noise, ve, p_steps=1000, snr=0.15, eps=1e-5, denoise=True):
+    """get_pc_sampler loop (sampling/unconditional.py:194-226): LangevinCorrector then
+    ReverseDiffusionPredictor, same update algebra as the conditional pair."""
+    x = noise(torch.empty(shape)) * ve.sigma_max
+    timesteps = torch.linspace(ve.T, eps, p_steps)
+    x_mean = x
+    for i in range(p_steps):
+        vec_t = torch.ones(shape[0]) * timesteps[i]
+        s = score_fn(x, vec_t)
+        x, x_mean = langevin_update(s, x, noise(x), snr)
+        s = score_fn(x, vec_t)
+        x, x_mean = reverse_diffusion_update(s, x, noise(x), ve.G(vec_t))
+    return x_mean if denoise else x

@@ -1,0 +1,128 @@
+"""Pins the CPU oracle (oracle/score_oracle.py) to fixtures produced by the imported reference
+(oracle/make_goldens.py).  Tolerances are fp32 round-off: same torch ops, possibly different
+association order."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import score_oracle as so
+
+torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize('case', list(cases.CASES))
+def test_network_and_score(golden_dir, case):
+    g = load(golden_dir, case)
+    cfg, B = cases.case_config(case)
+    nc = so.NetCfg.from_config(cfg)
+    p = so.synth_params(so.ddpm_param_shapes(nc), 0)
+    y = cases.case_y(case)
+    ve_x = so.VE(cfg.model.sigma_min_x, cfg.model.sigma_max_x, cfg.model.num_scales)
+    ve_y = so.VE(cfg.model.sigma_min_y, cfg.model.sigma_max_y, cfg.model.num_scales)
+    for j, tval in enumerate([1.0, 0.5, 1e-5]):
+        x = torch.from_numpy(g['x%d' % j])
+        t = torch.ones(B) * tval
+        with torch.no_grad():
+            if cfg.model.name == 'ddpm':
+                std = ve_x.std(t)
+                net = so.ddpm_forward(p, nc, x, std)
+                score = net / std[:, None, None, None]
+            elif cfg.model.name == 'ddpm_paired':
+                o = so.paired_forward(p, nc, x, y, t * 999, sr3=False)
+                net = torch.cat([o['x'], o['y']], 1)
+                score = so.score_paired_x(p, nc, ve_x, ve_y, x, y, t)
+            else:
+                net = so.paired_forward(p, nc, x, y, t * 999, sr3=True)
+                score = so.score_sr3(p, nc, ve_x, x, y, t)
+        assert rel(net.numpy(), g['net%d' % j]) < 2e-5
+        assert rel(score.numpy(), g['score%d' % j]) < 2e-5
+
+
+@pytest.mark.parametrize('case', list(cases.CASES))
+@pytest.mark.parametrize('p_steps', [1, 10, 50])
+def test_pc_trajectory(golden_dir, case, p_steps):
+    g = load(golden_dir, case)
+    cfg, B = cases.case_config(case)
+    nc = so.NetCfg.from_config(cfg)
+    p = so.synth_params(so.ddpm_param_shapes(nc), 0)
+    noise = so.NoiseTape(cases.tape(cases.pc_tape_shapes(case, p_steps)))
+    rec = []
+    m = cfg.model
+    with torch.no_grad():
+        if m.name == 'ddpm':
+            ve = so.VE(m.sigma_min_x, m.sigma_max_x, m.num_scales)
+
+            def score_fn(x, t):
+                std = ve.std(t)
+                return so.ddpm_forward(p, nc, x, std) / std[:, None, None, None]
+            xs = (B,) + tuple(cfg.data.shape_x)
+            res = so.pc_sample_unconditional(score_fn, xs, noise, ve, p_steps=p_steps, snr=cfg.sampling.snr)
+        else:
+            res = so.pc_sample_conditional(
+                p, nc, cases.case_y(case), noise, (m.sigma_min_x, m.sigma_max_x),
+                (m.sigma_min_y, m.sigma_max_y) if m.name == 'ddpm_paired' else None,
+                sr3=(m.name == 'ddpm_paired_SR3'), p_steps=p_steps, snr=cfg.sampling.snr,
+                N=m.num_scales, record=rec)
+    assert noise.i == len(noise.t)
+    smax = m.sigma_max_x
+    # trajectories live at scale sigma_max; compare relative to it
+    err = np.abs(res.numpy() - g['pc%d' % p_steps]).max() / max(np.abs(g['pc%d' % p_steps]).max(), smax)
+    assert err < 1e-4, err
+    if p_steps == 10 and rec:
+        ev = np.stack([r.numpy() for r in rec])
+        assert np.abs(ev - g['pc10_evolution']).max() / smax < 1e-4
+
+
+def test_modules(golden_dir):
+    g = load(golden_dir, 'modules')
+    act = torch.nn.functional.silu
+    with torch.no_grad():
+        for tag, cin, cout in [('res_same', 32, 32), ('res_proj', 96, 64)]:
+            shapes = {'GroupNorm_0.weight': (cin,), 'GroupNorm_0.bias': (cin,),
+                      'Conv_0.weight': (cout, cin, 3, 3), 'Conv_0.bias': (cout,),
+                      'Dense_0.weight': (cout, 128), 'Dense_0.bias': (cout,),
+                      'GroupNorm_1.weight': (cout,), 'GroupNorm_1.bias': (cout,),
+                      'Conv_1.weight': (cout, cout, 3, 3), 'Conv_1.bias': (cout,)}
+            if cin != cout:
+                shapes.update({'NIN_0.W': (cin, cout), 'NIN_0.b': (cout,)})
+            p = so.synth_params(shapes, 3)
+            out = so.res_block(p, '', torch.from_numpy(g[tag + '_x']), torch.from_numpy(g[tag + '_temb']), act, cout)
+            assert rel(out.numpy(), g[tag + '_out']) < 1e-5
+        for tag, c in [('attn25', 64), ('attn100', 32)]:
+            shapes = {'GroupNorm_0.weight': (c,), 'GroupNorm_0.bias': (c,)}
+            for j in range(4):
+                shapes['NIN_%d.W' % j] = (c, c)
+                shapes['NIN_%d.b' % j] = (c,)
+            p = so.synth_params(shapes, 4)
+            out = so.attn_block(p, '', torch.from_numpy(g[tag + '_x']))
+            assert rel(out.numpy(), g[tag + '_out']) < 1e-5
+        shapes = {'Conv_0.weight': (32, 32, 3, 3), 'Conv_0.bias': (32,)}
+        p = so.synth_params(shapes, 5)
+        assert rel(so.downsample(p, '', torch.from_numpy(g['down_x']), True).numpy(), g['down_out']) < 1e-5
+        assert rel(so.upsample(p, '', torch.from_numpy(g['up_x']), True).numpy(), g['up_out']) < 1e-5
+        te = so.timestep_embedding(torch.from_numpy(g['temb_t']), 96)
+        assert np.abs(te.numpy() - g['temb_out']).max() < 1e-6
+
+
+def test_ve_scalars(golden_dir):
+    g = load(golden_dir, 'sde_tables')
+    ve = so.VE(5e-3, np.sqrt(np.prod([3, 160, 160])), 1000)
+    assert np.array_equal(ve.discrete_sigmas.numpy(), g['discrete_sigmas'])
+    for n in (50, 1000):
+        ts = torch.linspace(1, 1e-5, n)
+        assert np.array_equal(ts.numpy(), g['timesteps%d' % n])
+        assert np.array_equal((ts * 999).numpy(), g['labels%d' % n])
+        assert np.array_equal(ve.G(ts).numpy(), g['G%d' % n])
+        assert np.array_equal(ve.std(ts).numpy(), g['std%d' % n])
