@@ -1,0 +1,134 @@
+"""ctypes binding of libcsd_hip.so (the C ABI declared in include/csd.h).
+
+PyTorch-ROCm tensors are used purely as device-memory containers: every call hands raw
+``data_ptr()`` addresses and the current HIP stream to the library.  There is NO fallback: if the
+shared library is missing or a call fails, a ``RuntimeError`` is raised (the
+reference's pybind ops raise RuntimeError via TORCH_CHECK, op/upfirdn2d.cpp:8-10).
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcsd_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+MAX_LEVELS = 8
+MAX_ATTN = 8
+
+ACT_IDS = {'none': 0, 'swish': 1, 'relu': 2, 'lrelu': 3, 'elu': 4}
+PREC_IDS = {'fp32': 0, 'f32': 0, 'fp16x3': 1, 'fp16': 2}
+
+
+class UNetConfig(ctypes.Structure):
+    _fields_ = [('arch', ctypes.c_int32), ('nf', ctypes.c_int32), ('n_levels', ctypes.c_int32),
+                ('ch_mult', ctypes.c_int32 * MAX_LEVELS), ('num_res_blocks', ctypes.c_int32),
+                ('n_attn', ctypes.c_int32), ('attn_resolutions', ctypes.c_int32 * MAX_ATTN),
+                ('image_size', ctypes.c_int32), ('x_channels', ctypes.c_int32),
+                ('y_channels', ctypes.c_int32), ('out_channels', ctypes.c_int32),
+                ('resamp_with_conv', ctypes.c_int32), ('conditional', ctypes.c_int32),
+                ('centered', ctypes.c_int32), ('act', ctypes.c_int32), ('precision', ctypes.c_int32)]
+
+
+class PCParams(ctypes.Structure):
+    _fields_ = [('n_steps', ctypes.c_int32), ('labels', ctypes.POINTER(ctypes.c_float)),
+                ('std_x', ctypes.POINTER(ctypes.c_float)), ('G', ctypes.POINTER(ctypes.c_float)),
+                ('std_y', ctypes.POINTER(ctypes.c_float)), ('snr', ctypes.c_float),
+                ('denoise', ctypes.c_int32), ('noise_tape', ctypes.c_void_p), ('seed', ctypes.c_uint64),
+                ('record', ctypes.c_void_p)]
+
+
+def build(verbose=False):
+    """Compile libcsd_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ['make', '-C', CSRC, '-j', str(min(8, os.cpu_count() or 1))]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        sys.stderr.write(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError('building libcsd_hip.so failed (see output above)')
+    return LIB_PATH
+
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/csd.h one to one
+_vp, _i, _i64, _f, _sz, _u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
+                                ctypes.c_size_t, ctypes.c_uint64)
+SIGNATURES = {
+    'csd_version': (ctypes.c_char_p, []),
+    'csd_last_error': (ctypes.c_char_p, []),
+    'csd_unet_create': (_i, [ctypes.POINTER(UNetConfig), ctypes.POINTER(_vp)]),
+    'csd_unet_destroy': (None, [_vp]),
+    'csd_unet_num_params': (_i, [_vp]),
+    'csd_unet_param_info': (_i, [_vp, _i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_i),
+                                 ctypes.POINTER(_i64)]),
+    'csd_unet_set_param': (_i, [_vp, ctypes.c_char_p, _vp, _i64]),
+    'csd_unet_packed_bytes': (_sz, [_vp]),
+    'csd_unet_pack': (_i, [_vp, _vp, _vp]),
+    'csd_unet_workspace_bytes': (_sz, [_vp, _i]),
+    'csd_unet_forward': (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp]),
+    'csd_unet_stats': (_i, [_vp, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double),
+                            ctypes.POINTER(ctypes.c_double)]),
+    'csd_pc_scratch_bytes': (_sz, [_vp, _i]),
+    'csd_pc_sample': (_i, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _i, ctypes.POINTER(PCParams), _vp]),
+    'csd_update_scratch_bytes': (_sz, [_i]),
+    'csd_langevin_step': (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i64, _vp, _vp]),
+    'csd_reverse_diffusion_step': (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i64, _vp]),
+    'csd_randn': (_i, [_vp, _i64, _u64, _u64, _vp]),
+    'csd_scale_rows': (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp]),
+    'csd_groupnorm_scratch_bytes': (_sz, [_i, _i, _i, _i]),
+    'csd_groupnorm_act': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    'csd_conv_scratch_bytes': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    'csd_conv2d': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'csd_attention_scratch_bytes': (_sz, [_i, _i, _i, _i]),
+    'csd_attention': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'csd_upfirdn2d': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'csd_fused_bias_act': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _f, _f, _vp]),
+    'csd_nearest_up2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'csd_timestep_embedding': (_i, [_vp, _vp, _i, _i, _vp]),
+}
+
+
+def lib():
+    """The loaded library; raises RuntimeError (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libcsd_hip.so not found at %s - run `python -c "import __graft_entry__ as g; g.build()"` '
+                '(or `make -C %s`). There is no CPU fallback.' % (LIB_PATH, CSRC))
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)   # AttributeError here = header/library out of sync
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().csd_last_error().decode('utf-8', 'replace')
+        raise RuntimeError('libcsd_hip %s failed (status %d): %s' % (what, rc, msg))
+
+
+def ptr(t):
+    """Device address of a torch tensor (None -> NULL). The tensor must be contiguous fp32 on a GPU."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise RuntimeError('libcsd_hip needs contiguous tensors')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device=None):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu_tensor(t, name='tensor'):
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError('%s must be a float32 tensor on the MI355X (got %s on %s); the HIP path has no CPU '
+                           'fallback' % (name, getattr(t, 'dtype', type(t)), getattr(t, 'device', '?')))

@@ -1,0 +1,145 @@
+// common.h - shared declarations for libcsd_hip.so (gfx950 only; no CUDA/compat paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/csd.h"
+
+namespace csd {
+
+// thread-local last-error text behind csd_last_error()
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define CSD_CHECK_HIP(expr)                                                         \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      csd::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return CSD_ERR_HIP;                                                           \
+    }                                                                               \
+  } while (0)
+
+#define CSD_REQUIRE(cond, ...)                 \
+  do {                                         \
+    if (!(cond)) {                             \
+      csd::set_error(__VA_ARGS__);             \
+      return CSD_ERR_INVALID;                  \
+    }                                          \
+  } while (0)
+
+#define CSD_LAUNCH_CHECK()                                                          \
+  do {                                                                              \
+    hipError_t _e = hipGetLastError();                                              \
+    if (_e != hipSuccess) {                                                         \
+      csd::set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+      return CSD_ERR_HIP;                                                           \
+    }                                                                               \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------
+// Convolution as implicit GEMM on the fp32 matrix cores (conv_f32.hip)
+//   M = output pixels (B*OH*OW), N = Cout, K = taps*Cin.  Activations NHWC fp32.
+// ---------------------------------------------------------------------------------------
+struct ConvPlan {
+  // problem
+  int B, IH, IW, OH, OW;    // source / output spatial size (source = before optional x2 upsample)
+  int C0, C1;               // channels of source 0 / source 1 (virtual concat), Cin = C0 + C1
+  int Cout;                 // real output channels
+  int taps;                 // 1 or 9
+  int stride, pad, up;      // out(o) reads in((o*stride + r - pad) >> up)
+  // tiling (filled by conv_plan_tiles)
+  int KC;                   // channels per LDS chunk (8 or 16)
+  int NT;                   // 32-wide cout tiles per workgroup (1..3)
+  int TH, TW;               // output tile, TH*TW <= 128
+  int PH, PW;               // staged source patch
+  int tiles_x, tiles_y;     // tiles over (B*OH virtual rows, OW)
+  int n_groups;             // Cout tiles / NT
+  int CoutPad;              // n_groups*NT*32
+  size_t lds_bytes;
+};
+
+struct ConvArgs {
+  const float* src0;
+  const float* src1;
+  const float* wpack;       // [CoutPad/32][Cin/KC][taps][KC/8][64][4]
+  const float* bias;        // [CoutPad] or null
+  const float* temb;        // [B][temb_stride] (already offset to this layer's columns) or null
+  const float* res;         // NHWC residual [B,OH,OW,Cout] or null
+  const float* nscale;      // [B][Cin] GroupNorm scale (rstd*gamma) or null
+  const float* nshift;      // [B][Cin]
+  float* out;
+  int temb_stride;
+  int out_stride;           // channels of the destination tensor (NHWC) - ignored for nchw
+  int out_coff;             // channel offset inside the destination tensor
+  int out_nchw;             // 1: write [B,Cout,OH,OW]
+  int act;                  // activation applied after the norm prologue
+  float out_scale;          // multiplies the final value (1, or 1/sqrt(2) for skip_rescale)
+};
+
+int conv_plan_tiles(ConvPlan* p);                       // chooses KC/NT/tile, returns csd_status
+size_t conv_packed_floats(const ConvPlan& p);           // floats of the packed weight (+ slack)
+// pack one weight tensor: layout 0 = OIHW [Cout_src][Cin][kh][kw], 1 = NIN [Cin][Cout_src];
+// cout_off places it inside a wider (concatenated) packed tensor.
+int conv_pack_weight(const ConvPlan& p, const float* w, int layout, int cin_src, int cout_src, int cout_off,
+                     float* wpack, hipStream_t s);
+int conv_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// GroupNorm statistics -> per-(b,c) scale/shift consumed by the conv staging prologue (norm.hip)
+// ---------------------------------------------------------------------------------------
+struct GNPlan {
+  int B, HW, C0, C1, G, nchunk;
+};
+size_t gn_partial_bytes(const GNPlan& p);
+int gn_plan(GNPlan* p, int B, int HW, int C0, int C1, int G);
+int gn_stats_launch(const GNPlan& p, const float* src0, const float* src1, double* partial,
+                    hipStream_t s);
+int gn_finalize_launch(const GNPlan& p, const double* partial, const float* gamma, const float* beta,
+                       float eps, float* nscale, float* nshift, hipStream_t s);
+// stand-alone apply: y = act(x*scale + shift), NHWC
+int gn_apply_launch(const float* x, const float* nscale, const float* nshift, float* y, int B, int HW,
+                    int C, int act, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// attention core on NHWC qkv (attention.hip): qkv [B, L, ld] with q at +0, k at +C, v at +2C
+// ---------------------------------------------------------------------------------------
+int attention_launch(const float* qkv, int ld, float* out, int B, int L, int C, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// small kernels (elementwise.hip)
+// ---------------------------------------------------------------------------------------
+int timestep_embedding_launch(const float* t, float* out, int B, int dim, hipStream_t s);
+// out[b][n] = sum_k f(in[b][k]) * W[n][k] + bias[n];  f = act_in
+int linear_launch(const float* in, const float* W, const float* bias, float* out, int B, int K, int N,
+                  int act_in, hipStream_t s);
+// NCHW x (+ y (+ sigma*noise)) -> NHWC [B,H,W,Cpad], v -> 2v-1 unless centered
+int assemble_input_launch(const float* x, const float* y, const float* y_noise, float y_sigma,
+                          float* out, int B, int Cx, int Cy, int HW, int Cpad, int centered,
+                          hipStream_t s);
+int nchw_to_nhwc_launch(const float* in, float* out, int B, int C, int HW, int Cw, int ld, hipStream_t s);
+int nhwc_to_nchw_launch(const float* in, float* out, int B, int C, int HW, int Cstride, hipStream_t s);
+int avgpool2_launch(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
+int nearest_up2_nhwc_launch(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
+
+// sampler.hip
+// `net` may be the x-part of a wider network output: sample b starts at net + b*net_stride
+int sumsq_rows_launch(const float* net, int64_t net_stride, const float* z, double* partial, int B,
+                      int64_t per, int nchunk, hipStream_t s);
+int langevin_update_launch(float* x, float* x_mean, const float* net, int64_t net_stride, const float* z,
+                           const double* partial, int nchunk, float std, float snr, int B,
+                           int64_t per, hipStream_t s);
+int reverse_diffusion_update_launch(float* x, float* x_mean, const float* net, int64_t net_stride,
+                                    const float* z, float std, float G, int B, int64_t per, hipStream_t s);
+int randn_launch(float* out, int64_t n, uint64_t seed, uint64_t stream_id, hipStream_t s);
+int scale_rows_launch(float* out, const float* in, const float* scale, int divide, int B, int64_t per,
+                      hipStream_t s);
+int sumsq_nchunk(int64_t per);
+
+}  // namespace csd

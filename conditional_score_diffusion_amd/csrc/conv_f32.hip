@@ -1,0 +1,385 @@
+// conv_f32.hip - 3x3 / 1x1 convolution as an implicit GEMM on the gfx950 fp32 matrix cores.
+//
+// Replaces (reference, behaviour only): models/layers.py:119-132 ddpm_conv3x3, :100-105
+// ddpm_conv1x1, :555-564 NIN, :593-604 Upsample (nearest x2 fused into the gather), :607-629
+// Downsample ((0,1,0,1) pad + stride 2 fused), and the elementwise glue of ResnetBlockDDPM
+// (:658-675): the GroupNorm-affine + SiLU *prologue* runs while the source patch is staged into
+// LDS, and bias + time-embedding + residual are the *epilogue*.
+//
+// Mapping (one workgroup = 4 waves = 256 threads):
+//   M tile : TH x TW (<=128) output pixels of the "virtual tall image" [B*OH, OW] - image
+//            borders are handled by a per-lane 9-bit tap-validity mask, so a tile may straddle
+//            images (needed for the 5x5 / 10x10 / 20x20 levels).
+//   N tile : NT x 32 output channels; wave w owns pixels [32w, 32w+32) x all NT*32 channels.
+//   K      : Cin in chunks of KC channels x `taps`; per chunk the (PH x PW x KC) source patch is
+//            staged ONCE into LDS (halo reuse across the 9 taps), double buffered, global->reg
+//            loads issued before the MFMA block and written to LDS after it.
+//   MFMA   : v_mfma_f32_32x32x2_f32 (A: 32 pixels x 2 channels, B: 2 channels x 32 couts).
+//            Exact fp32 (bitwise an fmaf chain), 157 TFLOP/s peak on MI355X.
+//   B operand: weights are pre-packed in fragment order, so each lane fetches one 16-byte
+//            vector per 4 MFMAs straight from L2/L1 (1 KiB per wave-instruction, fully coalesced)
+//            - no LDS traffic for weights; the stream is linear and prefetched one step ahead.
+#include "common.h"
+
+namespace csd {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define CONV_THREADS 256
+#define CONV_MAX_SLOTS 9     // float4 staging slots per thread per chunk
+#define CONV_PAD 4           // floats of padding per staged pixel (LDS bank spread)
+
+struct ConvKArgs {
+  ConvArgs a;
+  int B, IH, IW, OH, OW, C0, C1, Cout;
+  int stride, pad, up;
+  int TH, TW, PH, PW, tiles_x, n_groups, nblocks;
+  int nck;                  // number of K chunks
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case CSD_ACT_SWISH: return v / (1.0f + expf(-v));
+    case CSD_ACT_RELU: return v > 0.f ? v : 0.f;
+    case CSD_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+    case CSD_ACT_ELU: return v > 0.f ? v : expm1f(v);
+    default: return v;
+  }
+}
+
+template <int NT, int TAPS, int KC>
+__global__ __launch_bounds__(CONV_THREADS) void conv_f32_kernel(const ConvKArgs k) {
+  constexpr int KS = (TAPS == 9) ? 3 : 1;
+  constexpr int PS = KC + CONV_PAD;          // floats per staged pixel
+  constexpr int N4 = KC / 4;                 // float4 per staged pixel
+  constexpr int KK = KC / 8;                 // 8-channel MFMA groups per chunk
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int half = lane >> 5;
+
+  // ---- XCD-aware block -> work mapping: consecutive work items (same pixel tile, different
+  // cout group) stay on one XCD so its L2 serves the shared source patch (guide T1) ----
+  int w;
+  {
+    const int bid = blockIdx.x, nb = k.nblocks;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int ng = w % k.n_groups;
+  const int tile = w / k.n_groups;
+  const int tile_y = tile / k.tiles_x;
+  const int tile_x = tile - tile_y * k.tiles_x;
+  const int ov0 = tile_y * k.TH;             // first virtual output row of the tile
+  const int ox0 = tile_x * k.TW;
+
+  const int S = k.stride, P = k.pad, U = k.up;
+  const int prow0 = (ov0 * S - P) >> U;      // arithmetic shift == floor
+  const int pcol0 = (ox0 * S - P) >> U;
+  const int patch_floats = k.PH * k.PW * PS;
+  float* const buf0 = smem;
+  float* const buf1 = smem + patch_floats;
+  int* const otab = reinterpret_cast<int*>(smem + 2 * patch_floats);   // [128] output pixel index
+  int* const btab = otab + 128;                                        // [128] batch index
+
+  // ---- per-lane pixel (A-operand row) ----
+  int off[TAPS];
+  unsigned vmask = 0;
+  {
+    const int m = wave * 32 + (lane & 31);
+    const int ty = m / k.TW;
+    const int tx = m - ty * k.TW;
+    const int ov = ov0 + ty, ox = ox0 + tx;
+    const bool mv = (m < k.TH * k.TW) && (ov < k.B * k.OH) && (ox < k.OW);
+    const int b = ov / k.OH;
+    const int oy = ov - b * k.OH;
+    if (half == 0) {
+      otab[m] = mv ? ov * k.OW + ox : -1;
+      btab[m] = mv ? b : 0;
+    }
+    const int IHe = k.IH << U, IWe = k.IW << U;
+#pragma unroll
+    for (int r = 0; r < KS; ++r) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int iy = oy * S + r - P, ix = ox * S + s - P;
+        const bool v = mv && iy >= 0 && iy < IHe && ix >= 0 && ix < IWe;
+        const int pr = ((ov * S + r - P) >> U) - prow0;
+        const int pc = ((ox * S + s - P) >> U) - pcol0;
+        off[r * KS + s] = v ? (pr * k.PW + pc) * PS + half * 4 : 0;
+        vmask |= (v ? 1u : 0u) << (r * KS + s);
+      }
+    }
+  }
+
+  // ---- staging slots: which float4 of the patch this thread moves (same for every chunk) ----
+  const int total4 = k.PH * k.PW * N4;
+  const int Cin = k.C0 + k.C1;
+
+  float4 stage[CONV_MAX_SLOTS];
+  auto stage_load = [&](int ck) {
+    const int cb = ck * KC;
+    const float* src;
+    int Cs, coff;
+    if (cb < k.C0) { src = k.a.src0; Cs = k.C0; coff = cb; }
+    else { src = k.a.src1; Cs = k.C1; coff = cb - k.C0; }
+#pragma unroll
+    for (int j = 0; j < CONV_MAX_SLOTS; ++j) {
+      const int e = tid + j * CONV_THREADS;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < total4) {
+        const int pix = e / N4;
+        const int c4 = e - pix * N4;
+        const int pr = pix / k.PW;
+        const int pc = pix - pr * k.PW;
+        const int vr = prow0 + pr, col = pcol0 + pc;
+        if (vr >= 0 && vr < k.B * k.IH && col >= 0 && col < k.IW) {
+          v = *reinterpret_cast<const float4*>(src + ((size_t)vr * k.IW + col) * Cs + coff + c4 * 4);
+          if (k.a.nscale) {
+            const int b = vr / k.IH;
+            const float4 sc = *reinterpret_cast<const float4*>(k.a.nscale + (size_t)b * Cin + cb + c4 * 4);
+            const float4 sh = *reinterpret_cast<const float4*>(k.a.nshift + (size_t)b * Cin + cb + c4 * 4);
+            v.x = act_apply(v.x * sc.x + sh.x, k.a.act);
+            v.y = act_apply(v.y * sc.y + sh.y, k.a.act);
+            v.z = act_apply(v.z * sc.z + sh.z, k.a.act);
+            v.w = act_apply(v.w * sc.w + sh.w, k.a.act);
+          }
+        }
+      }
+      stage[j] = v;
+    }
+  };
+  auto stage_write = [&](float* buf) {
+#pragma unroll
+    for (int j = 0; j < CONV_MAX_SLOTS; ++j) {
+      const int e = tid + j * CONV_THREADS;
+      if (e < total4) {
+        const int pix = e / N4;
+        const int c4 = e - pix * N4;
+        *reinterpret_cast<float4*>(buf + pix * PS + c4 * 4) = stage[j];
+      }
+    }
+  };
+
+  // ---- accumulators and the linear weight stream ----
+  floatx16 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+  const size_t steps_per_tile = (size_t)k.nck * TAPS * KK;     // 1 KiB (256 floats) per step
+  const float* wp[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+    wp[n] = k.a.wpack + ((size_t)(ng * NT + n) * steps_per_tile) * 256 + lane * 4;
+
+  float4 bcur[NT], bnxt[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) bcur[n] = *reinterpret_cast<const float4*>(wp[n]);
+
+  stage_load(0);
+  stage_write(buf0);
+  __syncthreads();
+
+  for (int ck = 0; ck < k.nck; ++ck) {
+    const float* buf = (ck & 1) ? buf1 : buf0;
+    if (ck + 1 < k.nck) stage_load(ck + 1);       // global loads fly under the MFMA block
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const bool v = (vmask >> tap) & 1u;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        // prefetch next step's B fragments (stream is linear; packed buffer has 1 step of slack)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          wp[n] += 256;
+          bnxt[n] = *reinterpret_cast<const float4*>(wp[n]);
+        }
+        float4 a4 = *reinterpret_cast<const float4*>(buf + off[tap] + kk * 8);
+        if (!v) a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bcur[n].x, acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bcur[n].y, acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bcur[n].z, acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bcur[n].w, acc[n], 0, 0, 0);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bcur[n] = bnxt[n];
+      }
+    }
+    if (ck + 1 < k.nck) stage_write((ck & 1) ? buf0 : buf1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + time embedding + residual, NHWC (or NCHW) store ----
+  const int ohw = k.OH * k.OW;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int col = (ng * NT + n) * 32 + (lane & 31);
+    if (col >= k.Cout) continue;
+    const float bv = k.a.bias ? k.a.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int m = wave * 32 + row;
+      const int o = otab[m];
+      if (o < 0) continue;
+      float val = acc[n][r] + bv;
+      const int b = btab[m];
+      if (k.a.temb) val += k.a.temb[(size_t)b * k.a.temb_stride + col];
+      if (k.a.res) val += k.a.res[(size_t)o * k.Cout + col];
+      val *= k.a.out_scale;
+      if (k.a.out_nchw)
+        k.a.out[((size_t)b * k.Cout + col) * ohw + (o - b * ohw)] = val;
+      else
+        k.a.out[(size_t)o * k.a.out_stride + k.a.out_coff + col] = val;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int in_coord(int o, int r, int S, int P, int U) {
+  int v = o * S + r - P;
+  return v >= 0 ? (v >> U) : -((-v + (1 << U) - 1) >> U);   // floor
+}
+
+int conv_plan_tiles(ConvPlan* p) {
+  const int Cin = p->C0 + p->C1;
+  CSD_REQUIRE(p->taps == 1 || p->taps == 9, "conv: taps must be 1 or 9 (got %d)", p->taps);
+  CSD_REQUIRE(Cin % 8 == 0 && p->C0 % 8 == 0, "conv: Cin (%d+%d) must be a multiple of 8", p->C0, p->C1);
+  CSD_REQUIRE((p->IH << p->up) == p->OH * p->stride && (p->IW << p->up) == p->OW * p->stride,
+              "conv: size mismatch IH=%d IW=%d OH=%d OW=%d stride=%d up=%d", p->IH, p->IW, p->OH,
+              p->OW, p->stride, p->up);
+  p->KC = (p->C0 % 16 == 0 && p->C1 % 16 == 0) ? 16 : 8;
+  const int ntiles = cdiv(p->Cout, 32);
+  p->NT = (ntiles % 3 == 0) ? 3 : (ntiles % 2 == 0) ? 2 : 1;
+  p->n_groups = ntiles / p->NT;
+  p->CoutPad = ntiles * 32;
+  // tile: TW divides OW when possible; maximise covered pixels, then minimise the staged patch.
+  // Patch extents are the worst case over tile origins (the +1 covers odd origins in `up` mode).
+  const int KS = p->taps == 9 ? 3 : 1;
+  auto extent = [&](int t) {
+    return in_coord(t - 1, KS - 1, p->stride, p->pad, p->up) - in_coord(0, 0, p->stride, p->pad, p->up) + 1 +
+           (p->up ? 1 : 0);
+  };
+  int best_tw = 0, best_th = 0, best_cov = -1, best_patch = 1 << 30;
+  for (int tw = 1; tw <= 32 && tw <= p->OW; ++tw) {
+    if (p->OW % tw != 0 && !(tw == 32 && p->OW > 32)) continue;
+    for (int th = 128 / tw; th >= 1; --th) {
+      const int patch = extent(th) * extent(tw);
+      if (patch * (p->KC / 4) > CONV_MAX_SLOTS * CONV_THREADS) continue;
+      const int cov = th * tw;
+      if (cov > best_cov || (cov == best_cov && patch < best_patch)) {
+        best_cov = cov; best_patch = patch; best_tw = tw; best_th = th;
+      }
+      break;   // smaller th only lowers coverage for this tw
+    }
+  }
+  CSD_REQUIRE(best_tw > 0, "conv: no feasible tile for OW=%d", p->OW);
+  p->TW = best_tw;
+  p->TH = best_th;
+  p->PH = extent(p->TH);
+  p->PW = extent(p->TW);
+  p->tiles_x = cdiv(p->OW, p->TW);
+  p->tiles_y = cdiv(p->B * p->OH, p->TH);
+  p->lds_bytes = (size_t)2 * p->PH * p->PW * (p->KC + CONV_PAD) * sizeof(float) + 256 * sizeof(int);
+  CSD_REQUIRE(p->PH * p->PW * (p->KC / 4) <= CONV_MAX_SLOTS * CONV_THREADS, "conv: patch too large");
+  CSD_REQUIRE(p->lds_bytes <= 160 * 1024, "conv: LDS budget exceeded");
+  return CSD_OK;
+}
+
+size_t conv_packed_floats(const ConvPlan& p) {
+  const int Cin = p.C0 + p.C1;
+  // + one step (256 floats) of slack per tensor: the kernel prefetches one step past the end
+  return (size_t)(p.CoutPad / 32) * (Cin / 8) * p.taps * 256 + 256;
+}
+
+__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wpack, int layout,
+                                 int cin_src, int cout_src, int cout_off, int taps, int KC, int nck,
+                                 int nt_lo, int nt_hi) {
+  // one thread per packed float of the n-tiles [nt_lo, nt_hi)
+  const int KK = KC / 8;
+  const size_t per_tile = (size_t)nck * taps * KK * 256;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = per_tile * (nt_hi - nt_lo);
+  if (idx >= total) return;
+  size_t rem = idx;
+  const int nt = nt_lo + (int)(rem / per_tile); rem %= per_tile;
+  const int ck = (int)(rem / ((size_t)taps * KK * 256)); rem %= (size_t)taps * KK * 256;
+  const int tap = (int)(rem / (KK * 256)); rem %= (size_t)KK * 256;
+  const int kk = (int)(rem / 256); rem %= 256;
+  const int lane = (int)(rem / 4), q = (int)(rem % 4);
+  const int cout = nt * 32 + (lane & 31) - cout_off;
+  const int cin = ck * KC + kk * 8 + (lane >> 5) * 4 + q;
+  // padding rows/columns stay zero: the buffer is cleared before the first tensor is packed
+  if (cout >= 0 && cout < cout_src && cin < cin_src) {
+    const float v = (layout == 0) ? w[((size_t)cout * cin_src + cin) * taps + tap] : w[(size_t)cin * cout_src + cout];
+    wpack[(size_t)nt * per_tile + (idx % per_tile)] = v;
+  }
+}
+
+__global__ void conv_pack_zero_kernel(float* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
+int conv_pack_weight(const ConvPlan& p, const float* w, int layout, int cin_src, int cout_src, int cout_off,
+                     float* wpack, hipStream_t s) {
+  const int Cin = p.C0 + p.C1;
+  const int nck = Cin / p.KC;
+  const size_t nflt = conv_packed_floats(p);
+  if (cout_off == 0) {   // first (or only) tensor of this packed buffer: clear padding + slack
+    hipLaunchKernelGGL(conv_pack_zero_kernel, dim3((unsigned)cdiv64(nflt, 256)), dim3(256), 0, s, wpack, nflt);
+    CSD_LAUNCH_CHECK();
+  }
+  const int nt_lo = cout_off / 32, nt_hi = cdiv(cout_off + cout_src, 32);
+  const size_t total = (size_t)nck * p.taps * (p.KC / 8) * 256 * (nt_hi - nt_lo);
+  hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w, wpack, layout,
+                     cin_src, cout_src, cout_off, p.taps, p.KC, nck, nt_lo, nt_hi);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+template <int NT, int TAPS, int KC>
+static int launch_one(const ConvKArgs& k, size_t lds, int nblocks, hipStream_t s) {
+  auto kern = conv_f32_kernel<NT, TAPS, KC>;
+  static bool attr_set = false;   // per instantiation
+  if (!attr_set) {
+    CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(CONV_THREADS), lds, s, k);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+int conv_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s) {
+  ConvKArgs k;
+  k.a = a;
+  k.B = p.B; k.IH = p.IH; k.IW = p.IW; k.OH = p.OH; k.OW = p.OW;
+  k.C0 = p.C0; k.C1 = p.C1; k.Cout = p.Cout;
+  k.stride = p.stride; k.pad = p.pad; k.up = p.up;
+  k.TH = p.TH; k.TW = p.TW; k.PH = p.PH; k.PW = p.PW;
+  k.tiles_x = p.tiles_x; k.n_groups = p.n_groups;
+  k.nblocks = p.tiles_x * p.tiles_y * p.n_groups;
+  k.nck = (p.C0 + p.C1) / p.KC;
+#define CSD_CONV_CASE(NT_, TAPS_, KC_) \
+  if (p.NT == NT_ && p.taps == TAPS_ && p.KC == KC_) return launch_one<NT_, TAPS_, KC_>(k, p.lds_bytes, k.nblocks, s);
+  CSD_CONV_CASE(1, 9, 8) CSD_CONV_CASE(2, 9, 8) CSD_CONV_CASE(3, 9, 8)
+  CSD_CONV_CASE(1, 9, 16) CSD_CONV_CASE(2, 9, 16) CSD_CONV_CASE(3, 9, 16)
+  CSD_CONV_CASE(1, 1, 8) CSD_CONV_CASE(2, 1, 8) CSD_CONV_CASE(3, 1, 8)
+  CSD_CONV_CASE(1, 1, 16) CSD_CONV_CASE(2, 1, 16) CSD_CONV_CASE(3, 1, 16)
+#undef CSD_CONV_CASE
+  set_error("conv: no kernel for NT=%d taps=%d KC=%d", p.NT, p.taps, p.KC);
+  return CSD_ERR_INVALID;
+}
+
+}  // namespace csd

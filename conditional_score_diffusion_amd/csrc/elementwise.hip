@@ -1,0 +1,350 @@
+// elementwise.hip - the small HBM-/latency-bound kernels around the contraction kernels:
+// time embedding + dense layers, boundary layout changes (NCHW <-> NHWC), and the reference's
+// two native ops (upfirdn2d, fused_bias_act) re-written for gfx950.
+#include "common.h"
+
+namespace csd {
+
+__device__ __forceinline__ float ew_act(float v, int act) {
+  switch (act) {
+    case CSD_ACT_SWISH: return v / (1.0f + expf(-v));
+    case CSD_ACT_RELU: return v > 0.f ? v : 0.f;
+    case CSD_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+    case CSD_ACT_ELU: return v > 0.f ? v : expm1f(v);
+    default: return v;
+  }
+}
+
+// ---- get_timestep_embedding (models/layers.py:524-538) ------------------------------------
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out, int B,
+                                          int dim) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * dim) return;
+  const int b = i / dim, j = i - b * dim;
+  float v = 0.f;   // odd dim: last column zero-padded
+  if (j < 2 * half) {
+    const int kidx = j < half ? j : j - half;
+    // emb = log(10000)/(half-1) in Python double, then exp(arange * -emb), t*emb, sin/cos in fp32.
+    // Each fp32 transcendental is evaluated in fp64 and rounded once (= correctly rounded), the
+    // closest a different libm can get to the CPU reference's own <=1-ulp results: at t~999 one
+    // ulp of the frequency already moves sin() by ~5e-5.
+    const float e = (float)kidx * -(float)(9.210340371976184 / (double)(half - 1));
+    const float w = (float)exp((double)e);
+    const float arg = t[b] * w;
+    v = j < half ? (float)sin((double)arg) : (float)cos((double)arg);
+  }
+  out[i] = v;
+}
+
+int timestep_embedding_launch(const float* t, float* out, int B, int dim, hipStream_t s) {
+  CSD_REQUIRE(dim >= 4, "timestep_embedding: dim=%d too small", dim);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv(B * dim, 256)), dim3(256), 0, s, t, out, B, dim);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+// ---- nn.Linear on [B, K] (temb MLP models/ddpm.py:155-159; Dense_0 models/layers.py:666) ----
+// One wave per output feature n: the weight row stays in registers, the B inputs stream past.
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ in, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                     int B, int K, int N, int act_in) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float* wrow = W + (size_t)n * K;
+  const float bv = bias ? bias[n] : 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* x = in + (size_t)b * K;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc += ew_act(x[k], act_in) * wrow[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) out[(size_t)b * N + n] = acc + bv;
+  }
+}
+
+int linear_launch(const float* in, const float* W, const float* bias, float* out, int B, int K, int N,
+                  int act_in, hipStream_t s) {
+  hipLaunchKernelGGL(linear_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, in, W, bias, out, B, K, N, act_in);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+// ---- network input: cat(x, y [+ sigma*z]) , 2v-1, NCHW -> NHWC padded to Cpad channels --------
+// (models/ddpm.py:163-168,283; sampling/conditional.py:104-110)
+__global__ void assemble_input_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                      const float* __restrict__ yn, float ysig, float* __restrict__ out,
+                                      int Cx, int Cy, int HW, int Cpad, int centered, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i / Cpad;             // b*HW + p
+    const int c = (int)(i - pix * Cpad);
+    const size_t b = pix / HW;
+    const size_t p = pix - b * HW;
+    float v = 0.f;
+    if (c < Cx) {
+      v = x[(b * Cx + c) * HW + p];
+      if (!centered) v = 2.f * v - 1.f;
+    } else if (c < Cx + Cy) {
+      const size_t j = (b * Cy + (c - Cx)) * HW + p;
+      v = y[j];
+      if (yn) v = v + yn[j] * ysig;
+      if (!centered) v = 2.f * v - 1.f;
+    }
+    out[i] = v;
+  }
+}
+
+int assemble_input_launch(const float* x, const float* y, const float* y_noise, float y_sigma, float* out,
+                          int B, int Cx, int Cy, int HW, int Cpad, int centered, hipStream_t s) {
+  const size_t total = (size_t)B * HW * Cpad;
+  const int grid = (int)std::min<size_t>(cdiv64(total, 256), 8192);
+  hipLaunchKernelGGL(assemble_input_kernel, dim3(grid), dim3(256), 0, s, x, y, y_noise, y_sigma, out, Cx, Cy,
+                     HW, Cpad, centered, total);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+// ---- layout changes at the per-operator C-ABI boundary (LDS-tiled transposes) -----------------
+// in [B, C, HW] -> out [B, HW, ld]: channels [0, Cw) are written (zeros beyond C)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           int C, int HW, int Cpad, int ld) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, p = p0 + tx;
+    tile[j][tx] = (c < C && p < HW) ? in[((size_t)b * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int p = p0 + j, c = c0 + tx;
+    if (p < HW && c < Cpad) out[((size_t)b * HW + p) * ld + c] = tile[tx][j];
+  }
+}
+
+int nchw_to_nhwc_launch(const float* in, float* out, int B, int C, int HW, int Cw, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), cdiv(Cw, 32), B), dim3(256), 0, s, in, out, C,
+                     HW, Cw, ld);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+// in [B, HW, Cstride] (first C channels) -> out [B, C, HW]
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           int C, int HW, int Cstride) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int p = p0 + j, c = c0 + tx;
+    tile[j][tx] = (c < C && p < HW) ? in[((size_t)b * HW + p) * Cstride + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, p = p0 + tx;
+    if (c < C && p < HW) out[((size_t)b * C + c) * HW + p] = tile[tx][j];
+  }
+}
+
+int nhwc_to_nchw_launch(const float* in, float* out, int B, int C, int HW, int Cstride, hipStream_t s) {
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), B), dim3(256), 0, s, in, out, C, HW,
+                     Cstride);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+// ---- resampling without convolution (resamp_with_conv=False: models/layers.py:601,626) --------
+__global__ void avgpool2_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C,
+                                size_t total4) {
+  const int C4 = C >> 2, OH = H >> 1, OW = W >> 1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH);
+    const size_t b = r / OH;
+    const float4* p = reinterpret_cast<const float4*>(in) + ((b * H + 2 * oy) * W + 2 * ox) * C4 + c4;
+    const float4 a = p[0], bq = p[C4], c = p[(size_t)W * C4], d = p[(size_t)W * C4 + C4];
+    float4 o;
+    o.x = (a.x + bq.x + c.x + d.x) * 0.25f;
+    o.y = (a.y + bq.y + c.y + d.y) * 0.25f;
+    o.z = (a.z + bq.z + c.z + d.z) * 0.25f;
+    o.w = (a.w + bq.w + c.w + d.w) * 0.25f;
+    reinterpret_cast<float4*>(out)[i] = o;
+  }
+}
+
+int avgpool2_launch(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
+  const size_t total4 = (size_t)B * (H / 2) * (W / 2) * C / 4;
+  const int grid = (int)std::min<size_t>(cdiv64(total4, 256), 8192);
+  hipLaunchKernelGGL(avgpool2_kernel, dim3(grid), dim3(256), 0, s, in, out, H, W, C, total4);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+__global__ void nearest_up2_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                        int C, size_t total4) {
+  const int C4 = C >> 2, OH = H * 2, OW = W * 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH);
+    const size_t b = r / OH;
+    reinterpret_cast<float4*>(out)[i] =
+        reinterpret_cast<const float4*>(in)[((b * H + (oy >> 1)) * W + (ox >> 1)) * C4 + c4];
+  }
+}
+
+int nearest_up2_nhwc_launch(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
+  const size_t total4 = (size_t)B * H * 2 * W * 2 * C / 4;
+  const int grid = (int)std::min<size_t>(cdiv64(total4, 256), 8192);
+  hipLaunchKernelGGL(nearest_up2_nhwc_kernel, dim3(grid), dim3(256), 0, s, in, out, H, W, C, total4);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+// ---- nearest x2 on NCHW (C-ABI csd_nearest_up2) ---------------------------------------------------
+__global__ void nearest_up2_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                        size_t total) {
+  const int OW = 2 * W, OH = 2 * H;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    size_t r = i / OW;
+    const int oy = (int)(r % OH);
+    const size_t nc = r / OH;
+    out[i] = in[(nc * H + (oy >> 1)) * W + (ox >> 1)];
+  }
+}
+
+// ---- upfirdn2d (op/upfirdn2d_kernel.cu:107-207; semantics of op/upfirdn2d.py:161-202) --------------
+// out[n,c,oy,ox] = sum_{ky,kx} xpad_up[oy*down_y + ky, ox*down_x + kx] * kflip[ky,kx], where xpad_up
+// is x zero-stuffed by `up` and padded by (pad0, pad1) (negative pads crop).  One workgroup computes
+// a 16x64 output tile of one (n,c) plane; the source window and the flipped FIR taps are staged in
+// LDS; fp32 accumulate (the reference's half path accumulates in half - SURVEY.md App. B).
+#define UFD_TH 16
+#define UFD_TW 64
+__global__ __launch_bounds__(256) void upfirdn2d_kernel(const float* __restrict__ x, const float* __restrict__ kern,
+                                                        float* __restrict__ out, int H, int W, int OH, int OW,
+                                                        int kh, int kw, int upx, int upy, int dnx, int dny,
+                                                        int px0, int py0, int tiles_x) {
+  extern __shared__ float sm[];
+  float* sk = sm;                 // [kh*kw] flipped taps
+  float* sx = sm + kh * kw;       // source window
+  const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+  const size_t plane = blockIdx.y;
+  const int oy0 = tile_y * UFD_TH, ox0 = tile_x * UFD_TW;
+  // window of source rows/cols that can contribute to this tile
+  auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+  const int my0 = oy0 * dny - py0, mx0 = ox0 * dnx - px0;             // first up-sampled coord
+  const int iy0 = fdiv(my0, upy);                                    // floor: safe lower bound
+  const int ix0 = fdiv(mx0, upx);
+  const int wh = ((UFD_TH - 1) * dny + kh - 1) / upy + 2;
+  const int ww = ((UFD_TW - 1) * dnx + kw - 1) / upx + 2;
+  for (int i = threadIdx.x; i < kh * kw; i += 256) sk[i] = kern[kh * kw - 1 - i];
+  const float* xp = x + plane * H * W;
+  for (int i = threadIdx.x; i < wh * ww; i += 256) {
+    const int ry = i / ww, rx = i - ry * ww;
+    const int iy = iy0 + ry, ix = ix0 + rx;
+    sx[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xp[(size_t)iy * W + ix] : 0.f;
+  }
+  __syncthreads();
+  float* op = out + plane * OH * OW;
+  for (int i = threadIdx.x; i < UFD_TH * UFD_TW; i += 256) {
+    const int ty = i / UFD_TW, tx = i - ty * UFD_TW;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy >= OH || ox >= OW) continue;
+    float acc = 0.f;
+    for (int ky = 0; ky < kh; ++ky) {
+      const int my = oy * dny + ky - py0;          // coordinate in the zero-stuffed image
+      if (my < 0 || my % upy != 0) continue;
+      const int iy = my / upy - iy0;
+      for (int kx = 0; kx < kw; ++kx) {
+        const int mx = ox * dnx + kx - px0;
+        if (mx < 0 || mx % upx != 0) continue;
+        const int ix = mx / upx - ix0;
+        acc += sx[iy * ww + ix] * sk[ky * kw + kx];
+      }
+    }
+    op[(size_t)oy * OW + ox] = acc;
+  }
+}
+
+// ---- fused_bias_act (op/fused_bias_act_kernel.cu:18-49) -----------------------------------------
+__global__ void fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b,
+                                      const float* __restrict__ ref, float* __restrict__ out, size_t numel,
+                                      int C, size_t inner, int act, int grad, float alpha, float scale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float v = x[i];
+    if (b) v += b[(i / inner) % C];
+    const float r = ref ? ref[i] : 0.f;
+    float y;
+    if (act == 3) {   // leaky relu
+      if (grad == 0) y = (v > 0.f ? v : v * alpha) * scale;
+      else if (grad == 1) y = (r > 0.f ? v : v * alpha) * scale;
+      else y = 0.f;
+    } else {          // linear
+      y = (grad == 2) ? 0.f : v * scale;
+    }
+    out[i] = y;
+  }
+}
+
+}  // namespace csd
+
+// =================================================================================================
+// C ABI for the stand-alone operators
+// =================================================================================================
+using namespace csd;
+
+extern "C" int csd_upfirdn2d(const float* x, const float* kernel, float* out, int N, int C, int H, int W, int kh,
+                             int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                             int pad_y0, int pad_y1, void* stream) {
+  CSD_REQUIRE(up_x >= 1 && up_y >= 1 && down_x >= 1 && down_y >= 1, "upfirdn2d: up/down must be >= 1");
+  const int OH = (H * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;
+  const int OW = (W * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
+  CSD_REQUIRE(OH >= 1 && OW >= 1, "upfirdn2d: empty output");
+  const int tiles_x = cdiv(OW, UFD_TW), tiles_y = cdiv(OH, UFD_TH);
+  const int wh = ((UFD_TH - 1) * down_y + kh - 1) / up_y + 2;
+  const int ww = ((UFD_TW - 1) * down_x + kw - 1) / up_x + 2;
+  const size_t lds = (size_t)(kh * kw + wh * ww) * sizeof(float);
+  CSD_REQUIRE(lds <= 64 * 1024, "upfirdn2d: filter/window too large for the tiled kernel");
+  hipLaunchKernelGGL(upfirdn2d_kernel, dim3(tiles_x * tiles_y, N * C), dim3(256), lds, (hipStream_t)stream, x,
+                     kernel, out, H, W, OH, OW, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, tiles_x);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+extern "C" int csd_fused_bias_act(const float* x, const float* bias, const float* ref, float* out, int64_t numel,
+                                  int C, int64_t inner, int act, int grad, float alpha, float scale,
+                                  void* stream) {
+  CSD_REQUIRE(act == 1 || act == 3, "fused_bias_act: act must be 1 (linear) or 3 (lrelu)");
+  CSD_REQUIRE(grad >= 0 && grad <= 2, "fused_bias_act: grad must be 0..2");
+  if (numel == 0) return CSD_OK;
+  const int grid = (int)std::min<int64_t>(cdiv64(numel, 256), 8192);
+  hipLaunchKernelGGL(fused_bias_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bias, ref, out,
+                     (size_t)numel, C, (size_t)inner, act, grad, alpha, scale);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+extern "C" int csd_nearest_up2(const float* x, float* out, int N, int C, int H, int W, void* stream) {
+  const size_t total = (size_t)N * C * 4 * H * W;
+  if (total == 0) return CSD_OK;
+  const int grid = (int)std::min<size_t>(cdiv64(total, 256), 8192);
+  hipLaunchKernelGGL(nearest_up2_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, out, H, W, total);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+extern "C" int csd_timestep_embedding(const float* t, float* out, int B, int dim, void* stream) {
+  return timestep_embedding_launch(t, out, B, dim, (hipStream_t)stream);
+}

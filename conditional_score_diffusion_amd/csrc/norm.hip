@@ -1,0 +1,179 @@
+// norm.hip - GroupNorm statistics on NHWC fp32 (HBM-bound streaming reduction).
+//
+// Replaces nn.GroupNorm(num_groups, C, eps=1e-6) as used at models/layers.py:571,638,646 and
+// models/ddpm.py:145.  The normalisation itself is NOT a separate pass: gn_finalize emits a
+// per-(sample, channel) scale/shift pair which the consuming convolution applies (together with
+// the SiLU) while staging its source patch (conv_f32.hip) - the normalised tensor never
+// touches HBM.  gn_apply exists for the stand-alone csd_groupnorm_act() entry point only.
+//
+//   pass 1  gn_stats    : grid (nchunk, B); each workgroup streams a slab of pixels x ALL
+//                         channels (float4, fully coalesced rows of the NHWC tensor) and keeps
+//                         per-channel sum / sum-of-squares in fp64 registers (fp64 accumulate is
+//                         free under an HBM-bound stream and makes E[x^2]-E[x]^2 safe), then
+//                         folds them to per-group partials - deterministic, no atomics.
+//   pass 2  gn_finalize : grid B; folds the nchunk partials, writes scale = rstd*gamma and
+//                         shift = beta - mean*rstd*gamma.
+// The source may be a virtual channel-concat of two tensors (skip connections, models/ddpm.py:197)
+// - groups may straddle the seam, which is why statistics are kept per channel first.
+#include "common.h"
+
+namespace csd {
+
+#define GN_THREADS 256
+
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
+    const float* __restrict__ src0, const float* __restrict__ src1, double* __restrict__ partial,
+    int HW, int C0, int C1, int G, int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) double sred[];   // [2][C]
+  const int C = C0 + C1;
+  const int C4 = C >> 2;
+  const int rows = GN_THREADS / C4;            // pixel rows processed per sweep (>=1: C <= 1024)
+  const int tid = threadIdx.x;
+  const int row = tid / C4;
+  const int c4 = tid - row * C4;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int per = (HW + nchunk - 1) / nchunk;
+  const int p0 = chunk * per;
+  const int p1 = min(HW, p0 + per);
+  const bool active = row < rows;
+
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (active) {
+    const int c = c4 * 4;
+    const float* src;
+    int Cs, coff;
+    if (c < C0) { src = src0; Cs = C0; coff = c; }
+    else { src = src1; Cs = C1; coff = c - C0; }
+    const float* base = src + (size_t)b * HW * Cs + coff;
+    for (int p = p0 + row; p < p1; p += rows) {
+      const float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * Cs);
+      s[0] += v.x; q[0] += (double)v.x * v.x;
+      s[1] += v.y; q[1] += (double)v.y * v.y;
+      s[2] += v.z; q[2] += (double)v.z * v.z;
+      s[3] += v.w; q[3] += (double)v.w * v.w;
+    }
+  }
+  // fold the `rows` row-partials per channel in a fixed order (deterministic)
+  double* ssum = sred;
+  double* ssq = sred + C;
+  for (int r = 0; r < rows; ++r) {
+    if (active && row == r) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = c4 * 4 + j;
+        if (r == 0) { ssum[c] = s[j]; ssq[c] = q[j]; }
+        else { ssum[c] += s[j]; ssq[c] += q[j]; }
+      }
+    }
+    __syncthreads();
+  }
+  const int cpg = C / G;
+  for (int g = tid; g < G; g += GN_THREADS) {
+    double a = 0, bsum = 0;
+    for (int j = 0; j < cpg; ++j) { a += ssum[g * cpg + j]; bsum += ssq[g * cpg + j]; }
+    double* dst = partial + (((size_t)b * nchunk + chunk) * G + g) * 2;
+    dst[0] = a;
+    dst[1] = bsum;
+  }
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float* __restrict__ nscale,
+                                   float* __restrict__ nshift, int HW, int C, int G, int nchunk) {
+  const int b = blockIdx.x;
+  const int cpg = C / G;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int g = c / cpg;
+    double s = 0, q = 0;
+    for (int k = 0; k < nchunk; ++k) {
+      const double* p = partial + (((size_t)b * nchunk + k) * G + g) * 2;
+      s += p[0];
+      q += p[1];
+    }
+    const double n = (double)HW * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = rstd * gamma[c];
+    nscale[(size_t)b * C + c] = sc;
+    nshift[(size_t)b * C + c] = beta[c] - (float)mean * sc;
+  }
+}
+
+__device__ __forceinline__ float gn_act(float v, int act) {
+  switch (act) {
+    case CSD_ACT_SWISH: return v / (1.0f + expf(-v));
+    case CSD_ACT_RELU: return v > 0.f ? v : 0.f;
+    case CSD_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+    case CSD_ACT_ELU: return v > 0.f ? v : expm1f(v);
+    default: return v;
+  }
+}
+
+__global__ void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ nscale,
+                                const float* __restrict__ nshift, float* __restrict__ y, int HW, int C,
+                                int act, size_t total4) {
+  const int C4 = C >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i / C4;
+    const int c4 = (int)(i - pix * C4);
+    const int b = (int)(pix / HW);
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 sc = *reinterpret_cast<const float4*>(nscale + (size_t)b * C + c4 * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(nshift + (size_t)b * C + c4 * 4);
+    float4 o;
+    o.x = gn_act(v.x * sc.x + sh.x, act);
+    o.y = gn_act(v.y * sc.y + sh.y, act);
+    o.z = gn_act(v.z * sc.z + sh.z, act);
+    o.w = gn_act(v.w * sc.w + sh.w, act);
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
+
+int gn_plan(GNPlan* p, int B, int HW, int C0, int C1, int G) {
+  const int C = C0 + C1;
+  CSD_REQUIRE(C % 4 == 0 && C0 % 4 == 0 && C <= 1024, "groupnorm: C=%d+%d unsupported", C0, C1);
+  CSD_REQUIRE(G > 0 && C % G == 0, "groupnorm: %d channels not divisible into %d groups", C, G);
+  p->B = B; p->HW = HW; p->C0 = C0; p->C1 = C1; p->G = G;
+  // ~2048 workgroups per launch, each chunk at least ~64 pixel rows
+  int nchunk = cdiv(2048, B);
+  const int maxchunk = cdiv(HW, 64);
+  if (nchunk > maxchunk) nchunk = maxchunk;
+  if (nchunk < 1) nchunk = 1;
+  p->nchunk = nchunk;
+  return CSD_OK;
+}
+
+size_t gn_partial_bytes(const GNPlan& p) {
+  return (size_t)p.B * p.nchunk * p.G * 2 * sizeof(double);
+}
+
+int gn_stats_launch(const GNPlan& p, const float* src0, const float* src1, double* partial, hipStream_t s) {
+  const int C = p.C0 + p.C1;
+  const size_t lds = (size_t)2 * C * sizeof(double);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(p.nchunk, p.B), dim3(GN_THREADS), lds, s, src0, src1, partial,
+                     p.HW, p.C0, p.C1, p.G, p.nchunk);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+int gn_finalize_launch(const GNPlan& p, const double* partial, const float* gamma, const float* beta,
+                       float eps, float* nscale, float* nshift, hipStream_t s) {
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B), dim3(256), 0, s, partial, gamma, beta, eps, nscale,
+                     nshift, p.HW, p.C0 + p.C1, p.G, p.nchunk);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+int gn_apply_launch(const float* x, const float* nscale, const float* nshift, float* y, int B, int HW, int C,
+                    int act, hipStream_t s) {
+  const size_t total4 = (size_t)B * HW * C / 4;
+  const int grid = (int)std::min<size_t>(cdiv64(total4, 256), 2048 * 4);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, s, x, nscale, nshift, y, HW, C, act, total4);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+}  // namespace csd

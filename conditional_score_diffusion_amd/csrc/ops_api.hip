@@ -1,0 +1,119 @@
+// ops_api.hip - C ABI of the individual operators on the reference's NCHW fp32 tensors.
+// Each wrapper moves the operands into the library's NHWC layout inside caller-provided scratch,
+// runs the same kernels the network executor uses, and writes NCHW.  These exist for per-op parity
+// tests and for callers that use the reference's functional ops directly; the network path never
+// pays these layout changes.
+#include <string.h>
+
+#include "common.h"
+
+using namespace csd;
+
+namespace {
+inline int ceil8(int v) { return (v + 7) / 8 * 8; }
+inline size_t al64(size_t v) { return (v + 63) / 64 * 64; }
+}  // namespace
+
+// ---- GroupNorm (+activation) ---------------------------------------------------------------------
+extern "C" size_t csd_groupnorm_scratch_bytes(int B, int C, int H, int W) {
+  GNPlan g;
+  if (gn_plan(&g, B, H * W, C, 0, 1)) return 0;
+  const size_t t = (size_t)B * H * W * C;
+  return (2 * al64(t) + 2 * al64((size_t)B * C)) * sizeof(float) + gn_partial_bytes(g) * 64 + 1024;
+}
+
+extern "C" int csd_groupnorm_act(const float* x, const float* gamma, const float* beta, float* y, int B, int C,
+                                 int H, int W, int groups, float eps, int act, void* scratch, void* stream) {
+  CSD_REQUIRE(x && gamma && beta && y && scratch, "groupnorm: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  GNPlan g;
+  int rc = gn_plan(&g, B, H * W, C, 0, groups);
+  if (rc) return rc;
+  const size_t t = (size_t)B * H * W * C;
+  float* f = static_cast<float*>(scratch);
+  float* xh = f; f += al64(t);
+  float* yh = f; f += al64(t);
+  float* sc = f; f += al64((size_t)B * C);
+  float* sh = f; f += al64((size_t)B * C);
+  double* partial = reinterpret_cast<double*>(f);
+  if ((rc = nchw_to_nhwc_launch(x, xh, B, C, H * W, C, C, s))) return rc;
+  if ((rc = gn_stats_launch(g, xh, nullptr, partial, s))) return rc;
+  if ((rc = gn_finalize_launch(g, partial, gamma, beta, eps, sc, sh, s))) return rc;
+  if ((rc = gn_apply_launch(xh, sc, sh, yh, B, H * W, C, act, s))) return rc;
+  return nhwc_to_nchw_launch(yh, y, B, C, H * W, C, s);
+}
+
+// ---- convolution ------------------------------------------------------------------------------------
+static int conv_api_plan(ConvPlan* p, int B, int Cin, int Cout, int H, int W, int ksize, int stride, int pad_mode,
+                         int up2) {
+  CSD_REQUIRE(ksize == 1 || ksize == 3, "conv2d: ksize must be 1 or 3");
+  CSD_REQUIRE(stride == 1 || stride == 2, "conv2d: stride must be 1 or 2");
+  CSD_REQUIRE(!(up2 && stride != 1), "conv2d: up2 requires stride 1");
+  memset(p, 0, sizeof(*p));
+  p->B = B; p->IH = H; p->IW = W;
+  p->C0 = ceil8(Cin); p->C1 = 0; p->Cout = Cout;
+  p->taps = ksize * ksize;
+  p->stride = stride; p->up = up2 ? 1 : 0;
+  if (stride == 2) {
+    CSD_REQUIRE(pad_mode == 1 && ksize == 3, "conv2d: stride 2 is the reference Downsample: ksize 3, pad_mode 1");
+    CSD_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv2d: stride-2 input must have even size");
+    p->pad = 0;
+  } else {
+    CSD_REQUIRE(pad_mode == 0, "conv2d: stride 1 uses symmetric padding (pad_mode 0)");
+    p->pad = ksize / 2;
+  }
+  p->OH = (H << p->up) / stride; p->OW = (W << p->up) / stride;
+  return conv_plan_tiles(p);
+}
+
+extern "C" size_t csd_conv_scratch_bytes(int B, int Cin, int Cout, int H, int W, int ksize, int up2) {
+  ConvPlan p;
+  if (conv_api_plan(&p, B, Cin, Cout, H, W, ksize, 1, 0, up2)) return 0;
+  return (al64((size_t)B * H * W * p.C0) + al64(conv_packed_floats(p)) + al64((size_t)p.CoutPad)) * sizeof(float) + 1024;
+}
+
+extern "C" int csd_conv2d(const float* x, const float* weight, const float* bias, float* y, int B, int Cin, int Cout,
+                          int H, int W, int ksize, int stride, int pad_mode, int up2, int precision, void* scratch,
+                          void* stream) {
+  CSD_REQUIRE(x && weight && y && scratch, "conv2d: null argument");
+  CSD_REQUIRE(precision == CSD_PREC_F32, "conv2d: precision %d not available in this build", precision);
+  hipStream_t s = (hipStream_t)stream;
+  ConvPlan p;
+  int rc = conv_api_plan(&p, B, Cin, Cout, H, W, ksize, stride, pad_mode, up2);
+  if (rc) return rc;
+  float* f = static_cast<float*>(scratch);
+  float* xh = f; f += al64((size_t)B * H * W * p.C0);
+  float* wp = f; f += al64(conv_packed_floats(p));
+  float* bp = f;
+  if ((rc = nchw_to_nhwc_launch(x, xh, B, Cin, H * W, p.C0, p.C0, s))) return rc;
+  if ((rc = conv_pack_weight(p, weight, 0, Cin, Cout, 0, wp, s))) return rc;
+  CSD_CHECK_HIP(hipMemsetAsync(bp, 0, (size_t)p.CoutPad * sizeof(float), s));
+  if (bias) CSD_CHECK_HIP(hipMemcpyAsync(bp, bias, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.src0 = xh; a.wpack = wp; a.bias = bp; a.out = y;
+  a.out_stride = Cout; a.out_nchw = 1; a.out_scale = 1.f;
+  return conv_launch(p, a, s);
+}
+
+// ---- attention ------------------------------------------------------------------------------------------
+extern "C" size_t csd_attention_scratch_bytes(int B, int C, int H, int W) {
+  const size_t L = (size_t)H * W;
+  return (al64((size_t)B * L * 3 * C) + al64((size_t)B * L * C)) * sizeof(float) + 1024;
+}
+
+extern "C" int csd_attention(const float* q, const float* k, const float* v, float* out, int B, int C, int H, int W,
+                             void* scratch, void* stream) {
+  CSD_REQUIRE(q && k && v && out && scratch, "attention: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int L = H * W;
+  float* f = static_cast<float*>(scratch);
+  float* qkv = f; f += al64((size_t)B * L * 3 * C);
+  float* oh = f;
+  int rc;
+  if ((rc = nchw_to_nhwc_launch(q, qkv, B, C, L, C, 3 * C, s))) return rc;
+  if ((rc = nchw_to_nhwc_launch(k, qkv + C, B, C, L, C, 3 * C, s))) return rc;
+  if ((rc = nchw_to_nhwc_launch(v, qkv + 2 * C, B, C, L, C, 3 * C, s))) return rc;
+  if ((rc = attention_launch(qkv, 3 * C, oh, B, L, C, s))) return rc;
+  return nhwc_to_nchw_launch(oh, out, B, C, L, C, s);
+}

@@ -1,0 +1,1016 @@
+// unet.hip - graph executor for the DDPM-family score network + the fused PC sampling loop,
+// and the C-ABI entry points around them.
+//
+// Replaces (reference, behaviour only): models/ddpm.py:80-213 (DDPM.__init__/forward),
+// :275-298 (paired wrappers), the per-step glue of sampling/conditional.py:180-226 and
+// sampling/unconditional.py:194-226.  The module list is rebuilt from the config values exactly
+// as DDPM.__init__ does, so parameter names/indices equal the reference state_dict
+// ("all_modules.{i}.Conv_0.weight" ...).  Execution is a flat, pre-planned list of kernel
+// launches on ONE stream: no per-step host objects, no allocation, no synchronisation.
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "common.h"
+
+namespace csd {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+// parameters
+// ---------------------------------------------------------------------------------------------
+struct Param {
+  std::string name;
+  int ndim;
+  int64_t shape[4];
+  int64_t numel;
+  const float* ptr = nullptr;
+};
+
+enum ModKind { M_LINEAR, M_CONV3, M_RES, M_ATTN, M_DOWN, M_UP, M_GN };
+struct Module {
+  ModKind kind;
+  int idx;
+  int cin = 0, cout = 0;   // res / conv3 / linear ; attn/down/up/gn use cin as "channels"
+};
+
+// one packed convolution weight (+bias): where it lives inside the packed buffer
+struct PackedConv {
+  ConvPlan proto;          // channel-level fields only (C0,C1,Cout,taps,KC,NT,CoutPad)
+  size_t w_off = 0, b_off = 0;   // float offsets in the packed buffer
+  struct Src { int param_w, param_b, layout, cout_src, cout_off, cin_src; };
+  std::vector<Src> srcs;
+};
+
+struct Net;
+
+// ---------------------------------------------------------------------------------------------
+// execution plan for one batch size
+// ---------------------------------------------------------------------------------------------
+enum OpKind { OP_ASSEMBLE, OP_TEMB, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_CONV, OP_ATTN, OP_AVGPOOL, OP_UPNEAR,
+              OP_TO_NCHW };
+
+static const size_t NONE = (size_t)-1;
+
+struct Op {
+  OpKind kind;
+  // generic offsets (floats) into workspace unless stated
+  size_t a = NONE, b = NONE, c = NONE, d = NONE, e = NONE, out = NONE;
+  size_t temb_base = NONE;            // offset of dense_all (conv epilogue time-embedding source)
+  size_t pk0 = NONE, pk1 = NONE;      // offsets into the packed buffer
+  int i0 = 0, i1 = 0, i2 = 0, i3 = 0, i4 = 0;
+  ConvPlan cp;
+  GNPlan gp;
+  int act = 0;
+  int out_external = 0;               // conv writes to the caller's NCHW output
+  size_t temb_col = NONE;             // column offset inside dense_all
+  int temb_stride = 0;
+};
+
+struct Plan {
+  int B = 0;
+  std::vector<Op> ops;
+  size_t ws_floats = 0;
+  int64_t launches = 0;
+  double flops = 0, bytes = 0;
+};
+
+class Arena {
+ public:
+  size_t alloc(size_t nfloats) {
+    nfloats = (nfloats + 63) / 64 * 64;   // 256-byte granules
+    // best fit in the free list
+    int best = -1;
+    for (int i = 0; i < (int)free_.size(); ++i)
+      if (free_[i].second >= nfloats && (best < 0 || free_[i].second < free_[best].second)) best = i;
+    size_t off;
+    if (best >= 0) {
+      off = free_[best].first;
+      if (free_[best].second == nfloats) free_.erase(free_.begin() + best);
+      else { free_[best].first += nfloats; free_[best].second -= nfloats; }
+    } else {
+      // extend the top (merge with a trailing free block if there is one)
+      off = top_;
+      for (int i = 0; i < (int)free_.size(); ++i)
+        if (free_[i].first + free_[i].second == top_) { off = free_[i].first; free_.erase(free_.begin() + i); break; }
+      top_ = off + nfloats;
+    }
+    live_[off] = nfloats;
+    peak_ = std::max(peak_, top_);
+    return off;
+  }
+  void release(size_t off) {
+    if (off == NONE) return;
+    auto it = live_.find(off);
+    if (it == live_.end()) return;
+    size_t n = it->second;
+    live_.erase(it);
+    // coalesce
+    for (int i = 0; i < (int)free_.size();) {
+      if (free_[i].first + free_[i].second == off) { off = free_[i].first; n += free_[i].second; free_.erase(free_.begin() + i); }
+      else if (off + n == free_[i].first) { n += free_[i].second; free_.erase(free_.begin() + i); }
+      else ++i;
+    }
+    free_.push_back({off, n});
+  }
+  size_t peak() const { return peak_; }
+
+ private:
+  std::vector<std::pair<size_t, size_t>> free_;
+  std::map<size_t, size_t> live_;
+  size_t top_ = 0, peak_ = 0;
+};
+
+struct Net {
+  csd_unet_config cfg;
+  std::vector<Module> mods;
+  std::vector<Param> params;
+  std::map<std::string, int> pindex;
+  // packed layout
+  std::vector<PackedConv> pconvs;
+  std::map<std::string, int> pconv_by_name;          // "3.Conv_0", "13.qkv", "13.NIN_3", "2" ...
+  struct Copy { int param; size_t off; };            // raw fp32 copies (linear, GN affine, dense)
+  std::vector<Copy> copies;
+  std::map<std::string, size_t> copy_off;
+  size_t packed_floats = 0;
+  size_t dense_all_off = 0, dense_all_bias_off = 0;  // concatenated Dense_0 of every res block
+  int dense_total = 0;
+  std::map<int, int> dense_col;                      // module idx -> first column
+  bool packed_once = false;
+  std::map<int, std::unique_ptr<Plan>> plans;
+  int in_cpad = 8;
+
+  int add_param(const std::string& name, std::initializer_list<int64_t> shape) {
+    Param p;
+    p.name = name;
+    p.ndim = (int)shape.size();
+    p.numel = 1;
+    int i = 0;
+    for (auto s : shape) { p.shape[i++] = s; p.numel *= s; }
+    for (; i < 4; ++i) p.shape[i] = 1;
+    params.push_back(p);
+    pindex[name] = (int)params.size() - 1;
+    return (int)params.size() - 1;
+  }
+  int P(const std::string& name) const {
+    auto it = pindex.find(name);
+    return it == pindex.end() ? -1 : it->second;
+  }
+};
+
+static std::string mname(int idx, const char* sub) {
+  char buf[96];
+  if (sub && sub[0]) snprintf(buf, sizeof(buf), "all_modules.%d.%s", idx, sub);
+  else snprintf(buf, sizeof(buf), "all_modules.%d", idx);
+  return buf;
+}
+
+// ---- module list: mirrors DDPM.__init__ (models/ddpm.py:96-147) -------------------------------
+static int build_modules(Net& n) {
+  const csd_unet_config& c = n.cfg;
+  CSD_REQUIRE(c.arch == 0, "unet: arch %d not supported (0 = DDPM family)", c.arch);
+  CSD_REQUIRE(c.n_levels >= 1 && c.n_levels <= CSD_MAX_LEVELS, "unet: bad n_levels %d", c.n_levels);
+  CSD_REQUIRE(c.nf % 32 == 0, "unet: nf=%d must be a multiple of 32 (GroupNorm(32) + 32-wide MFMA tiles)", c.nf);
+  CSD_REQUIRE(c.image_size % (1 << (c.n_levels - 1)) == 0, "unet: image_size %d not divisible by 2^%d",
+              c.image_size, c.n_levels - 1);
+  CSD_REQUIRE(c.x_channels >= 1 && c.x_channels + c.y_channels <= 8, "unet: x+y channels must be <= 8");
+  CSD_REQUIRE(c.act >= CSD_ACT_SWISH && c.act <= CSD_ACT_ELU, "unet: bad activation id %d", c.act);
+  CSD_REQUIRE(c.precision == CSD_PREC_F32, "unet: precision %d not available in this build", c.precision);
+  auto add = [&](ModKind k, int cin, int cout) {
+    Module m;
+    m.kind = k; m.idx = (int)n.mods.size(); m.cin = cin; m.cout = cout;
+    n.mods.push_back(m);
+  };
+  auto is_attn = [&](int res) {
+    for (int i = 0; i < c.n_attn; ++i) if (c.attn_resolutions[i] == res) return true;
+    return false;
+  };
+  const int nf = c.nf;
+  if (c.conditional) { add(M_LINEAR, nf, 4 * nf); add(M_LINEAR, 4 * nf, 4 * nf); }
+  add(M_CONV3, c.x_channels + c.y_channels, nf);
+  std::vector<int> hs_c{nf};
+  int in_ch = nf;
+  for (int l = 0; l < c.n_levels; ++l) {
+    const int res = c.image_size >> l;
+    for (int b = 0; b < c.num_res_blocks; ++b) {
+      const int out_ch = nf * c.ch_mult[l];
+      add(M_RES, in_ch, out_ch);
+      in_ch = out_ch;
+      if (is_attn(res)) add(M_ATTN, in_ch, in_ch);
+      hs_c.push_back(in_ch);
+    }
+    if (l != c.n_levels - 1) { add(M_DOWN, in_ch, in_ch); hs_c.push_back(in_ch); }
+  }
+  add(M_RES, in_ch, in_ch);
+  add(M_ATTN, in_ch, in_ch);
+  add(M_RES, in_ch, in_ch);
+  for (int l = c.n_levels - 1; l >= 0; --l) {
+    const int res = c.image_size >> l;
+    for (int b = 0; b < c.num_res_blocks + 1; ++b) {
+      const int out_ch = nf * c.ch_mult[l];
+      add(M_RES, in_ch + hs_c.back(), out_ch);
+      hs_c.pop_back();
+      in_ch = out_ch;
+    }
+    if (is_attn(res)) add(M_ATTN, in_ch, in_ch);
+    if (l != 0) add(M_UP, in_ch, in_ch);
+  }
+  add(M_GN, in_ch, in_ch);
+  add(M_CONV3, in_ch, c.out_channels);
+
+  // parameter table in state_dict order
+  const int temb = 4 * nf;
+  for (auto& m : n.mods) {
+    switch (m.kind) {
+      case M_LINEAR:
+        n.add_param(mname(m.idx, "weight"), {m.cout, m.cin});
+        n.add_param(mname(m.idx, "bias"), {m.cout});
+        break;
+      case M_CONV3:
+        n.add_param(mname(m.idx, "weight"), {m.cout, m.cin, 3, 3});
+        n.add_param(mname(m.idx, "bias"), {m.cout});
+        break;
+      case M_GN:
+        n.add_param(mname(m.idx, "weight"), {m.cin});
+        n.add_param(mname(m.idx, "bias"), {m.cin});
+        break;
+      case M_DOWN:
+      case M_UP:
+        if (c.resamp_with_conv) {
+          n.add_param(mname(m.idx, "Conv_0.weight"), {m.cin, m.cin, 3, 3});
+          n.add_param(mname(m.idx, "Conv_0.bias"), {m.cin});
+        }
+        break;
+      case M_ATTN:
+        n.add_param(mname(m.idx, "GroupNorm_0.weight"), {m.cin});
+        n.add_param(mname(m.idx, "GroupNorm_0.bias"), {m.cin});
+        for (int j = 0; j < 4; ++j) {
+          char w[32], b[32];
+          snprintf(w, sizeof(w), "NIN_%d.W", j);
+          snprintf(b, sizeof(b), "NIN_%d.b", j);
+          n.add_param(mname(m.idx, w), {m.cin, m.cin});
+          n.add_param(mname(m.idx, b), {m.cin});
+        }
+        break;
+      case M_RES:
+        n.add_param(mname(m.idx, "GroupNorm_0.weight"), {m.cin});
+        n.add_param(mname(m.idx, "GroupNorm_0.bias"), {m.cin});
+        n.add_param(mname(m.idx, "Conv_0.weight"), {m.cout, m.cin, 3, 3});
+        n.add_param(mname(m.idx, "Conv_0.bias"), {m.cout});
+        if (c.conditional) {
+          n.add_param(mname(m.idx, "Dense_0.weight"), {m.cout, temb});
+          n.add_param(mname(m.idx, "Dense_0.bias"), {m.cout});
+        }
+        n.add_param(mname(m.idx, "GroupNorm_1.weight"), {m.cout});
+        n.add_param(mname(m.idx, "GroupNorm_1.bias"), {m.cout});
+        n.add_param(mname(m.idx, "Conv_1.weight"), {m.cout, m.cout, 3, 3});
+        n.add_param(mname(m.idx, "Conv_1.bias"), {m.cout});
+        if (m.cin != m.cout) {
+          n.add_param(mname(m.idx, "NIN_0.W"), {m.cin, m.cout});
+          n.add_param(mname(m.idx, "NIN_0.b"), {m.cout});
+        }
+        break;
+    }
+  }
+  return CSD_OK;
+}
+
+// ---- packed layout ------------------------------------------------------------------------------
+static int proto_conv(ConvPlan* p, int c0, int c1, int cout, int taps) {
+  memset(p, 0, sizeof(*p));
+  p->B = 1; p->IH = p->IW = p->OH = p->OW = 32;   // placeholder geometry: only channel fields matter
+  p->C0 = c0; p->C1 = c1; p->Cout = cout; p->taps = taps;
+  p->stride = 1; p->pad = taps == 9 ? 1 : 0; p->up = 0;
+  return conv_plan_tiles(p);
+}
+
+static int build_packed_layout(Net& n) {
+  size_t off = 0;
+  auto take = [&](size_t nfl) { size_t o = off; off += (nfl + 63) / 64 * 64; return o; };
+  auto add_copy = [&](const std::string& pname) {
+    const int pi = n.P(pname);
+    Net::Copy cpy{pi, take((size_t)n.params[pi].numel)};
+    n.copies.push_back(cpy);
+    n.copy_off[pname] = cpy.off;
+  };
+  auto add_conv = [&](const std::string& key, int c0, int c1, int cout, int taps,
+                      std::vector<PackedConv::Src> srcs) -> int {
+    PackedConv pc;
+    int rc = proto_conv(&pc.proto, c0, c1, cout, taps);
+    if (rc) return rc;
+    pc.w_off = take(conv_packed_floats(pc.proto));
+    pc.b_off = take((size_t)pc.proto.CoutPad);
+    pc.srcs = srcs;
+    n.pconv_by_name[key] = (int)n.pconvs.size();
+    n.pconvs.push_back(pc);
+    return CSD_OK;
+  };
+  const csd_unet_config& c = n.cfg;
+  // skip-connection split: replay the hs_c stack to know (C0, C1) of every up-path res block
+  std::vector<int> hs_c{c.nf};
+  int in_ch = c.nf;
+  size_t mi = 0;
+  auto next_mod = [&]() -> Module& { return n.mods[mi++]; };
+  if (c.conditional) {
+    for (int j = 0; j < 2; ++j) {
+      Module& m = next_mod();
+      add_copy(mname(m.idx, "weight"));
+      add_copy(mname(m.idx, "bias"));
+    }
+  }
+  int rc;
+  {
+    Module& m = next_mod();   // stem: Cin padded to 8 (zero weights for the padding channels)
+    rc = add_conv(std::to_string(m.idx), n.in_cpad, 0, m.cout, 9,
+                  {{n.P(mname(m.idx, "weight")), n.P(mname(m.idx, "bias")), 0, m.cout, 0, m.cin}});
+    if (rc) return rc;
+  }
+  auto res_layout = [&](Module& m, int c0, int c1) -> int {
+    const std::string k = std::to_string(m.idx);
+    add_copy(mname(m.idx, "GroupNorm_0.weight"));
+    add_copy(mname(m.idx, "GroupNorm_0.bias"));
+    int r = add_conv(k + ".Conv_0", c0, c1, m.cout, 9,
+                     {{n.P(mname(m.idx, "Conv_0.weight")), n.P(mname(m.idx, "Conv_0.bias")), 0, m.cout, 0}});
+    if (r) return r;
+    add_copy(mname(m.idx, "GroupNorm_1.weight"));
+    add_copy(mname(m.idx, "GroupNorm_1.bias"));
+    r = add_conv(k + ".Conv_1", m.cout, 0, m.cout, 9,
+                 {{n.P(mname(m.idx, "Conv_1.weight")), n.P(mname(m.idx, "Conv_1.bias")), 0, m.cout, 0}});
+    if (r) return r;
+    if (m.cin != m.cout) {
+      r = add_conv(k + ".NIN_0", c0, c1, m.cout, 1,
+                   {{n.P(mname(m.idx, "NIN_0.W")), n.P(mname(m.idx, "NIN_0.b")), 1, m.cout, 0}});
+      if (r) return r;
+    }
+    if (c.conditional) {
+      n.dense_col[m.idx] = n.dense_total;
+      n.dense_total += m.cout;
+    }
+    return CSD_OK;
+  };
+  auto attn_layout = [&](Module& m) -> int {
+    const std::string k = std::to_string(m.idx);
+    const int C = m.cin;
+    add_copy(mname(m.idx, "GroupNorm_0.weight"));
+    add_copy(mname(m.idx, "GroupNorm_0.bias"));
+    int r = add_conv(k + ".qkv", C, 0, 3 * C, 1,
+                     {{n.P(mname(m.idx, "NIN_0.W")), n.P(mname(m.idx, "NIN_0.b")), 1, C, 0},
+                      {n.P(mname(m.idx, "NIN_1.W")), n.P(mname(m.idx, "NIN_1.b")), 1, C, C},
+                      {n.P(mname(m.idx, "NIN_2.W")), n.P(mname(m.idx, "NIN_2.b")), 1, C, 2 * C}});
+    if (r) return r;
+    return add_conv(k + ".NIN_3", C, 0, C, 1,
+                    {{n.P(mname(m.idx, "NIN_3.W")), n.P(mname(m.idx, "NIN_3.b")), 1, C, 0}});
+  };
+  auto resample_layout = [&](Module& m) -> int {
+    if (!c.resamp_with_conv) return CSD_OK;
+    return add_conv(std::to_string(m.idx) + ".Conv_0", m.cin, 0, m.cin, 9,
+                    {{n.P(mname(m.idx, "Conv_0.weight")), n.P(mname(m.idx, "Conv_0.bias")), 0, m.cin, 0}});
+  };
+  auto is_attn = [&](int res) {
+    for (int i = 0; i < c.n_attn; ++i) if (c.attn_resolutions[i] == res) return true;
+    return false;
+  };
+  for (int l = 0; l < c.n_levels; ++l) {
+    const int res = c.image_size >> l;
+    for (int b = 0; b < c.num_res_blocks; ++b) {
+      Module& m = next_mod();
+      if ((rc = res_layout(m, in_ch, 0))) return rc;
+      in_ch = m.cout;
+      if (is_attn(res)) { if ((rc = attn_layout(next_mod()))) return rc; }
+      hs_c.push_back(in_ch);
+    }
+    if (l != c.n_levels - 1) { if ((rc = resample_layout(next_mod()))) return rc; hs_c.push_back(in_ch); }
+  }
+  if ((rc = res_layout(next_mod(), in_ch, 0))) return rc;
+  if ((rc = attn_layout(next_mod()))) return rc;
+  if ((rc = res_layout(next_mod(), in_ch, 0))) return rc;
+  for (int l = c.n_levels - 1; l >= 0; --l) {
+    const int res = c.image_size >> l;
+    for (int b = 0; b < c.num_res_blocks + 1; ++b) {
+      Module& m = next_mod();
+      const int skip = hs_c.back();
+      hs_c.pop_back();
+      if ((rc = res_layout(m, in_ch, skip))) return rc;
+      in_ch = m.cout;
+    }
+    if (is_attn(res)) { if ((rc = attn_layout(next_mod()))) return rc; }
+    if (l != 0) { if ((rc = resample_layout(next_mod()))) return rc; }
+  }
+  {
+    Module& m = next_mod();
+    add_copy(mname(m.idx, "weight"));
+    add_copy(mname(m.idx, "bias"));
+  }
+  {
+    Module& m = next_mod();
+    rc = add_conv(std::to_string(m.idx), m.cin, 0, m.cout, 9,
+                  {{n.P(mname(m.idx, "weight")), n.P(mname(m.idx, "bias")), 0, m.cout, 0}});
+    if (rc) return rc;
+  }
+  CSD_REQUIRE(mi == n.mods.size(), "unet: internal module walk mismatch");
+  if (c.conditional) {
+    n.dense_all_off = take((size_t)n.dense_total * 4 * c.nf);
+    n.dense_all_bias_off = take((size_t)n.dense_total);
+  }
+  n.packed_floats = off;
+  return CSD_OK;
+}
+
+// ---- plan for batch B ---------------------------------------------------------------------------
+struct Builder {
+  Net& n;
+  Plan& pl;
+  Arena ar;
+  int B;
+  size_t gn_partial = NONE, nscale = NONE, nshift = NONE;   // shared scratch
+  size_t dense_all = NONE;
+  int rc = CSD_OK;
+
+  Builder(Net& n_, Plan& p_, int B_) : n(n_), pl(p_), B(B_) {}
+
+  void count(double flops, double bytes) { pl.flops += flops; pl.bytes += bytes; pl.launches += 1; }
+
+  // GroupNorm statistics of (src0|src1) -> nscale/nshift
+  void gn(size_t src0, size_t src1, int c0, int c1, int hw, const std::string& gname, const std::string& bname) {
+    Op s;
+    s.kind = OP_GN_STATS;
+    if (gn_plan(&s.gp, B, hw, c0, c1, 32)) { rc = CSD_ERR_INVALID; return; }
+    s.a = src0; s.b = src1; s.out = gn_partial;
+    pl.ops.push_back(s);
+    Op f;
+    f.kind = OP_GN_FINAL;
+    f.gp = s.gp;
+    f.a = gn_partial; f.pk0 = n.copy_off.at(gname); f.pk1 = n.copy_off.at(bname);
+    f.out = nscale; f.b = nshift;
+    pl.ops.push_back(f);
+    pl.launches += 2;
+    pl.bytes += 2.0 * B * hw * (c0 + c1) * 4;   // GroupNorm reads + writes its tensor
+  }
+
+  // convolution; returns output offset (allocated here unless external)
+  size_t conv(const std::string& key, size_t src0, size_t src1, int ih, int iw, int stride, int pad, int up,
+              bool norm, int act, size_t res, size_t temb_col, bool external_nchw, int real_cin = -1) {
+    const PackedConv& pc = n.pconvs[n.pconv_by_name.at(key)];
+    Op o;
+    o.kind = OP_CONV;
+    o.cp = pc.proto;
+    o.cp.B = B; o.cp.IH = ih; o.cp.IW = iw;
+    o.cp.stride = stride; o.cp.pad = pad; o.cp.up = up;
+    o.cp.OH = (ih << up) / stride; o.cp.OW = (iw << up) / stride;
+    if (conv_plan_tiles(&o.cp)) { rc = CSD_ERR_INVALID; return NONE; }
+    if (o.cp.KC != pc.proto.KC || o.cp.NT != pc.proto.NT) { set_error("conv plan/pack mismatch"); rc = CSD_ERR_INVALID; return NONE; }
+    o.a = src0; o.b = src1; o.pk0 = pc.w_off; o.pk1 = pc.b_off;
+    o.c = res;
+    o.d = norm ? nscale : NONE;
+    o.e = norm ? nshift : NONE;
+    o.temb_base = dense_all;
+    o.act = act;
+    o.temb_col = temb_col;
+    o.temb_stride = n.dense_total;
+    o.out_external = external_nchw ? 1 : 0;
+    const size_t out_elems = (size_t)B * o.cp.OH * o.cp.OW * o.cp.Cout;
+    o.out = external_nchw ? NONE : ar.alloc(out_elems);
+    pl.ops.push_back(o);
+    const int cin = real_cin > 0 ? real_cin : (o.cp.C0 + o.cp.C1);
+    count(2.0 * out_elems * cin * o.cp.taps, ((double)B * ih * iw * cin + (double)out_elems) * 4);
+    return o.out;
+  }
+
+  size_t res_block(const Module& m, size_t x0, size_t x1, int c0, int c1, int hw_side) {
+    const std::string k = std::to_string(m.idx);
+    const int hw = hw_side * hw_side;
+    gn(x0, x1, c0, c1, hw, mname(m.idx, "GroupNorm_0.weight"), mname(m.idx, "GroupNorm_0.bias"));
+    const size_t tcol = n.cfg.conditional ? (size_t)n.dense_col.at(m.idx) : NONE;
+    const size_t h1 = conv(k + ".Conv_0", x0, x1, hw_side, hw_side, 1, 1, 0, true, n.cfg.act, NONE, tcol, false);
+    gn(h1, NONE, m.cout, 0, hw, mname(m.idx, "GroupNorm_1.weight"), mname(m.idx, "GroupNorm_1.bias"));
+    size_t shortcut = x0, sc_buf = NONE;
+    if (m.cin != m.cout) {
+      sc_buf = conv(k + ".NIN_0", x0, x1, hw_side, hw_side, 1, 0, 0, false, 0, NONE, NONE, false);
+      shortcut = sc_buf;
+    } else if (x1 != NONE) {
+      set_error("res block %d: identity shortcut on a concatenated input is not supported", m.idx);
+      rc = CSD_ERR_INVALID;
+    }
+    const size_t out = conv(k + ".Conv_1", h1, NONE, hw_side, hw_side, 1, 1, 0, true, n.cfg.act, shortcut, NONE, false);
+    ar.release(h1);
+    ar.release(sc_buf);
+    return out;
+  }
+
+  size_t attn_block(const Module& m, size_t x, int hw_side) {
+    const std::string k = std::to_string(m.idx);
+    const int C = m.cin, L = hw_side * hw_side;
+    gn(x, NONE, C, 0, L, mname(m.idx, "GroupNorm_0.weight"), mname(m.idx, "GroupNorm_0.bias"));
+    const size_t qkv = conv(k + ".qkv", x, NONE, hw_side, hw_side, 1, 0, 0, true, CSD_ACT_NONE, NONE, NONE, false);
+    Op a;
+    a.kind = OP_ATTN;
+    a.a = qkv; a.i0 = L; a.i1 = C;
+    a.out = ar.alloc((size_t)B * L * C);
+    pl.ops.push_back(a);
+    count(4.0 * B * (double)L * L * C, 0);
+    const size_t o = conv(k + ".NIN_3", a.out, NONE, hw_side, hw_side, 1, 0, 0, false, 0, x, NONE, false);
+    ar.release(qkv);
+    ar.release(a.out);
+    return o;
+  }
+};
+
+static int build_plan(Net& n, int B, Plan** out) {
+  auto it = n.plans.find(B);
+  if (it != n.plans.end()) { *out = it->second.get(); return CSD_OK; }
+  CSD_REQUIRE(B >= 1, "unet: batch must be >= 1");
+  std::unique_ptr<Plan> plp(new Plan());
+  Plan& pl = *plp;
+  pl.B = B;
+  Builder bd(n, pl, B);
+  const csd_unet_config& c = n.cfg;
+  const int S = c.image_size, nf = c.nf;
+  // shared scratch: worst-case GN partials / scale+shift
+  int cmax = nf;
+  for (auto& m : n.mods) cmax = std::max(cmax, std::max(m.cin, m.cout));
+  {
+    GNPlan g;
+    size_t worst = 0;
+    for (int l = 0; l < c.n_levels; ++l) {
+      const int side = S >> l;
+      gn_plan(&g, B, side * side, cmax, 0, 32);
+      worst = std::max(worst, gn_partial_bytes(g));
+    }
+    bd.gn_partial = bd.ar.alloc(worst / sizeof(float) + 64);
+    bd.nscale = bd.ar.alloc((size_t)B * cmax);
+    bd.nshift = bd.ar.alloc((size_t)B * cmax);
+  }
+  size_t mi = 0;
+  auto next_mod = [&]() -> const Module& { return n.mods[mi++]; };
+
+  // ---- input + time embedding ----
+  Op as;
+  as.kind = OP_ASSEMBLE;
+  as.out = bd.ar.alloc((size_t)B * S * S * n.in_cpad);
+  pl.ops.push_back(as);
+  pl.launches += 1;
+  if (c.conditional) {
+    const Module& l0 = next_mod();
+    const Module& l1 = next_mod();
+    Op e;
+    e.kind = OP_TEMB;
+    e.out = bd.ar.alloc((size_t)B * nf);
+    e.i0 = nf;
+    pl.ops.push_back(e);
+    Op a;
+    a.kind = OP_LINEAR;
+    a.a = e.out; a.out = bd.ar.alloc((size_t)B * 4 * nf);
+    a.pk0 = n.copy_off.at(mname(l0.idx, "weight")); a.pk1 = n.copy_off.at(mname(l0.idx, "bias"));
+    a.i0 = nf; a.i1 = 4 * nf; a.act = CSD_ACT_NONE;
+    pl.ops.push_back(a);
+    Op b2;
+    b2.kind = OP_LINEAR;
+    b2.a = a.out; b2.out = bd.ar.alloc((size_t)B * 4 * nf);
+    b2.pk0 = n.copy_off.at(mname(l1.idx, "weight")); b2.pk1 = n.copy_off.at(mname(l1.idx, "bias"));
+    b2.i0 = 4 * nf; b2.i1 = 4 * nf; b2.act = c.act;
+    pl.ops.push_back(b2);
+    Op d;
+    d.kind = OP_LINEAR;   // every ResnetBlock's Dense_0(act(temb)) in one launch
+    d.a = b2.out; d.out = bd.ar.alloc((size_t)B * n.dense_total);
+    d.pk0 = n.dense_all_off; d.pk1 = n.dense_all_bias_off;
+    d.i0 = 4 * nf; d.i1 = n.dense_total; d.act = c.act;
+    pl.ops.push_back(d);
+    bd.dense_all = d.out;
+    pl.launches += 4;
+    pl.flops += 2.0 * B * ((double)nf * 4 * nf + 16.0 * nf * nf + 4.0 * nf * n.dense_total);
+    pl.bytes += 4.0 * B * (nf + 4 * nf + 4 * nf + 4 * nf + (4.0 * nf + 1) * 0 + 2.0 * n.dense_total);
+  }
+  auto is_attn = [&](int res) {
+    for (int i = 0; i < c.n_attn; ++i) if (c.attn_resolutions[i] == res) return true;
+    return false;
+  };
+  struct Skip { size_t off; int ch; };
+  std::vector<Skip> hs;
+  {
+    const Module& m = next_mod();
+    const size_t h0 = bd.conv(std::to_string(m.idx), as.out, NONE, S, S, 1, 1, 0, false, 0, NONE, NONE, false,
+                              c.x_channels + c.y_channels);
+    bd.ar.release(as.out);
+    hs.push_back({h0, m.cout});
+  }
+  int in_ch = nf;
+  for (int l = 0; l < c.n_levels; ++l) {
+    const int side = S >> l;
+    for (int b = 0; b < c.num_res_blocks; ++b) {
+      const Module& m = next_mod();
+      size_t h = bd.res_block(m, hs.back().off, NONE, in_ch, 0, side);
+      in_ch = m.cout;
+      if (is_attn(side)) {
+        const Module& am = next_mod();
+        const size_t h2 = bd.attn_block(am, h, side);
+        bd.ar.release(h);
+        h = h2;
+      }
+      hs.push_back({h, in_ch});
+    }
+    if (l != c.n_levels - 1) {
+      const Module& m = next_mod();
+      size_t d;
+      if (c.resamp_with_conv) {
+        d = bd.conv(std::to_string(m.idx) + ".Conv_0", hs.back().off, NONE, side, side, 2, 0, 0, false, 0, NONE,
+                    NONE, false);
+      } else {
+        Op p;
+        p.kind = OP_AVGPOOL;
+        p.a = hs.back().off; p.i0 = side; p.i1 = in_ch;
+        p.out = bd.ar.alloc((size_t)B * (side / 2) * (side / 2) * in_ch);
+        pl.ops.push_back(p);
+        pl.launches += 1;
+        d = p.out;
+      }
+      hs.push_back({d, in_ch});
+    }
+  }
+  size_t h = hs.back().off;   // stays on the stack: popped by the first up-path block
+  {
+    const int side = S >> (c.n_levels - 1);
+    const Module& r0 = next_mod();
+    size_t t0 = bd.res_block(r0, h, NONE, in_ch, 0, side);
+    const Module& am = next_mod();
+    size_t t1 = bd.attn_block(am, t0, side);
+    bd.ar.release(t0);
+    const Module& r1 = next_mod();
+    size_t t2 = bd.res_block(r1, t1, NONE, in_ch, 0, side);
+    bd.ar.release(t1);
+    h = t2;
+  }
+  for (int l = c.n_levels - 1; l >= 0; --l) {
+    const int side = S >> l;
+    for (int b = 0; b < c.num_res_blocks + 1; ++b) {
+      const Module& m = next_mod();
+      const Skip sk = hs.back();
+      hs.pop_back();
+      const size_t o = bd.res_block(m, h, sk.off, in_ch, sk.ch, side);
+      bd.ar.release(h);
+      bd.ar.release(sk.off);
+      h = o;
+      in_ch = m.cout;
+    }
+    if (is_attn(side)) {
+      const Module& am = next_mod();
+      const size_t o = bd.attn_block(am, h, side);
+      bd.ar.release(h);
+      h = o;
+    }
+    if (l != 0) {
+      const Module& m = next_mod();
+      size_t o;
+      if (c.resamp_with_conv) {
+        o = bd.conv(std::to_string(m.idx) + ".Conv_0", h, NONE, side, side, 1, 1, 1, false, 0, NONE, NONE, false);
+      } else {
+        Op p;
+        p.kind = OP_UPNEAR;
+        p.a = h; p.i0 = side; p.i1 = in_ch;
+        p.out = bd.ar.alloc((size_t)B * side * 2 * side * 2 * in_ch);
+        pl.ops.push_back(p);
+        pl.launches += 1;
+        o = p.out;
+      }
+      bd.ar.release(h);
+      h = o;
+    }
+  }
+  {
+    const Module& g = next_mod();
+    bd.gn(h, NONE, in_ch, 0, S * S, mname(g.idx, "weight"), mname(g.idx, "bias"));
+    const Module& m = next_mod();
+    bd.conv(std::to_string(m.idx), h, NONE, S, S, 1, 1, 0, true, c.act, NONE, NONE, true);
+    bd.ar.release(h);
+  }
+  if (bd.rc) return bd.rc;
+  CSD_REQUIRE(mi == n.mods.size() && hs.empty(), "unet: plan walk mismatch");
+  // parameters are read once per forward (+ param_bytes per NFE)
+  double pbytes = 0;
+  for (auto& p : n.params) pbytes += 4.0 * p.numel;
+  pl.bytes += pbytes;
+  pl.ws_floats = bd.ar.peak();
+  *out = plp.get();
+  n.plans[B] = std::move(plp);
+  return CSD_OK;
+}
+
+// ---- run ------------------------------------------------------------------------------------------
+static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const float* x, const float* y,
+                    const float* labels, float* out, const float* y_noise, float y_sigma, hipStream_t s) {
+  const csd_unet_config& c = n.cfg;
+  const int B = pl.B, S = c.image_size;
+  auto W = [&](size_t off) -> float* { return off == NONE ? nullptr : ws + off; };
+  for (const Op& o : pl.ops) {
+    int rc = CSD_OK;
+    switch (o.kind) {
+      case OP_ASSEMBLE:
+        rc = assemble_input_launch(x, y, y_noise, y_sigma, W(o.out), B, c.x_channels, c.y_channels, S * S,
+                                   n.in_cpad, c.centered, s);
+        break;
+      case OP_TEMB:
+        rc = timestep_embedding_launch(labels, W(o.out), B, o.i0, s);
+        break;
+      case OP_LINEAR:
+        rc = linear_launch(W(o.a), pk + o.pk0, pk + o.pk1, W(o.out), B, o.i0, o.i1, o.act, s);
+        break;
+      case OP_GN_STATS:
+        rc = gn_stats_launch(o.gp, W(o.a), W(o.b), reinterpret_cast<double*>(W(o.out)), s);
+        break;
+      case OP_GN_FINAL:
+        rc = gn_finalize_launch(o.gp, reinterpret_cast<const double*>(W(o.a)), pk + o.pk0, pk + o.pk1, 1e-6f,
+                                W(o.out), W(o.b), s);
+        break;
+      case OP_CONV: {
+        ConvArgs a;
+        a.src0 = W(o.a); a.src1 = W(o.b);
+        a.wpack = pk + o.pk0; a.bias = pk + o.pk1;
+        a.temb = o.temb_col == NONE ? nullptr : ws + o.temb_base + o.temb_col;
+        a.res = W(o.c);
+        a.nscale = W(o.d);
+        a.nshift = W(o.e);
+        a.out = o.out_external ? out : W(o.out);
+        a.temb_stride = o.temb_stride;
+        a.out_stride = o.cp.Cout; a.out_coff = 0;
+        a.out_nchw = o.out_external;
+        a.act = o.act;
+        a.out_scale = 1.f;
+        rc = conv_launch(o.cp, a, s);
+        break;
+      }
+      case OP_ATTN:
+        rc = attention_launch(W(o.a), 3 * o.i1, W(o.out), B, o.i0, o.i1, s);
+        break;
+      case OP_AVGPOOL:
+        rc = avgpool2_launch(W(o.a), W(o.out), B, o.i0, o.i0, o.i1, s);
+        break;
+      case OP_UPNEAR:
+        rc = nearest_up2_nhwc_launch(W(o.a), W(o.out), B, o.i0, o.i0, o.i1, s);
+        break;
+      default:
+        set_error("unet: unknown op");
+        rc = CSD_ERR_STATE;
+    }
+    if (rc) return rc;
+  }
+  return CSD_OK;
+}
+
+
+// ---- weight packing -------------------------------------------------------------------------------
+__global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+__global__ void fill_f32_kernel(float* __restrict__ dst, float v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = v;
+}
+
+static int dev_copy(const float* src, float* dst, size_t nfl, hipStream_t s) {
+  if (!nfl) return CSD_OK;
+  const int grid = (int)std::min<size_t>(cdiv64(nfl, 256), 1024);
+  hipLaunchKernelGGL(copy_f32_kernel, dim3(grid), dim3(256), 0, s, src, dst, nfl);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+static int dev_fill(float* dst, float v, size_t nfl, hipStream_t s) {
+  if (!nfl) return CSD_OK;
+  const int grid = (int)std::min<size_t>(cdiv64(nfl, 256), 1024);
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(grid), dim3(256), 0, s, dst, v, nfl);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+static int pack_all(Net& n, float* pk, hipStream_t s) {
+  for (auto& p : n.params)
+    CSD_REQUIRE(p.ptr != nullptr, "pack: parameter '%s' was never registered (csd_unet_set_param)", p.name.c_str());
+  int rc;
+  for (auto& cp : n.copies)
+    if ((rc = dev_copy(n.params[cp.param].ptr, pk + cp.off, (size_t)n.params[cp.param].numel, s))) return rc;
+  for (auto& pc : n.pconvs) {
+    if ((rc = dev_fill(pk + pc.b_off, 0.f, (size_t)pc.proto.CoutPad, s))) return rc;
+    for (auto& src : pc.srcs) {   // sources are listed with ascending cout_off, first one clears the tensor
+      const int cin_src = src.cin_src > 0 ? src.cin_src : pc.proto.C0 + pc.proto.C1;
+      if ((rc = conv_pack_weight(pc.proto, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
+                                 src.cout_off, pk + pc.w_off, s))) return rc;
+      if ((rc = dev_copy(n.params[src.param_b].ptr, pk + pc.b_off + src.cout_off, (size_t)src.cout_src, s))) return rc;
+    }
+  }
+  if (n.cfg.conditional) {
+    const int K = 4 * n.cfg.nf;
+    for (auto& m : n.mods) {
+      if (m.kind != M_RES) continue;
+      const int col = n.dense_col.at(m.idx);
+      if ((rc = dev_copy(n.params[n.P(mname(m.idx, "Dense_0.weight"))].ptr, pk + n.dense_all_off + (size_t)col * K,
+                         (size_t)m.cout * K, s))) return rc;
+      if ((rc = dev_copy(n.params[n.P(mname(m.idx, "Dense_0.bias"))].ptr, pk + n.dense_all_bias_off + col,
+                         (size_t)m.cout, s))) return rc;
+    }
+  }
+  n.packed_once = true;
+  return CSD_OK;
+}
+
+}  // namespace csd
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+using namespace csd;
+
+struct csd_unet {
+  Net net;
+};
+
+extern "C" const char* csd_version(void) { return "csd-hip 0.1 (gfx950)"; }
+extern "C" const char* csd_last_error(void) { return get_error(); }
+
+extern "C" int csd_unet_create(const csd_unet_config* cfg, csd_unet** out) {
+  CSD_REQUIRE(cfg && out, "unet_create: null argument");
+  std::unique_ptr<csd_unet> h(new csd_unet());
+  h->net.cfg = *cfg;
+  int rc = build_modules(h->net);
+  if (rc) return rc;
+  rc = build_packed_layout(h->net);
+  if (rc) return rc;
+  *out = h.release();
+  return CSD_OK;
+}
+
+extern "C" void csd_unet_destroy(csd_unet* net) { delete net; }
+
+extern "C" int csd_unet_num_params(const csd_unet* net) { return net ? (int)net->net.params.size() : 0; }
+
+extern "C" int csd_unet_param_info(const csd_unet* net, int index, const char** name, int* ndim, int64_t shape[4]) {
+  CSD_REQUIRE(net && index >= 0 && index < (int)net->net.params.size(), "param_info: index %d out of range", index);
+  const Param& p = net->net.params[index];
+  if (name) *name = p.name.c_str();
+  if (ndim) *ndim = p.ndim;
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
+  return CSD_OK;
+}
+
+extern "C" int csd_unet_set_param(csd_unet* net, const char* name, const void* dev_ptr, int64_t numel) {
+  CSD_REQUIRE(net && name && dev_ptr, "set_param: null argument");
+  const int i = net->net.P(name);
+  if (i < 0) { set_error("set_param: unknown parameter '%s'", name); return CSD_ERR_NOT_FOUND; }
+  Param& p = net->net.params[i];
+  CSD_REQUIRE(p.numel == numel, "set_param: '%s' expects %lld elements, got %lld", name, (long long)p.numel,
+              (long long)numel);
+  CSD_REQUIRE((reinterpret_cast<uintptr_t>(dev_ptr) & 3) == 0, "set_param: '%s' is not 4-byte aligned", name);
+  p.ptr = static_cast<const float*>(dev_ptr);
+  return CSD_OK;
+}
+
+extern "C" size_t csd_unet_packed_bytes(const csd_unet* net) { return net ? net->net.packed_floats * sizeof(float) : 0; }
+
+extern "C" int csd_unet_pack(csd_unet* net, void* packed, void* stream) {
+  CSD_REQUIRE(net && packed, "pack: null argument");
+  CSD_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 255) == 0, "pack: packed buffer must be 256-byte aligned");
+  return pack_all(net->net, static_cast<float*>(packed), (hipStream_t)stream);
+}
+
+extern "C" size_t csd_unet_workspace_bytes(csd_unet* net, int B) {
+  if (!net) return 0;
+  Plan* pl = nullptr;
+  if (build_plan(net->net, B, &pl)) return 0;
+  return pl->ws_floats * sizeof(float);
+}
+
+extern "C" int csd_unet_stats(csd_unet* net, int B, int64_t* launches, double* flops, double* bytes) {
+  CSD_REQUIRE(net, "stats: null handle");
+  Plan* pl = nullptr;
+  int rc = build_plan(net->net, B, &pl);
+  if (rc) return rc;
+  if (launches) *launches = pl->launches;
+  if (flops) *flops = pl->flops;
+  if (bytes) *bytes = pl->bytes;
+  return CSD_OK;
+}
+
+static int check_forward_args(csd_unet* net, const void* packed, void* ws, size_t ws_bytes, int B, Plan** pl) {
+  CSD_REQUIRE(net && packed && ws, "forward: null argument");
+  if (!net->net.packed_once) { set_error("forward: csd_unet_pack has not been called"); return CSD_ERR_STATE; }
+  CSD_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "forward: workspace must be 256-byte aligned");
+  int rc = build_plan(net->net, B, pl);
+  if (rc) return rc;
+  if (ws_bytes < (*pl)->ws_floats * sizeof(float)) {
+    set_error("forward: workspace too small (%zu < %zu bytes)", ws_bytes, (*pl)->ws_floats * sizeof(float));
+    return CSD_ERR_WORKSPACE;
+  }
+  return CSD_OK;
+}
+
+extern "C" int csd_unet_forward(csd_unet* net, const void* packed, void* workspace, size_t workspace_bytes,
+                                const float* x, const float* y, const float* labels, float* out, int B,
+                                const float* y_noise, float y_sigma, void* stream) {
+  Plan* pl = nullptr;
+  int rc = check_forward_args(net, packed, workspace, workspace_bytes, B, &pl);
+  if (rc) return rc;
+  CSD_REQUIRE(x && out, "forward: null x/out");
+  CSD_REQUIRE((net->net.cfg.y_channels == 0) == (y == nullptr), "forward: y must be given iff y_channels > 0");
+  CSD_REQUIRE(!net->net.cfg.conditional || labels, "forward: labels required for a conditional network");
+  return run_plan(net->net, *pl, static_cast<const float*>(packed), static_cast<float*>(workspace), x, y, labels,
+                  out, y_noise, y_sigma, (hipStream_t)stream);
+}
+
+// ---- fused PC sampler -------------------------------------------------------------------------------
+// scratch layout (floats): net_out [B*Co*HW] | x_mean [B*Cx*HW] | z [B*Cx*HW] | zy [B*Cy*HW] | labels [B]
+//                          | partial (double) [B*64*2]
+extern "C" size_t csd_pc_scratch_bytes(const csd_unet* net, int B) {
+  if (!net) return 0;
+  const csd_unet_config& c = net->net.cfg;
+  const size_t hw = (size_t)c.image_size * c.image_size;
+  size_t fl = 0;
+  fl += align_up((size_t)B * c.out_channels * hw, 64);
+  fl += 2 * align_up((size_t)B * c.x_channels * hw, 64);
+  fl += align_up((size_t)B * std::max(c.y_channels, 1) * hw, 64);
+  fl += align_up((size_t)B, 64);
+  return fl * sizeof(float) + (size_t)B * 64 * 2 * sizeof(double) + 256;
+}
+
+__global__ void fill_labels_kernel(float* dst, float v, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) dst[i] = v;
+}
+
+extern "C" int csd_pc_sample(csd_unet* net, const void* packed, void* workspace, size_t workspace_bytes,
+                             void* scratch, size_t scratch_bytes, float* x, const float* y, int B,
+                             const csd_pc_params* p, void* stream) {
+  Plan* pl = nullptr;
+  int rc = check_forward_args(net, packed, workspace, workspace_bytes, B, &pl);
+  if (rc) return rc;
+  CSD_REQUIRE(p && x && scratch, "pc_sample: null argument");
+  CSD_REQUIRE(p->n_steps >= 1 && p->labels && p->std_x && p->G, "pc_sample: per-step scalar arrays missing");
+  const csd_unet_config& c = net->net.cfg;
+  CSD_REQUIRE((c.y_channels == 0) == (y == nullptr), "pc_sample: y must be given iff y_channels > 0");
+  CSD_REQUIRE(!(p->std_y && c.y_channels == 0), "pc_sample: std_y given for an unconditional network");
+  if (scratch_bytes < csd_pc_scratch_bytes(net, B)) {
+    set_error("pc_sample: scratch too small");
+    return CSD_ERR_WORKSPACE;
+  }
+  CSD_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 255) == 0, "pc_sample: scratch must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t hw = (size_t)c.image_size * c.image_size;
+  const size_t nx = (size_t)B * c.x_channels * hw, ny = (size_t)B * c.y_channels * hw;
+  const size_t no = (size_t)B * c.out_channels * hw;
+  float* f = static_cast<float*>(scratch);
+  float* net_out = f; f += align_up(no, 64);
+  float* x_mean = f; f += align_up(nx, 64);
+  float* z = f; f += align_up(nx, 64);
+  float* zy = f; f += align_up(std::max(ny, (size_t)B * hw), 64);
+  float* labels = f; f += align_up((size_t)B, 64);
+  double* partial = reinterpret_cast<double*>(f);
+  const int64_t per = (int64_t)c.x_channels * hw;
+  const int nchunk = sumsq_nchunk(per);
+  const bool perturb_y = p->std_y != nullptr;
+  // paired networks emit [score_x | score_y] per sample: the x block of sample b starts at
+  // b*out_channels*hw, which the update kernels take as `net_stride`.
+  const int64_t net_stride = (int64_t)c.out_channels * hw;
+  const float* tape = p->noise_tape;
+  uint64_t draw = 1;   // draw 0 is the prior, owned by the caller
+  auto next_noise = [&](float* dst, size_t n) -> const float* {
+    if (tape) { const float* r = tape; tape += n; return r; }
+    randn_launch(dst, (int64_t)n, p->seed, draw, s);
+    ++draw;
+    return dst;
+  };
+  const float* pk = static_cast<const float*>(packed);
+  float* ws = static_cast<float*>(workspace);
+  for (int i = 0; i < p->n_steps; ++i) {
+    hipLaunchKernelGGL(fill_labels_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, labels, p->labels[i], B);
+    CSD_LAUNCH_CHECK();
+    for (int phase = 0; phase < 2; ++phase) {   // corrector, then predictor (sampling/conditional.py:208-211)
+      const float* zyp = nullptr;
+      if (perturb_y) zyp = next_noise(zy, ny);
+      rc = run_plan(net->net, *pl, pk, ws, x, y, labels, net_out, zyp, perturb_y ? p->std_y[i] : 0.f, s);
+      if (rc) return rc;
+      const float* zp = next_noise(z, nx);
+      if (phase == 0) {
+        if ((rc = sumsq_rows_launch(net_out, net_stride, zp, partial, B, per, nchunk, s))) return rc;
+        rc = langevin_update_launch(x, x_mean, net_out, net_stride, zp, partial, nchunk, p->std_x[i], p->snr, B,
+                                    per, s);
+      } else {
+        rc = reverse_diffusion_update_launch(x, x_mean, net_out, net_stride, zp, p->std_x[i], p->G[i], B, per, s);
+      }
+      if (rc) return rc;
+    }
+    if (p->record) {
+      CSD_CHECK_HIP(hipMemcpyAsync(p->record + (size_t)i * nx, x, nx * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+  }
+  if (p->denoise) CSD_CHECK_HIP(hipMemcpyAsync(x, x_mean, nx * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return CSD_OK;
+}

@@ -1,0 +1,240 @@
+"""DDPM-family score networks as thin adapters over the HIP graph executor.
+
+Registers the reference's names ``ddpm``, ``ddpm_paired_SR3`` and ``ddpm_paired``
+(models/ddpm.py:80,275,287) with the reference's constructor / call signatures:
+
+    model = create_model(config)              # cls(config)
+    out = model(x | {'x': x, 'y': y}, labels) # Tensor | {'x': .., 'y': ..}
+
+The nn.Module holds ONLY the parameters, named exactly like the reference ``state_dict``
+(``all_modules.{i}.Conv_0.weight`` ...; conv OIHW, NIN ``W`` [in,out], Linear [out,in]) so that
+reference checkpoints load with ``load_state_dict``; the parameter table itself comes from the
+library (csd_unet_param_info), which rebuilds the module list from the config the way
+``DDPM.__init__`` does.  ``forward`` hands raw device pointers to ``csd_unet_forward``; all
+arithmetic runs in libcsd_hip.so.  There is no PyTorch fallback.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .._lib import check, current_stream, lib, ptr, require_gpu_tensor
+from . import utils
+
+
+class _Node(nn.Module):
+    """Parameter container: gives nested state_dict keys (``3.Conv_0.weight``)."""
+
+
+def _fan_avg_uniform(shape, scale, is_nin):
+    """``default_init(scale)`` = variance_scaling(scale, 'fan_avg', 'uniform') with the reference's
+    default axes in_axis=1, out_axis=0 (models/layers.py:54-91)."""
+    rf = 1
+    for s in shape[2:]:
+        rf *= s
+    fan_in, fan_out = shape[1] * rf, shape[0] * rf
+    var = (1e-10 if scale == 0 else scale) / ((fan_in + fan_out) / 2.0)
+    return (torch.rand(*shape) * 2. - 1.) * math.sqrt(3 * var)
+
+
+class HipUNet(nn.Module):
+    """Base adapter. Subclasses fix (x_channels, y_channels) conventions."""
+
+    arch = 0
+
+    def __init__(self, config, precision='fp32'):
+        super().__init__()
+        m, d = config.model, config.data
+        self.nf = m.nf
+        self.num_res_blocks = m.num_res_blocks
+        self.attn_resolutions = tuple(m.attn_resolutions)
+        self.num_resolutions = len(m.ch_mult)
+        self.conditional = bool(m.conditional)
+        self.centered = bool(d.centered)
+        self.image_size = int(d.effective_image_size)
+        self.out_channels = int(m.output_channels)
+        self.x_channels, self.y_channels = self._channels(config)
+        act = m.nonlinearity.lower()
+        if act not in _lib.ACT_IDS or act == 'none':
+            raise NotImplementedError('activation function does not exist!')   # models/layers.py:29-41
+        cfg = _lib.UNetConfig()
+        cfg.arch = self.arch
+        cfg.nf = m.nf
+        cfg.n_levels = len(m.ch_mult)
+        for i, v in enumerate(m.ch_mult):
+            cfg.ch_mult[i] = int(v)
+        cfg.num_res_blocks = m.num_res_blocks
+        cfg.n_attn = len(m.attn_resolutions)
+        for i, v in enumerate(m.attn_resolutions):
+            cfg.attn_resolutions[i] = int(v)
+        cfg.image_size = self.image_size
+        cfg.x_channels, cfg.y_channels, cfg.out_channels = self.x_channels, self.y_channels, self.out_channels
+        cfg.resamp_with_conv = int(bool(m.resamp_with_conv))
+        cfg.conditional = int(self.conditional)
+        cfg.centered = int(self.centered)
+        cfg.act = _lib.ACT_IDS[act]
+        cfg.precision = _lib.PREC_IDS[precision]
+        self._cfg = cfg
+        self._h = ctypes.c_void_p()
+        check(lib().csd_unet_create(ctypes.byref(cfg), ctypes.byref(self._h)), 'unet_create')
+        self._dropout = float(m.get('dropout', 0.0)) if hasattr(m, 'get') else float(getattr(m, 'dropout', 0.0))
+        self._build_params()
+        self._packed = None
+        self._packed_key = None
+        self._ws = None
+
+    # -- parameters ------------------------------------------------------------------------------
+    def _channels(self, config):
+        raise NotImplementedError
+
+    def _param_table(self):
+        n = lib().csd_unet_num_params(self._h)
+        out = []
+        name, ndim, shape = ctypes.c_char_p(), ctypes.c_int(), (ctypes.c_int64 * 4)()
+        for i in range(n):
+            check(lib().csd_unet_param_info(self._h, i, ctypes.byref(name), ctypes.byref(ndim), shape), 'param_info')
+            out.append((name.value.decode(), tuple(shape[j] for j in range(ndim.value))))
+        return out
+
+    def _build_params(self):
+        table = self._param_table()
+        last_idx = max(int(k.split('.')[1]) for k, _ in table)
+        nodes = {}
+        for key, shape in table:
+            parts = key.split('.')           # all_modules, idx, [sub], leaf
+            idx = int(parts[1])
+            node = nodes.setdefault(idx, _Node())
+            for sub in parts[2:-1]:
+                if not hasattr(node, sub):
+                    node.add_module(sub, _Node())
+                node = getattr(node, sub)
+            leaf = parts[-1]
+            if len(shape) >= 2:
+                is_nin = leaf == 'W'
+                if 'Conv_1' in key or 'NIN_3' in key or (idx == last_idx and len(shape) == 4):
+                    scale = 0.          # init_scale=0 -> 1e-10 (models/layers.py:648,575; ddpm.py:146)
+                elif is_nin:
+                    scale = 0.1         # NIN default init_scale (models/layers.py:556)
+                else:
+                    scale = 1.
+                val = _fan_avg_uniform(shape, scale, is_nin)
+            elif leaf == 'weight':      # GroupNorm gamma
+                val = torch.ones(shape)
+            else:
+                val = torch.zeros(shape)
+            node.register_parameter(leaf, nn.Parameter(val))
+        self.all_modules = nn.ModuleList([nodes[i] for i in sorted(nodes)])
+        assert sorted(nodes) == list(range(len(nodes)))
+        self._param_names = [k for k, _ in table]
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None):
+                lib().csd_unet_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- packing -----------------------------------------------------------------------------------
+    def _ensure_packed(self):
+        params = dict(self.named_parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params.values())
+        if self._packed is not None and key == self._packed_key:
+            return
+        dev = self.device
+        if dev.type != 'cuda':
+            raise RuntimeError('the HIP score network runs on the MI355X only: move the model with .to("cuda") '
+                               '(parameters are on %s); there is no CPU fallback' % dev)
+        for name in self._param_names:
+            p = params[name]
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError('parameter %s must be contiguous float32' % name)
+            check(lib().csd_unet_set_param(self._h, name.encode(), ctypes.c_void_p(p.data_ptr()), p.numel()),
+                  'set_param')
+        nbytes = lib().csd_unet_packed_bytes(self._h)
+        if self._packed is None or self._packed.numel() < nbytes or self._packed.device != dev:
+            self._packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        check(lib().csd_unet_pack(self._h, ptr(self._packed), current_stream(dev)), 'unet_pack')
+        self._packed_key = key
+
+    def _workspace(self, B):
+        need = lib().csd_unet_workspace_bytes(self._h, B)
+        if need == 0:
+            raise RuntimeError('libcsd_hip: cannot plan batch %d: %s' % (B, lib().csd_last_error().decode()))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def stats(self, B):
+        """(kernel launches, algorithmic FLOPs, algorithmic bytes) of one evaluation at batch B."""
+        n, fl, by = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        check(lib().csd_unet_stats(self._h, B, ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by)), 'unet_stats')
+        return n.value, fl.value, by.value
+
+    # -- evaluation --------------------------------------------------------------------------------
+    def _run(self, x, y, labels, y_noise=None, y_sigma=0.0):
+        if self.training and self._dropout > 0 and torch.is_grad_enabled():
+            raise RuntimeError('training-mode evaluation (dropout %.2f + autograd) is not provided by the HIP '
+                               'library yet; call model.eval() / torch.no_grad()' % self._dropout)
+        require_gpu_tensor(x, 'x')
+        B = x.shape[0]
+        S = self.image_size
+        if tuple(x.shape) != (B, self.x_channels, S, S):
+            raise RuntimeError('x has shape %s, expected %s' % (tuple(x.shape), (B, self.x_channels, S, S)))
+        if self.y_channels:
+            require_gpu_tensor(y, 'y')
+            if tuple(y.shape) != (B, self.y_channels, S, S):
+                raise RuntimeError('y has shape %s, expected %s' % (tuple(y.shape), (B, self.y_channels, S, S)))
+            y = y.contiguous()
+        labels = labels.to(device=x.device, dtype=torch.float32).contiguous()
+        if labels.shape != (B,):
+            raise RuntimeError('labels must have shape [%d]' % B)
+        self._ensure_packed()
+        ws = self._workspace(B)
+        out = torch.empty(B, self.out_channels, S, S, dtype=torch.float32, device=x.device)
+        check(lib().csd_unet_forward(self._h, ptr(self._packed), ptr(ws), ws.numel(), ptr(x.contiguous()),
+                                     ptr(y) if self.y_channels else None, ptr(labels), ptr(out), B,
+                                     ptr(y_noise) if y_noise is not None else None, float(y_sigma),
+                                     current_stream(x.device)), 'unet_forward')
+        return out
+
+
+@utils.register_model(name='ddpm')
+class DDPM(HipUNet):
+    """Unconditional DDPM U-Net: ``model(x, labels) -> Tensor`` (models/ddpm.py:80-213)."""
+
+    def _channels(self, config):
+        return int(config.model.input_channels), 0
+
+    def forward(self, x, labels):
+        return self._run(x, None, labels)
+
+
+class _Paired(HipUNet):
+    def _channels(self, config):
+        cx = int(config.data.shape_x[0])
+        return cx, int(config.model.input_channels) - cx
+
+
+@utils.register_model(name='ddpm_paired_SR3')
+class DDPM_paired_SR3(_Paired):
+    """CDE / SR3 estimator: net(cat(x, y)) -> score_x (models/ddpm.py:275-285)."""
+
+    def forward(self, input_dict, labels):
+        return self._run(input_dict['x'], input_dict['y'], labels)
+
+
+@utils.register_model(name='ddpm_paired')
+class DDPM_paired(_Paired):
+    """CMDE / VS-CMDE estimator: net(cat(x, y)) -> {'x': .., 'y': ..} (models/ddpm.py:287-298)."""
+
+    def forward(self, input_dict, labels):
+        out = self._run(input_dict['x'], input_dict['y'], labels)
+        c = self.x_channels
+        return {'x': out[:, :c], 'y': out[:, c:]}

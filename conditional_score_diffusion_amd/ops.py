@@ -1,0 +1,141 @@
+"""Thin tensor-level wrappers over the per-operator C ABI (include/csd.h).
+
+Tensors are containers only: every function checks that its operands are contiguous fp32 GPU
+tensors, allocates the output / scratch with torch, and enqueues the HIP kernels on the current
+stream.  No torch arithmetic happens here.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, lib, ptr, require_gpu_tensor
+
+
+def _scratch(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _c(t, name):
+    require_gpu_tensor(t, name)
+    return t.contiguous()
+
+
+def groupnorm_act(x, gamma, beta, groups=32, eps=1e-6, act='none'):
+    """act(GroupNorm(x)) - nn.GroupNorm + get_act (models/layers.py:571,638,646)."""
+    x, gamma, beta = _c(x, 'x'), _c(gamma, 'gamma'), _c(beta, 'beta')
+    B, C, H, W = x.shape
+    y = torch.empty_like(x)
+    sc = _scratch(lib().csd_groupnorm_scratch_bytes(B, C, H, W), x.device)
+    check(lib().csd_groupnorm_act(ptr(x), ptr(gamma), ptr(beta), ptr(y), B, C, H, W, groups, eps,
+                                  _lib.ACT_IDS[act], ptr(sc), current_stream(x.device)), 'groupnorm_act')
+    return y
+
+
+def conv2d(x, weight, bias=None, stride=1, downsample_pad=False, up2=False, precision='fp32'):
+    """3x3 / 1x1 convolution, weight OIHW (models/layers.py:100-132); ``stride=2,
+    downsample_pad=True`` is the reference Downsample (pad (0,1,0,1), models/layers.py:619-625);
+    ``up2`` applies nearest x2 first (models/layers.py:600-604)."""
+    x, weight = _c(x, 'x'), _c(weight, 'weight')
+    if bias is not None:
+        bias = _c(bias, 'bias')
+    B, Cin, H, W = x.shape
+    Cout, Cin_w, kh, kw = weight.shape
+    if Cin_w != Cin or kh != kw:
+        raise RuntimeError('conv2d: weight %s does not match input channels %d' % (tuple(weight.shape), Cin))
+    OH = (H * (2 if up2 else 1)) // stride
+    OW = (W * (2 if up2 else 1)) // stride
+    y = torch.empty(B, Cout, OH, OW, dtype=torch.float32, device=x.device)
+    sc = _scratch(lib().csd_conv_scratch_bytes(B, Cin, Cout, H, W, kh, int(up2)), x.device)
+    check(lib().csd_conv2d(ptr(x), ptr(weight), ptr(bias), ptr(y), B, Cin, Cout, H, W, kh, stride,
+                           1 if downsample_pad else 0, int(up2), _lib.PREC_IDS[precision], ptr(sc),
+                           current_stream(x.device)), 'conv2d')
+    return y
+
+
+def attention(q, k, v):
+    """softmax(q.k C^-1/2) v over H*W positions (models/layers.py:584-588)."""
+    q, k, v = _c(q, 'q'), _c(k, 'k'), _c(v, 'v')
+    B, C, H, W = q.shape
+    out = torch.empty_like(q)
+    sc = _scratch(lib().csd_attention_scratch_bytes(B, C, H, W), q.device)
+    check(lib().csd_attention(ptr(q), ptr(k), ptr(v), ptr(out), B, C, H, W, ptr(sc), current_stream(q.device)),
+          'attention')
+    return out
+
+
+def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
+    """Same call signature as the reference's op.upfirdn2d (op/upfirdn2d.py:147-158)."""
+    x, kernel = _c(x, 'x'), _c(kernel, 'kernel')
+    N, C, H, W = x.shape
+    kh, kw = kernel.shape
+    OH = (H * up + pad[0] + pad[1] - kh) // down + 1
+    OW = (W * up + pad[0] + pad[1] - kw) // down + 1
+    out = torch.empty(N, C, OH, OW, dtype=torch.float32, device=x.device)
+    check(lib().csd_upfirdn2d(ptr(x), ptr(kernel), ptr(out), N, C, H, W, kh, kw, up, up, down, down,
+                              pad[0], pad[1], pad[0], pad[1], current_stream(x.device)), 'upfirdn2d')
+    return out
+
+
+def fused_leaky_relu(x, bias, negative_slope=0.2, scale=2 ** 0.5):
+    """Forward of op.fused_leaky_relu (op/fused_act.py:86-97): lrelu(x + b[c]) * scale."""
+    x, bias = _c(x, 'x'), _c(bias, 'bias')
+    out = torch.empty_like(x)
+    inner = 1
+    for s in x.shape[2:]:
+        inner *= s
+    check(lib().csd_fused_bias_act(ptr(x), ptr(bias), None, ptr(out), x.numel(), x.shape[1], inner, 3, 0,
+                                   negative_slope, scale, current_stream(x.device)), 'fused_bias_act')
+    return out
+
+
+def nearest_up2(x):
+    x = _c(x, 'x')
+    N, C, H, W = x.shape
+    out = torch.empty(N, C, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
+    check(lib().csd_nearest_up2(ptr(x), ptr(out), N, C, H, W, current_stream(x.device)), 'nearest_up2')
+    return out
+
+
+def timestep_embedding(t, dim):
+    t = _c(t, 't')
+    out = torch.empty(t.shape[0], dim, dtype=torch.float32, device=t.device)
+    check(lib().csd_timestep_embedding(ptr(t), ptr(out), t.shape[0], dim, current_stream(t.device)),
+          'timestep_embedding')
+    return out
+
+
+def randn(shape, seed, stream_id, device):
+    """Counter-based standard normals (Philox4x32-10): same (seed, stream_id) -> same tensor."""
+    out = torch.empty(*shape, dtype=torch.float32, device=device)
+    check(lib().csd_randn(ptr(out), out.numel(), int(seed), int(stream_id), current_stream(out.device)), 'randn')
+    return out
+
+
+def scale_rows(x, scale, divide=False):
+    """x[b] * scale[b] (or / scale[b]) - divide_by_sigmas (models/utils.py:50-74)."""
+    x, scale = _c(x, 'x'), _c(scale, 'scale')
+    out = torch.empty_like(x)
+    B = x.shape[0]
+    check(lib().csd_scale_rows(ptr(out), ptr(x), ptr(scale), int(divide), B, x.numel() // B,
+                               current_stream(x.device)), 'scale_rows')
+    return out
+
+
+def langevin_step(x, net, z, std, snr):
+    """In-place Langevin corrector update (sampling/correctors.py:88-108); returns (x, x_mean)."""
+    x, net, z = _c(x, 'x'), _c(net, 'net'), _c(z, 'z')
+    B = x.shape[0]
+    x_mean = torch.empty_like(x)
+    sc = _scratch(lib().csd_update_scratch_bytes(B), x.device)
+    check(lib().csd_langevin_step(ptr(x), ptr(x_mean), ptr(net), ptr(z), float(std), float(snr), B,
+                                  x.numel() // B, ptr(sc), current_stream(x.device)), 'langevin_step')
+    return x, x_mean
+
+
+def reverse_diffusion_step(x, net, z, std, G):
+    """In-place reverse-diffusion predictor update (sampling/predictors.py:97-102)."""
+    x, net, z = _c(x, 'x'), _c(net, 'net'), _c(z, 'z')
+    B = x.shape[0]
+    x_mean = torch.empty_like(x)
+    check(lib().csd_reverse_diffusion_step(ptr(x), ptr(x_mean), ptr(net), ptr(z), float(std), float(G), B,
+                                           x.numel() // B, current_stream(x.device)), 'reverse_diffusion_step')
+    return x, x_mean

@@ -1,0 +1,96 @@
+"""Host driver of the fused device-resident PC loop (csd_pc_sample).
+
+Computes the per-step scalars on the CPU in fp32 with the SAME torch expressions the reference
+evaluates per step (timesteps: sampling/conditional.py:202; labels: models/utils.py:213; sigma(t):
+sde_lib.py:390-395; G_i: sde_lib.py:410-418), then launches ONE library call that runs the whole
+loop on the device: 2 network evaluations + 2 update kernels per step, no per-step Python objects,
+no host synchronisation.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib, ops, sde_lib
+from .._lib import check, current_stream, lib, ptr
+
+
+def fusable(model, sde, predictor, corrector, c_steps, probability_flow, continuous, use_path=False):
+    """True when (model, sde, predictor, corrector) is the pair the fused loop implements."""
+    from ..models.ddpm import HipUNet
+    from . import correctors as C, predictors as P
+    c_sde = sde['x'] if isinstance(sde, dict) else sde
+    ok_sde = isinstance(c_sde, (sde_lib.VESDE, sde_lib.cVESDE))
+    if isinstance(sde, dict):
+        ok_sde = ok_sde and isinstance(sde.get('y'), sde_lib.VESDE) and len(sde) == 2
+    ok_pc = predictor in (P.ReverseDiffusionPredictor, P.conditionalReverseDiffusionPredictor) and \
+        corrector in (C.LangevinCorrector, C.conditionalLangevinCorrector)
+    return (isinstance(model, HipUNet) and ok_sde and ok_pc and c_steps == 1 and not probability_flow
+            and continuous and not use_path)
+
+
+def step_scalars(sde, p_steps, eps, unconditional_label=None):
+    """fp32 per-step arrays (labels, std_x, G, std_y|None) + the timesteps tensor."""
+    c_sde = sde['x'] if isinstance(sde, dict) else sde
+    ts = torch.linspace(c_sde.T, eps, p_steps)
+    dummy = torch.zeros(p_steps, 1)
+    std_x = c_sde.marginal_prob(dummy, ts)[1].float()
+    G = c_sde.discretize(dummy, ts)[1].float()
+    if unconditional_label is None:
+        labels = (ts * (c_sde.N - 1)).float()
+    else:   # unconditional continuous VE: the network sees sigma(t) or log sigma(t) (models/utils.py:246-253)
+        labels = torch.log(std_x) if unconditional_label == 'fourier' else std_x.clone()
+    std_y = sde['y'].marginal_prob(dummy, ts)[1].float() if isinstance(sde, dict) else None
+    return ts, labels.contiguous(), std_x.contiguous(), G.contiguous(), (std_y.contiguous() if std_y is not None else None)
+
+
+def _fp(t):
+    return t.data_ptr() and ctypes.cast(t.data_ptr(), ctypes.POINTER(ctypes.c_float))
+
+
+def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=0, record=False,
+        unconditional_label=None):
+    """Run the fused loop; returns (samples, record_or_None)."""
+    c_sde = sde['x'] if isinstance(sde, dict) else sde
+    dev = model.device
+    if dev.type != 'cuda':
+        raise RuntimeError('the fused PC sampler runs on the MI355X only (model is on %s)' % dev)
+    B = shape[0]
+    ts, labels, std_x, G, std_y = step_scalars(sde, p_steps, eps, unconditional_label)
+    # prior: N(0, sigma_max^2) (+ data mean) - drawn on the host like the reference (sde_lib.py:397-403)
+    if noise_tape is not None:
+        tape = [t.float() for t in noise_tape]
+        x = (tape[0] * c_sde.sigma_max)
+        if c_sde.diffused_mean is not None:
+            x = x + c_sde.diffused_mean.unsqueeze(0)
+        x = x.to(dev).contiguous()
+        flat = torch.cat([t.reshape(-1) for t in tape[1:]]).to(dev).contiguous() if len(tape) > 1 else None
+        expected = 2 * p_steps * (2 if std_y is not None else 1)
+        if len(tape) - 1 != expected:
+            raise RuntimeError('noise tape holds %d draws after the prior, the loop needs %d' % (len(tape) - 1, expected))
+    else:
+        x = ops.randn(tuple(shape), seed, 0, dev)
+        x = ops.scale_rows(x, torch.full((B,), float(c_sde.sigma_max), device=dev))
+        if c_sde.diffused_mean is not None:
+            raise NotImplementedError('data-mean prior with on-device noise is not provided yet')
+        flat = None
+    model.eval()
+    model._ensure_packed()
+    ws = model._workspace(B)
+    scratch = torch.empty(lib().csd_pc_scratch_bytes(model._h, B), dtype=torch.uint8, device=dev)
+    rec = torch.empty((p_steps,) + tuple(x.shape), dtype=torch.float32, device=dev) if record else None
+    p = _lib.PCParams()
+    p.n_steps = p_steps
+    p.labels, p.std_x, p.G = _fp(labels), _fp(std_x), _fp(G)
+    p.std_y = _fp(std_y) if std_y is not None else None
+    p.snr = float(snr)
+    p.denoise = int(bool(denoise))
+    p.noise_tape = flat.data_ptr() if flat is not None else None
+    p.seed = int(seed)
+    p.record = rec.data_ptr() if rec is not None else None
+    yy = y.contiguous() if y is not None else None
+    check(lib().csd_pc_sample(model._h, ptr(model._packed), ptr(ws), ws.numel(), ptr(scratch), scratch.numel(),
+                              ptr(x), ptr(yy) if yy is not None else None, B, ctypes.byref(p),
+                              current_stream(dev)), 'pc_sample')
+    # keep the host arrays alive until the enqueue returned (they are read at enqueue time only)
+    del labels, std_x, G, std_y
+    return x, rec, ts

@@ -1,0 +1,198 @@
+/*
+ * csd.h - C ABI of libcsd_hip.so: the MI355X (gfx950) score-network + predictor-corrector
+ * sampler hot path of GBATZOLIS/conditional_score_diffusion.
+ *
+ * Conventions:
+ *   - extern "C", plain pointers and sizes; no C++/torch types cross the boundary.
+ *   - every function returns 0 on success or a negative csd_status; csd_last_error() gives the
+ *     text of the calling thread's last failure.  Nothing throws.
+ *   - the CALLER owns every device buffer (inputs, outputs, packed weights, workspace); the
+ *     library owns only opaque host-side handles.  All work is enqueued on the caller's
+ *     hipStream_t (passed as void*) and never synchronises it, except where stated.
+ *   - boundary tensors are the reference's: NCHW fp32 contiguous.  (Internally activations are
+ *     NHWC fp32; that layout never leaks.)
+ *   - one handle per (device, stream, host thread); handles are independent of each other.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference
+ * repository root).
+ */
+#ifndef CSD_H_
+#define CSD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum csd_status {
+  CSD_OK = 0,
+  CSD_ERR_INVALID = -1,      /* bad argument / unsupported configuration            */
+  CSD_ERR_HIP = -2,          /* a HIP runtime call or kernel launch failed           */
+  CSD_ERR_STATE = -3,        /* call sequence violated (e.g. forward before pack)    */
+  CSD_ERR_NOT_FOUND = -4,    /* unknown parameter name                               */
+  CSD_ERR_WORKSPACE = -5     /* caller-supplied buffer too small                     */
+} csd_status;
+
+/* activation ids (models/layers.py:29-41 get_act) */
+enum { CSD_ACT_NONE = 0, CSD_ACT_SWISH = 1, CSD_ACT_RELU = 2, CSD_ACT_LRELU = 3, CSD_ACT_ELU = 4 };
+
+/* arithmetic of the convolution / 1x1 contractions */
+enum {
+  CSD_PREC_F32 = 0,          /* fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32): exact fp32 fmaf chain */
+  CSD_PREC_F16X3 = 1,        /* split-fp16 (hi+lo) operands, 3 fp16 MFMAs, fp32 accumulate        */
+  CSD_PREC_F16 = 2           /* fp16 operands, fp32 accumulate                                      */
+};
+
+const char* csd_version(void);
+const char* csd_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Score network (U-Net) - replaces models/ddpm.py:80-213 (DDPM), :275-298 (DDPM_paired_SR3,
+ * DDPM_paired) behind models/utils.py:27-47,114-120 (registry / create_model).
+ * ---------------------------------------------------------------------------------------- */
+#define CSD_MAX_LEVELS 8
+#define CSD_MAX_ATTN 8
+
+typedef struct csd_unet_config {
+  int32_t arch;                 /* 0 = DDPM family (models/ddpm.py)                         */
+  int32_t nf;                   /* config.model.nf                                           */
+  int32_t n_levels;             /* len(config.model.ch_mult)                                 */
+  int32_t ch_mult[CSD_MAX_LEVELS];
+  int32_t num_res_blocks;
+  int32_t n_attn;               /* len(config.model.attn_resolutions)                        */
+  int32_t attn_resolutions[CSD_MAX_ATTN];
+  int32_t image_size;           /* config.data.effective_image_size                          */
+  int32_t x_channels;           /* channels of x                                             */
+  int32_t y_channels;           /* channels of the condition y (0: unconditional 'ddpm')     */
+  int32_t out_channels;         /* config.model.output_channels                              */
+  int32_t resamp_with_conv;
+  int32_t conditional;          /* config.model.conditional (time embedding on/off)          */
+  int32_t centered;             /* config.data.centered: 0 -> h = 2x-1 (models/ddpm.py:163-168)*/
+  int32_t act;                  /* CSD_ACT_*                                                 */
+  int32_t precision;            /* CSD_PREC_*                                                */
+} csd_unet_config;
+
+typedef struct csd_unet csd_unet;
+
+int csd_unet_create(const csd_unet_config* cfg, csd_unet** out);
+void csd_unet_destroy(csd_unet* net);
+
+/* Parameter table, in reference state_dict order/naming ("all_modules.3.Conv_0.weight", ...).
+ * Layouts are the reference's: conv OIHW, NIN.W [in,out], Linear [out,in]. */
+int csd_unet_num_params(const csd_unet* net);
+int csd_unet_param_info(const csd_unet* net, int index, const char** name, int* ndim, int64_t shape[4]);
+/* Register the device address of one parameter (fp32, contiguous, reference layout). */
+int csd_unet_set_param(csd_unet* net, const char* name, const void* dev_ptr, int64_t numel);
+
+/* Repack every registered parameter into the library's MFMA-fragment layout.  `packed` is a
+ * caller-owned device buffer of csd_unet_packed_bytes(); must be re-run after weights change. */
+size_t csd_unet_packed_bytes(const csd_unet* net);
+int csd_unet_pack(csd_unet* net, void* packed, void* stream);
+
+/* Activation workspace needed for batch size B. */
+size_t csd_unet_workspace_bytes(csd_unet* net, int B);
+
+/* One network evaluation = model(x | {'x','y'}, labels) of models/utils.py:134-150 in eval mode.
+ *   x      [B, x_channels, S, S]   y [B, y_channels, S, S] (NULL iff y_channels == 0)
+ *   labels [B]                     out [B, out_channels, S, S]
+ *   y_noise/y_sigma: optional fused perturbation y_t = y + y_sigma * y_noise
+ *                    (sampling/conditional.py:104-110); pass NULL / 0 to use y as is. */
+int csd_unet_forward(csd_unet* net, const void* packed, void* workspace, size_t workspace_bytes,
+                     const float* x, const float* y, const float* labels, float* out, int B,
+                     const float* y_noise, float y_sigma, void* stream);
+
+/* number of kernel launches / algorithmic flops+bytes of one forward at batch B (for bench) */
+int csd_unet_stats(csd_unet* net, int B, int64_t* launches, double* flops, double* bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused predictor-corrector sampler - replaces the loop of sampling/conditional.py:180-226 and
+ * sampling/unconditional.py:194-226 for the (reverse_diffusion, langevin) VE pair
+ * (sampling/predictors.py:79-102, sampling/correctors.py:51-108, sde_lib.py:353-362,410-418).
+ * Per-step scalars are computed by the host mirror in fp32 exactly as the reference does and
+ * handed over as arrays of length n_steps.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct csd_pc_params {
+  int32_t n_steps;              /* p_steps                                                   */
+  const float* labels;          /* [n_steps] network label for step i (t*(N-1) or sigma(t))  */
+  const float* std_x;           /* [n_steps] sigma_x(t): score = net / std_x                 */
+  const float* G;               /* [n_steps] reverse-diffusion G_i                            */
+  const float* std_y;           /* [n_steps] sigma_y(t) or NULL (SR3 / unconditional)        */
+  float snr;                    /* Langevin target snr                                       */
+  int32_t denoise;              /* return x_mean of the last predictor step                  */
+  /* noise source: a tape (parity mode) or on-device Philox (throughput mode) */
+  const float* noise_tape;      /* draws in reference order, or NULL         */
+  uint64_t seed;                /* Philox key when noise_tape == NULL                        */
+  /* F3: batch-mean norm coupling.  Optional callback-free hook: when
+   * `norm_exchange` is non-NULL the two per-step batch sums are written there (double[2]) and
+   * the host wrapper may all-reduce them; unused by the fused loop itself. */
+  float* record;                /* optional [n_steps, B, C, S, S]: x after every step, or NULL*/
+} csd_pc_params;
+
+/* x: [B, x_channels, S, S] in: prior sample (already scaled by sigma_max); out: result.
+ * y: [B, y_channels, S, S] or NULL.  scratch: csd_pc_scratch_bytes() device bytes. */
+size_t csd_pc_scratch_bytes(const csd_unet* net, int B);
+int csd_pc_sample(csd_unet* net, const void* packed, void* workspace, size_t workspace_bytes,
+                  void* scratch, size_t scratch_bytes, float* x, const float* y, int B,
+                  const csd_pc_params* p, void* stream);
+
+/* Stand-alone update kernels (the "noise-add" steps), usable with any score source:
+ *   csd_langevin_step: sampling/correctors.py:88-108 (alpha = 1)
+ *   csd_reverse_diffusion_step: sampling/predictors.py:84-89,97-102 with f = 0
+ * net: raw network output; score = net / std.  x is updated in place, x_mean written.
+ * scratch: >= csd_update_scratch_bytes(B) bytes. */
+size_t csd_update_scratch_bytes(int B);
+int csd_langevin_step(float* x, float* x_mean, const float* net, const float* z, float std,
+                      float snr, int B, int64_t per_sample, void* scratch, void* stream);
+int csd_reverse_diffusion_step(float* x, float* x_mean, const float* net, const float* z, float std,
+                               float G, int B, int64_t per_sample, void* stream);
+/* standard-normal fill (Philox4x32-10 + Box-Muller); counter-based: (seed, stream_id) */
+int csd_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+/* out[b,:] = in[b,:] * scale[b]  or / scale[b] (divide_by_sigmas, models/utils.py:50-74) */
+int csd_scale_rows(float* out, const float* in, const float* scale, int divide, int B,
+                   int64_t per_sample, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Individual operators (NCHW fp32 boundary) - the kernels the network is built from, exported
+ * for per-op parity tests and for callers that use the reference's functional ops directly.
+ * ---------------------------------------------------------------------------------------- */
+/* y = act(GroupNorm(x; G groups, eps) * gamma + beta)  - nn.GroupNorm + get_act
+ * (models/layers.py:571,638,646).  scratch: csd_groupnorm_scratch_bytes(B, C, H, W). */
+size_t csd_groupnorm_scratch_bytes(int B, int C, int H, int W);
+int csd_groupnorm_act(const float* x, const float* gamma, const float* beta, float* y, int B, int C,
+                      int H, int W, int groups, float eps, int act, void* scratch, void* stream);
+
+/* 3x3 / 1x1 convolution (models/layers.py:100-132 ddpm_conv1x1/ddpm_conv3x3; NIN :555-564 via
+ * ksize=1).  weight OIHW, stride in {1,2}; pad_mode 0: symmetric pad (ksize/2); 1: the
+ * reference Downsample's (0,1,0,1) pad + stride 2 (models/layers.py:619-625); up2: nearest x2
+ * upsample of x first (models/layers.py:600-604).  scratch: csd_conv_scratch_bytes(). */
+size_t csd_conv_scratch_bytes(int B, int Cin, int Cout, int H, int W, int ksize, int up2);
+int csd_conv2d(const float* x, const float* weight, const float* bias, float* y, int B, int Cin,
+               int Cout, int H, int W, int ksize, int stride, int pad_mode, int up2, int precision,
+               void* scratch, void* stream);
+
+/* single-head self-attention core of AttnBlock (models/layers.py:584-588):
+ * q,k,v,out [B, C, H, W]; w = softmax(q.k * C^-1/2) over keys; out = w.v */
+size_t csd_attention_scratch_bytes(int B, int C, int H, int W);
+int csd_attention(const float* q, const float* k, const float* v, float* out, int B, int C, int H,
+                  int W, void* scratch, void* stream);
+
+/* upfirdn2d (op/upfirdn2d.py:147-158, op/upfirdn2d_kernel.cu:107-207): x [N, C, H, W],
+ * kernel [kh, kw]; out [N, C, (H*up+pad0+pad1-kh)/down+1, ...]. */
+int csd_upfirdn2d(const float* x, const float* kernel, float* out, int N, int C, int H, int W, int kh,
+                  int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                  int pad_y1, void* stream);
+/* fused_bias_act (op/fused_bias_act_kernel.cu:18-49): out = lrelu(x + b[c], alpha) * scale,
+ * act: 1 linear, 3 lrelu; grad 0 forward, 1 backward w.r.t. x using `ref` = forward output. */
+int csd_fused_bias_act(const float* x, const float* bias, const float* ref, float* out, int64_t numel,
+                       int C, int64_t inner, int act, int grad, float alpha, float scale, void* stream);
+/* nearest-neighbour x2 upsample (F.interpolate in models/layers.py:601) */
+int csd_nearest_up2(const float* x, float* out, int N, int C, int H, int W, void* stream);
+/* sinusoidal timestep embedding (models/layers.py:524-538): out [B, dim] */
+int csd_timestep_embedding(const float* t, float* out, int B, int dim, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSD_H_ */

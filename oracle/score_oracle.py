@@ -305,6 +305,23 @@ def paired_forward(p, cfg, x, y, labels, sr3):
     return {'x': out[:, :c], 'y': out[:, c:]}
 
 
+def upfirdn2d_ref(x, kernel, up=1, down=1, pad=(0, 0)):
+    """CPU branch of the reference's upfirdn2d (op/upfirdn2d.py:161-202 ``upfirdn2d_native``):
+    zero-stuff by `up`, pad/crop, correlate with the FLIPPED kernel, keep every `down`-th sample."""
+    N, C, H, W = x.shape
+    kh, kw = kernel.shape
+    p0, p1 = pad
+    out = x.reshape(N * C, H, 1, W, 1)
+    out = F.pad(out, [0, up - 1, 0, 0, 0, up - 1])
+    out = out.reshape(N * C, 1, H * up, W * up)
+    out = F.pad(out, [max(p0, 0), max(p1, 0), max(p0, 0), max(p1, 0)])
+    out = out[:, :, max(-p0, 0):out.shape[2] - max(-p1, 0), max(-p0, 0):out.shape[3] - max(-p1, 0)]
+    w = torch.flip(kernel, [0, 1]).view(1, 1, kh, kw)
+    out = F.conv2d(out, w)
+    out = out[:, :, ::down, ::down]
+    return out.reshape(N, C, out.shape[2], out.shape[3])
+
+
 # ------------------------------------------------------------------------------------------
 # VE SDE scalars (fp32, exactly the reference's expressions)
 # ------------------------------------------------------------------------------------------

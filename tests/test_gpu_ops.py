@@ -1,0 +1,155 @@
+"""-m gpu: per-operator parity of the HIP kernels (through the C ABI) against plain fp32 PyTorch
+on the CPU.  Tolerances: fp32 round-off of a different summation order; stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import score_oracle as so  # noqa: E402
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rnd(*s, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*s, generator=g) * scale
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, ksize, stride, up2
+    (2, 8, 32, 20, 3, 1, False),
+    (2, 32, 64, 10, 3, 1, False),
+    (1, 96, 96, 16, 3, 1, False),
+    (2, 6, 32, 20, 3, 1, False),      # Cin padded to 8
+    (2, 96, 3, 20, 3, 1, False),      # Cout padded to 32
+    (3, 32, 32, 10, 3, 2, False),     # Downsample: pad (0,1,0,1), stride 2 -> 5x5
+    (2, 64, 64, 16, 3, 2, False),
+    (3, 32, 32, 5, 3, 1, True),       # Upsample: nearest x2 then conv -> 10x10
+    (2, 64, 96, 8, 3, 1, True),
+    (2, 64, 96, 5, 1, 1, False),      # NIN / 1x1
+    (4, 288, 288, 5, 3, 1, False),    # odd 5x5 level, tile straddles images
+    (1, 192, 96, 40, 3, 1, False),
+    (1, 96, 96, 160, 3, 1, False),    # full-resolution layer
+]
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,ks,stride,up2', CONV_CASES)
+def test_conv2d(B, Cin, Cout, H, ks, stride, up2):
+    from conditional_score_diffusion_amd import ops
+    x = rnd(B, Cin, H, H, seed=1)
+    w = rnd(Cout, Cin, ks, ks, seed=2, scale=(1.0 / (Cin * ks * ks)) ** 0.5)
+    b = rnd(Cout, seed=3, scale=0.1)
+    if up2:
+        ref = F.conv2d(F.interpolate(x, scale_factor=2, mode='nearest'), w, b, padding=ks // 2)
+    elif stride == 2:
+        ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+    else:
+        ref = F.conv2d(x, w, b, padding=ks // 2)
+    out = ops.conv2d(x.to(dev()), w.to(dev()), b.to(dev()), stride=stride, downsample_pad=(stride == 2), up2=up2)
+    assert out.shape == ref.shape
+    assert rel(out, ref) < 2e-6 * max(1, (Cin * ks * ks) ** 0.5 / 8)   # fp32 dot of length K
+
+
+@pytest.mark.parametrize('B,C,H,G,act', [(2, 32, 20, 32, 'swish'), (3, 96, 10, 32, 'none'), (2, 288, 5, 32, 'swish'),
+                                         (1, 96, 160, 32, 'swish'), (2, 64, 8, 16, 'relu')])
+def test_groupnorm_act(B, C, H, G, act):
+    from conditional_score_diffusion_amd import ops
+    x = rnd(B, C, H, H, seed=4) * 3 + 0.7
+    ga, be = 1 + 0.1 * rnd(C, seed=5), 0.1 * rnd(C, seed=6)
+    ref = F.group_norm(x, G, ga, be, eps=1e-6)
+    ref = {'swish': F.silu, 'none': lambda v: v, 'relu': F.relu}[act](ref)
+    out = ops.groupnorm_act(x.to(dev()), ga.to(dev()), be.to(dev()), groups=G, eps=1e-6, act=act)
+    assert rel(out, ref) < 5e-6
+
+
+@pytest.mark.parametrize('B,C,H', [(2, 64, 5), (2, 32, 10), (1, 192, 20), (2, 96, 16), (3, 288, 10), (2, 288, 5)])
+def test_attention(B, C, H):
+    from conditional_score_diffusion_amd import ops
+    q, k, v = rnd(B, C, H, H, seed=7), rnd(B, C, H, H, seed=8), rnd(B, C, H, H, seed=9)
+    w = torch.einsum('bchw,bcij->bhwij', q, k) * (int(C) ** (-0.5))
+    w = F.softmax(w.reshape(B, H, H, H * H), dim=-1).reshape(B, H, H, H, H)
+    ref = torch.einsum('bhwij,bcij->bchw', w, v)
+    out = ops.attention(q.to(dev()), k.to(dev()), v.to(dev()))
+    assert rel(out, ref) < 1e-5
+
+
+def test_attention_peaked_softmax():
+    """forces large score spread so the online-softmax rescale branch matters (guide rule 26)"""
+    from conditional_score_diffusion_amd import ops
+    B, C, H = 1, 64, 20
+    q, k, v = rnd(B, C, H, H, seed=1) * 4, rnd(B, C, H, H, seed=2) * 4, rnd(B, C, H, H, seed=3)
+    k[:, :, 19, 19] = q[:, :, 0, 0] * 3          # a late key that dominates query 0
+    w = torch.einsum('bchw,bcij->bhwij', q, k) * (int(C) ** (-0.5))
+    w = F.softmax(w.reshape(B, H, H, H * H).double(), dim=-1).reshape(B, H, H, H, H)
+    ref = torch.einsum('bhwij,bcij->bchw', w, v.double())
+    out = ops.attention(q.to(dev()), k.to(dev()), v.to(dev()))
+    assert rel(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize('up,down,pad', [(2, 1, (2, 1)), (1, 2, (1, 1)), (1, 1, (1, 2)), (2, 2, (0, 0))])
+def test_upfirdn2d(up, down, pad):
+    from conditional_score_diffusion_amd import ops
+    x = rnd(2, 5, 12, 12, seed=11)
+    k1 = torch.tensor([1., 3., 3., 1.])
+    k = torch.outer(k1, k1)
+    k = k / k.sum() * (up ** 2)
+    ref = so.upfirdn2d_ref(x, k, up, down, pad)
+    out = ops.upfirdn2d(x.to(dev()), k.to(dev()), up, down, pad)
+    assert out.shape == ref.shape
+    assert rel(out, ref) < 1e-6
+
+
+def test_fused_leaky_relu_and_up():
+    from conditional_score_diffusion_amd import ops
+    x, b = rnd(2, 6, 7, 7, seed=12), rnd(6, seed=13)
+    ref = F.leaky_relu(x + b.view(1, -1, 1, 1), 0.2) * (2 ** 0.5)
+    assert rel(ops.fused_leaky_relu(x.to(dev()), b.to(dev())), ref) < 1e-6
+    ref = F.interpolate(x, scale_factor=2, mode='nearest')
+    assert torch.equal(ops.nearest_up2(x.to(dev())).cpu(), ref)
+
+
+def test_timestep_embedding():
+    from conditional_score_diffusion_amd import ops
+    t = torch.tensor([999.0, 978.6124, 500.25, 0.00999, 277.128])
+    ref = so.timestep_embedding(t, 96)
+    out = ops.timestep_embedding(t.to(dev()), 96).cpu()
+    assert float((out - ref).abs().max()) < 1.5e-4   # 1 ulp of the frequency * t=999 moves sin by ~6e-5
+    assert float((out - ref).abs().mean()) < 1e-5
+
+
+def test_randn_statistics_and_determinism():
+    from conditional_score_diffusion_amd import ops
+    a = ops.randn((4, 3, 160, 160), 42, 7, dev())
+    b = ops.randn((4, 3, 160, 160), 42, 7, dev())
+    c = ops.randn((4, 3, 160, 160), 42, 8, dev())
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    a = a.cpu().double()
+    n = a.numel()
+    assert abs(float(a.mean())) < 5 / n ** 0.5
+    assert abs(float(a.var()) - 1) < 0.01
+    assert abs(float((a ** 4).mean()) - 3) < 0.1
+    assert torch.isfinite(a).all()
+
+
+def test_update_kernels():
+    from conditional_score_diffusion_amd import ops
+    B = 3
+    x, net, z = rnd(B, 3, 20, 20, seed=1) * 50, rnd(B, 3, 20, 20, seed=2), rnd(B, 3, 20, 20, seed=3)
+    std, snr, G = 37.5, 0.15, 4.2
+    xr, xmr = so.langevin_update(net / std, x, z, snr)
+    xo, xmo = ops.langevin_step(x.to(dev()).clone(), net.to(dev()), z.to(dev()), std, snr)
+    assert rel(xo, xr) < 1e-6 and rel(xmo, xmr) < 1e-6
+    xr, xmr = so.reverse_diffusion_update(net / std, x, z, torch.full((B,), G))
+    xo, xmo = ops.reverse_diffusion_step(x.to(dev()).clone(), net.to(dev()), z.to(dev()), std, G)
+    assert rel(xo, xr) < 1e-6 and rel(xmo, xmr) < 1e-6
+    sc = torch.tensor([2.0, 0.5, 277.0])
+    assert rel(ops.scale_rows(x.to(dev()), sc.to(dev()), divide=True), x / sc.view(-1, 1, 1, 1)) < 1e-7
