@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py - images/sec for 1000-step PC sampling, SR3 CelebA-160 score network (BASELINE.json
+configs[1]: configs/ve/inverse_problems/super_resolution/celebA_SR3_160.py values, batch 64 per
+MI355X, random-init weights, synthetic low-resolution inputs).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one predictor-corrector iteration of the reference loop (Langevin corrector then
+reverse-diffusion predictor = 2 score-network evaluations + 2 update kernels) over the whole
+per-GPU batch, executed by the fused device loop (csd_pc_sample) with on-device Philox noise.
+Every step of the 1000-step schedule costs the same (no data-dependent work), so
+    value = images/sec of a full 1000-step sampling run = B_total / (1000 * seconds_per_step).
+K consecutive steps of the real 1000-step schedule are timed (K = 1000 times the whole run).
+Inputs are resident in HBM before the timed region.  One process per GPU; N > 1 is launched by
+torch.distributed.run, the batch is sharded (64 images per GPU, weak scaling), no data-path
+collective except the single all-gather of the finished samples.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+F32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# algorithmic work per image per network evaluation, SR3-160
+ALG_FLOP_PER_IMG_NFE = 107.0e9
+ALG_BYTES_PER_IMG_NFE = 923.5e6
+ALG_WEIGHT_BYTES_PER_NFE = 173.9e6
+
+
+def sr3_160_config():
+    """The values of configs/ve/inverse_problems/super_resolution/celebA_SR3_160.py that the hot
+    path reads (SURVEY.md section 5 'Config / flags')."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import cases
+    return cases.make_config(name='ddpm_paired_SR3', nf=96, ch_mult=(1, 1, 2, 2, 3, 3), num_res_blocks=2,
+                             attn_resolutions=(20, 10, 5), image_size=160, x_ch=3, y_ch=3, num_scales=1000,
+                             sigma_min_x=5e-3, sigma_max_x=float(np.sqrt(3 * 160 * 160)), snr=0.15)
+
+
+def synth_y(B, seed=123):
+    rs = np.random.RandomState(seed)
+    lr = rs.uniform(0, 1, size=(B, 3, 20, 20)).astype(np.float32)
+    return torch.from_numpy(np.repeat(np.repeat(lr, 8, axis=2), 8, axis=3))
+
+
+def cpu_baseline(cfg, steps=1, B=2):
+    """The CPU oracle (oracle/score_oracle.py, a validated port of the reference's PyTorch CPU path)
+    on a bounded sample of the same workload: B images, `steps` PC iterations at 160x160."""
+    import cases  # noqa: F401
+    import score_oracle as so
+    nc = so.NetCfg.from_config(cfg)
+    p = so.synth_params(so.ddpm_param_shapes(nc), 0)
+    y = synth_y(B)
+    shapes = [(B, 3, 160, 160)] * (1 + 2 * steps)
+    rs = np.random.RandomState(1)
+    tape = [torch.from_numpy(rs.standard_normal(s).astype(np.float32)) for s in shapes]
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.time()
+        so.pc_sample_conditional(p, nc, y, so.NoiseTape(tape), (cfg.model.sigma_min_x, cfg.model.sigma_max_x), None,
+                                 sr3=True, p_steps=1000, snr=cfg.sampling.snr, N=1000, max_steps=steps)
+        dt = time.time() - t0
+    return {'value': B / (1000.0 * dt / steps), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': 'B=%d images x %d PC step(s) (=%d network evaluations) of the 1000-step schedule at 160x160, '
+                      'torch %s CPU fp32, %d threads, %.1f s wall' % (B, steps, 2 * steps * B, torch.__version__, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64, help='images per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=1)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)' % args.gpus)
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from conditional_score_diffusion_amd import _lib, ops, sde_lib
+    from conditional_score_diffusion_amd.models import utils as mutils
+    from conditional_score_diffusion_amd.sampling import fused
+    import ctypes
+
+    cfg = sr3_160_config()
+    B = args.batch
+    torch.manual_seed(0)
+    model = mutils.create_model(cfg)
+    # random-init weights of that architecture; the reference's init_scale=0 layers are re-drawn at
+    # scale 1 so the sampler is not numerically degenerate - same FLOPs either way
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import score_oracle as so
+    model.load_state_dict(so.synth_params(so.ddpm_param_shapes(so.NetCfg.from_config(cfg)), 0))
+    model = model.to(dev).eval()
+    sde = sde_lib.cVESDE(cfg.model.sigma_min_x, cfg.model.sigma_max_x, cfg.model.num_scales)
+    y = synth_y(B, seed=123 + rank).to(dev)
+    ts, labels, std_x, G, _ = fused.step_scalars(sde, 1000, 1e-5)
+
+    model._ensure_packed()
+    ws = model._workspace(B)
+    scratch = torch.empty(_lib.lib().csd_pc_scratch_bytes(model._h, B), dtype=torch.uint8, device=dev)
+    x = ops.randn((B, 3, 160, 160), 42 + rank, 0, dev)
+    x = ops.scale_rows(x, torch.full((B,), float(sde.sigma_max), device=dev))
+
+    def run_steps(first, n, seed):
+        p = _lib.PCParams()
+        p.n_steps = n
+        f = lambda t: ctypes.cast(t[first:first + n].contiguous().data_ptr(), ctypes.POINTER(ctypes.c_float))  # noqa: E731
+        keep = [labels[first:first + n].contiguous(), std_x[first:first + n].contiguous(), G[first:first + n].contiguous()]
+        p.labels, p.std_x, p.G = [ctypes.cast(k.data_ptr(), ctypes.POINTER(ctypes.c_float)) for k in keep]
+        p.std_y = None
+        p.snr = float(cfg.sampling.snr)
+        p.denoise = 0
+        p.noise_tape = None
+        p.seed = seed
+        p.record = None
+        _lib.check(_lib.lib().csd_pc_sample(model._h, _lib.ptr(model._packed), _lib.ptr(ws), ws.numel(),
+                                            _lib.ptr(scratch), scratch.numel(), _lib.ptr(x), _lib.ptr(y), B,
+                                            ctypes.byref(p), _lib.current_stream(dev)), 'pc_sample')
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    K, W = args.steps, args.warmup
+    if W > 0:
+        run_steps(0, W, 1000 + rank)
+    barrier()
+    _lib.profile_start()
+    t0 = time.perf_counter()
+    run_steps(W, K, 2000 + rank)
+    if world > 1:   # the one collective of the sampling path: gather the finished samples
+        out = torch.empty((world * B, 3, 160, 160), dtype=torch.float32, device=dev)
+        torch.distributed.all_gather_into_tensor(out, x)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_stop()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(x).all(), 'sampler state became non-finite'
+
+    if rank == 0:
+        ms_step = dt / K * 1e3
+        total_images = B * world
+        value = total_images / (1000.0 * dt / K)
+        dom = prof['conv3x3']
+        dom_tf = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 else 0.0
+        kernel_ms = sum(v['ms'] for v in prof.values())
+        # north_star yardstick: HBM roofline of the whole sampling run
+        bytes_per_img = 2000 * (ALG_BYTES_PER_IMG_NFE + ALG_WEIGHT_BYTES_PER_NFE / B)
+        hbm_roof = HBM_PEAK_GBS * 1e9 / bytes_per_img                      # images/s/GPU
+        flop_roof = F32_MFMA_PEAK_TF * 1e12 / (2000 * ALG_FLOP_PER_IMG_NFE)
+        res = {
+            'metric': 'images/sec for 1000-step PC sampling, NCSN++-family score net, CelebA 160x160',
+            'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: celebA_SR3_160 (ddpm_paired_SR3, nf=96, ch_mult (1,1,2,2,3,3), '
+                                   'attn 20/10/5), 1000-step PC (reverse_diffusion + langevin, snr 0.15), '
+                                   'batch %d per GPU, random-init weights, synthetic LR inputs' % B,
+                       'images_per_gpu': B, 'global_batch': total_images, 'pc_steps_timed': K,
+                       'nfe_per_step': 2, 'noise': 'on-device Philox4x32-10', 'precision_mode': 'fp32 MFMA (exact fp32)'},
+            'roofline': {'kernel': 'conv_f32_kernel (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)',
+                         'bound': 'mfma', 'achieved': dom_tf, 'peak': F32_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
+                         'frac': dom_tf / F32_MFMA_PEAK_TF, 'traffic': None,
+                         'launches': dom['launches'], 'avg_launch_ms': dom['ms'] / max(dom['launches'], 1),
+                         'share_of_kernel_time': dom['ms'] / max(kernel_ms, 1e-9)},
+            'hbm_roofline': {'images_per_sec_per_gpu': hbm_roof, 'frac': value / world / hbm_roof,
+                             'achieved_GBs': value / world * bytes_per_img / 1e9, 'peak_GBs': HBM_PEAK_GBS},
+            'flop_roofline_f32': {'images_per_sec_per_gpu': flop_roof, 'frac': value / world / flop_roof,
+                                  'achieved_TFLOPs': value / world * 2000 * ALG_FLOP_PER_IMG_NFE / 1e12},
+            'kernel_classes_ms_per_step': {k: v['ms'] / K for k, v in prof.items()},
+            'kernel_time_fraction_of_wall': kernel_ms / (dt * 1e3),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            torch.set_num_threads(os.cpu_count() or 1)
+            res['cpu_baseline'] = cpu_baseline(cfg, steps=args.cpu_steps)
+        else:
+            res['cpu_baseline'] = None
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -58,6 +58,9 @@ _vp, _i, _i64, _f, _sz, _u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, c
 SIGNATURES = {
     'csd_version': (ctypes.c_char_p, []),
     'csd_last_error': (ctypes.c_char_p, []),
+    'csd_profile_start': (_i, []),
+    'csd_profile_stop': (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),
+                              ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     'csd_unet_create': (_i, [ctypes.POINTER(UNetConfig), ctypes.POINTER(_vp)]),
     'csd_unet_destroy': (None, [_vp]),
     'csd_unet_num_params': (_i, [_vp]),
@@ -105,6 +108,22 @@ def lib():
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+PROF_CLASSES = ['conv3x3', 'conv3x3_resample', 'conv1x1', 'gn_stats', 'gn_finalize', 'attention', 'sampler', 'other']
+
+
+def profile_start():
+    check(lib().csd_profile_start(), 'profile_start')
+
+
+def profile_stop():
+    """-> {class: {'ms', 'launches', 'flops', 'bytes'}} for the launches since profile_start()."""
+    n = len(PROF_CLASSES)
+    ms, fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
+    la = (ctypes.c_int64 * n)()
+    check(lib().csd_profile_stop(n, ms, la, fl, by), 'profile_stop')
+    return {PROF_CLASSES[i]: {'ms': ms[i], 'launches': la[i], 'flops': fl[i], 'bytes': by[i]} for i in range(n)}
 
 
 def check(rc, what=''):

@@ -37,6 +37,14 @@ struct ConvKArgs {
   int nck;                  // number of K chunks
 };
 
+// explicit global-address-space 16-byte load: keeps hipcc from falling back to flat_load (which
+// also ticks lgkmcnt and would serialise the LDS reads behind the weight prefetch)
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gload4(const float* p) {
+  const v4f_t v = *(const __attribute__((address_space(1))) v4f_t*)(p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
     case CSD_ACT_SWISH: return v / (1.0f + expf(-v));
@@ -47,8 +55,11 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
-template <int NT, int TAPS, int KC>
-__global__ __launch_bounds__(CONV_THREADS) void conv_f32_kernel(const ConvKArgs k) {
+template <int NT, int TAPS, int KC, int SLOTS>
+__global__ __launch_bounds__(CONV_THREADS) void conv_f32_kernel(const float* __restrict__ g_src0,
+                                                                const float* __restrict__ g_src1,
+                                                                const float* __restrict__ g_wpack,
+                                                                const ConvKArgs k) {
   constexpr int KS = (TAPS == 9) ? 3 : 1;
   constexpr int PS = KC + CONV_PAD;          // floats per staged pixel
   constexpr int N4 = KC / 4;                 // float4 per staged pixel
@@ -119,15 +130,17 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_f32_kernel(const ConvKArgs 
   const int total4 = k.PH * k.PW * N4;
   const int Cin = k.C0 + k.C1;
 
-  float4 stage[CONV_MAX_SLOTS];
+  // stage_load only ISSUES the global loads (raw values stay in flight under the MFMA block);
+  // stage_write applies the GroupNorm affine + activation and stores to LDS afterwards.
+  float4 stage[SLOTS];
   auto stage_load = [&](int ck) {
     const int cb = ck * KC;
     const float* src;
     int Cs, coff;
-    if (cb < k.C0) { src = k.a.src0; Cs = k.C0; coff = cb; }
-    else { src = k.a.src1; Cs = k.C1; coff = cb - k.C0; }
+    if (cb < k.C0) { src = g_src0; Cs = k.C0; coff = cb; }
+    else { src = g_src1; Cs = k.C1; coff = cb - k.C0; }
 #pragma unroll
-    for (int j = 0; j < CONV_MAX_SLOTS; ++j) {
+    for (int j = 0; j < SLOTS; ++j) {
       const int e = tid + j * CONV_THREADS;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (e < total4) {
@@ -136,30 +149,34 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_f32_kernel(const ConvKArgs 
         const int pr = pix / k.PW;
         const int pc = pix - pr * k.PW;
         const int vr = prow0 + pr, col = pcol0 + pc;
-        if (vr >= 0 && vr < k.B * k.IH && col >= 0 && col < k.IW) {
-          v = *reinterpret_cast<const float4*>(src + ((size_t)vr * k.IW + col) * Cs + coff + c4 * 4);
-          if (k.a.nscale) {
-            const int b = vr / k.IH;
-            const float4 sc = *reinterpret_cast<const float4*>(k.a.nscale + (size_t)b * Cin + cb + c4 * 4);
-            const float4 sh = *reinterpret_cast<const float4*>(k.a.nshift + (size_t)b * Cin + cb + c4 * 4);
-            v.x = act_apply(v.x * sc.x + sh.x, k.a.act);
-            v.y = act_apply(v.y * sc.y + sh.y, k.a.act);
-            v.z = act_apply(v.z * sc.z + sh.z, k.a.act);
-            v.w = act_apply(v.w * sc.w + sh.w, k.a.act);
-          }
-        }
+        if (vr >= 0 && vr < k.B * k.IH && col >= 0 && col < k.IW)
+          v = gload4(src + ((size_t)vr * k.IW + col) * Cs + coff + c4 * 4);
       }
       stage[j] = v;
     }
   };
-  auto stage_write = [&](float* buf) {
+  auto stage_write = [&](float* buf, int ck) {
+    const int cb = ck * KC;
 #pragma unroll
-    for (int j = 0; j < CONV_MAX_SLOTS; ++j) {
+    for (int j = 0; j < SLOTS; ++j) {
       const int e = tid + j * CONV_THREADS;
       if (e < total4) {
         const int pix = e / N4;
         const int c4 = e - pix * N4;
-        *reinterpret_cast<float4*>(buf + pix * PS + c4 * 4) = stage[j];
+        float4 v = stage[j];
+        if (k.a.nscale) {
+          const int pr = pix / k.PW;
+          int vr = prow0 + pr;
+          vr = vr < 0 ? 0 : (vr >= k.B * k.IH ? k.B * k.IH - 1 : vr);   // out-of-image rows are masked later
+          const int b = vr / k.IH;
+          const float4 sc = *reinterpret_cast<const float4*>(k.a.nscale + (size_t)b * Cin + cb + c4 * 4);
+          const float4 sh = *reinterpret_cast<const float4*>(k.a.nshift + (size_t)b * Cin + cb + c4 * 4);
+          v.x = act_apply(v.x * sc.x + sh.x, k.a.act);
+          v.y = act_apply(v.y * sc.y + sh.y, k.a.act);
+          v.z = act_apply(v.z * sc.z + sh.z, k.a.act);
+          v.w = act_apply(v.w * sc.w + sh.w, k.a.act);
+        }
+        *reinterpret_cast<float4*>(buf + pix * PS + c4 * 4) = v;
       }
     }
   };
@@ -172,47 +189,59 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_f32_kernel(const ConvKArgs 
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
   const size_t steps_per_tile = (size_t)k.nck * TAPS * KK;     // 1 KiB (256 floats) per step
-  const float* wp[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n)
-    wp[n] = k.a.wpack + ((size_t)(ng * NT + n) * steps_per_tile) * 256 + lane * 4;
+  const size_t tile_stride = steps_per_tile * 256;             // floats between consecutive cout tiles
+  const float* wstep = g_wpack + (size_t)(ng * NT) * tile_stride;   // wave-uniform, advances 256 floats/step
+  const int lane4 = lane * 4;
 
-  float4 bcur[NT], bnxt[NT];
+  // two-stage register pipeline, statically indexed (everything below is fully unrolled):
+  // while the 4*NT MFMAs of step s run, the B fragments (global, L2-resident) and the A fragment
+  // (LDS) of step s+1 are already in flight.  sched_barrier pins that order - left alone, hipcc
+  // sinks every load next to its first use and exposes a full L2 round trip per 4 MFMAs.
+  float4 breg[2][NT];
+  float4 areg[2];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) bcur[n] = *reinterpret_cast<const float4*>(wp[n]);
+  for (int n = 0; n < NT; ++n) breg[0][n] = gload4(wstep + n * tile_stride + lane4);
 
   stage_load(0);
-  stage_write(buf0);
+  stage_write(buf0, 0);
   __syncthreads();
 
+  constexpr int STEPS = TAPS * KK;                // steps per chunk
   for (int ck = 0; ck < k.nck; ++ck) {
     const float* buf = (ck & 1) ? buf1 : buf0;
     if (ck + 1 < k.nck) stage_load(ck + 1);       // global loads fly under the MFMA block
+    areg[0] = *reinterpret_cast<const float4*>(buf + off[0]);
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const bool v = (vmask >> tap) & 1u;
+    for (int st = 0; st < STEPS; ++st) {
+      const int cur = st & 1, nxt = cur ^ 1;
+      const int tap = st / KK;
+      // ---- issue the loads of step st+1 ----
+      wstep += 256;
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) {
-        // prefetch next step's B fragments (stream is linear; packed buffer has 1 step of slack)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          wp[n] += 256;
-          bnxt[n] = *reinterpret_cast<const float4*>(wp[n]);
-        }
-        float4 a4 = *reinterpret_cast<const float4*>(buf + off[tap] + kk * 8);
-        if (!v) a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bcur[n].x, acc[n], 0, 0, 0);
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bcur[n].y, acc[n], 0, 0, 0);
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bcur[n].z, acc[n], 0, 0, 0);
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bcur[n].w, acc[n], 0, 0, 0);
-        }
-#pragma unroll
-        for (int n = 0; n < NT; ++n) bcur[n] = bnxt[n];
+      for (int n = 0; n < NT; ++n)
+        breg[nxt][n] = gload4(wstep + n * tile_stride + lane4);   // 1 step of slack past the end
+      if (st + 1 < STEPS) {
+        const int tap1 = (st + 1) / KK, kk1 = (st + 1) % KK;
+        areg[nxt] = *reinterpret_cast<const float4*>(buf + off[tap1] + kk1 * 8);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- MFMAs of step st ----
+      float4 a4 = areg[cur];
+      if (!((vmask >> tap) & 1u)) a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, breg[cur][n].x, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, breg[cur][n].y, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, breg[cur][n].z, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, breg[cur][n].w, acc[n], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (ck + 1 < k.nck) stage_write((ck & 1) ? buf0 : buf1);
+    if (STEPS & 1) {   // odd step count: keep the ping-pong phase aligned across chunks
+#pragma unroll
+      for (int n = 0; n < NT; ++n) breg[0][n] = breg[1][n];
+    }
+    if (ck + 1 < k.nck) stage_write((ck & 1) ? buf0 : buf1, ck + 1);
     __syncthreads();
   }
 
@@ -347,16 +376,16 @@ int conv_pack_weight(const ConvPlan& p, const float* w, int layout, int cin_src,
   return CSD_OK;
 }
 
-template <int NT, int TAPS, int KC>
+template <int NT, int TAPS, int KC, int SLOTS>
 static int launch_one(const ConvKArgs& k, size_t lds, int nblocks, hipStream_t s) {
-  auto kern = conv_f32_kernel<NT, TAPS, KC>;
+  auto kern = conv_f32_kernel<NT, TAPS, KC, SLOTS>;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
     CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(CONV_THREADS), lds, s, k);
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(CONV_THREADS), lds, s, k.a.src0, k.a.src1, k.a.wpack, k);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
@@ -371,8 +400,12 @@ int conv_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s) {
   k.tiles_x = p.tiles_x; k.n_groups = p.n_groups;
   k.nblocks = p.tiles_x * p.tiles_y * p.n_groups;
   k.nck = (p.C0 + p.C1) / p.KC;
-#define CSD_CONV_CASE(NT_, TAPS_, KC_) \
-  if (p.NT == NT_ && p.taps == TAPS_ && p.KC == KC_) return launch_one<NT_, TAPS_, KC_>(k, p.lds_bytes, k.nblocks, s);
+  const int slots = cdiv(p.PH * p.PW * (p.KC / 4), CONV_THREADS);
+#define CSD_CONV_CASE(NT_, TAPS_, KC_)                                                              \
+  if (p.NT == NT_ && p.taps == TAPS_ && p.KC == KC_) {                                              \
+    if (slots <= 3) return launch_one<NT_, TAPS_, KC_, 3>(k, p.lds_bytes, k.nblocks, s);            \
+    return launch_one<NT_, TAPS_, KC_, CONV_MAX_SLOTS>(k, p.lds_bytes, k.nblocks, s);               \
+  }
   CSD_CONV_CASE(1, 9, 8) CSD_CONV_CASE(2, 9, 8) CSD_CONV_CASE(3, 9, 8)
   CSD_CONV_CASE(1, 9, 16) CSD_CONV_CASE(2, 9, 16) CSD_CONV_CASE(3, 9, 16)
   CSD_CONV_CASE(1, 1, 8) CSD_CONV_CASE(2, 1, 8) CSD_CONV_CASE(3, 1, 8)

@@ -29,6 +29,39 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err; }
 
 // ---------------------------------------------------------------------------------------------
+// in-library profiler: HIP events around every launch of the network / sampler, recorded on the
+// SAME stream the kernels run on (bench.py's roofline numbers come from here)
+// ---------------------------------------------------------------------------------------------
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
+struct Profiler {
+  bool on = false;
+  std::vector<ProfRec> recs;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  size_t used = 0;
+};
+static Profiler g_prof;
+
+struct ProfScope {
+  hipStream_t s;
+  hipEvent_t b = nullptr;
+  ProfScope(int cls, double flops, double bytes, hipStream_t s_) : s(s_) {
+    if (!g_prof.on) return;
+    if (g_prof.used == g_prof.pool.size()) {
+      hipEvent_t e0, e1;
+      if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
+      g_prof.pool.push_back({e0, e1});
+    }
+    auto& pr = g_prof.pool[g_prof.used++];
+    (void)hipEventRecord(pr.first, s);
+    b = pr.second;
+    g_prof.recs.push_back({pr.first, pr.second, cls, flops, bytes});
+  }
+  ~ProfScope() {
+    if (b) (void)hipEventRecord(b, s);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
 // parameters
 // ---------------------------------------------------------------------------------------------
 struct Param {
@@ -77,6 +110,8 @@ struct Op {
   int out_external = 0;               // conv writes to the caller's NCHW output
   size_t temb_col = NONE;             // column offset inside dense_all
   int temb_stride = 0;
+  int cls = CSD_PROF_OTHER;           // profiling class
+  double flops = 0, bytes = 0;        // algorithmic work of this launch
 };
 
 struct Plan {
@@ -440,7 +475,10 @@ struct Builder {
 
   Builder(Net& n_, Plan& p_, int B_) : n(n_), pl(p_), B(B_) {}
 
-  void count(double flops, double bytes) { pl.flops += flops; pl.bytes += bytes; pl.launches += 1; }
+  void count(double flops, double bytes) {
+    pl.flops += flops; pl.bytes += bytes; pl.launches += 1;
+    pl.ops.back().flops = flops; pl.ops.back().bytes = bytes;
+  }
 
   // GroupNorm statistics of (src0|src1) -> nscale/nshift
   void gn(size_t src0, size_t src1, int c0, int c1, int hw, const std::string& gname, const std::string& bname) {
@@ -448,12 +486,14 @@ struct Builder {
     s.kind = OP_GN_STATS;
     if (gn_plan(&s.gp, B, hw, c0, c1, 32)) { rc = CSD_ERR_INVALID; return; }
     s.a = src0; s.b = src1; s.out = gn_partial;
+    s.cls = CSD_PROF_GN_STATS; s.bytes = (double)B * hw * (c0 + c1) * 4;
     pl.ops.push_back(s);
     Op f;
     f.kind = OP_GN_FINAL;
     f.gp = s.gp;
     f.a = gn_partial; f.pk0 = n.copy_off.at(gname); f.pk1 = n.copy_off.at(bname);
     f.out = nscale; f.b = nshift;
+    f.cls = CSD_PROF_GN_FINAL;
     pl.ops.push_back(f);
     pl.launches += 2;
     pl.bytes += 2.0 * B * hw * (c0 + c1) * 4;   // GroupNorm reads + writes its tensor
@@ -482,6 +522,7 @@ struct Builder {
     o.out_external = external_nchw ? 1 : 0;
     const size_t out_elems = (size_t)B * o.cp.OH * o.cp.OW * o.cp.Cout;
     o.out = external_nchw ? NONE : ar.alloc(out_elems);
+    o.cls = o.cp.taps == 1 ? CSD_PROF_CONV1X1 : ((stride == 1 && !up) ? CSD_PROF_CONV3X3 : CSD_PROF_CONV3X3_RESAMPLE);
     pl.ops.push_back(o);
     const int cin = real_cin > 0 ? real_cin : (o.cp.C0 + o.cp.C1);
     count(2.0 * out_elems * cin * o.cp.taps, ((double)B * ih * iw * cin + (double)out_elems) * 4);
@@ -518,6 +559,7 @@ struct Builder {
     a.kind = OP_ATTN;
     a.a = qkv; a.i0 = L; a.i1 = C;
     a.out = ar.alloc((size_t)B * L * C);
+    a.cls = CSD_PROF_ATTENTION;
     pl.ops.push_back(a);
     count(4.0 * B * (double)L * L * C, 0);
     const size_t o = conv(k + ".NIN_3", a.out, NONE, hw_side, hw_side, 1, 0, 0, false, 0, x, NONE, false);
@@ -714,6 +756,7 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
   auto W = [&](size_t off) -> float* { return off == NONE ? nullptr : ws + off; };
   for (const Op& o : pl.ops) {
     int rc = CSD_OK;
+    ProfScope prof(o.cls, o.flops, o.bytes, s);
     switch (o.kind) {
       case OP_ASSEMBLE:
         rc = assemble_input_launch(x, y, y_noise, y_sigma, W(o.out), B, c.x_channels, c.y_channels, S * S,
@@ -833,6 +876,32 @@ using namespace csd;
 struct csd_unet {
   Net net;
 };
+
+extern "C" int csd_profile_start(void) {
+  g_prof.on = true;
+  g_prof.recs.clear();
+  g_prof.used = 0;
+  return CSD_OK;
+}
+
+extern "C" int csd_profile_stop(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes) {
+  g_prof.on = false;
+  CSD_REQUIRE(n_classes >= CSD_PROF_NUM_CLASSES && ms && launches && flops && bytes, "profile_stop: bad arguments");
+  for (int i = 0; i < n_classes; ++i) { ms[i] = 0; launches[i] = 0; flops[i] = 0; bytes[i] = 0; }
+  if (g_prof.recs.empty()) return CSD_OK;
+  CSD_CHECK_HIP(hipEventSynchronize(g_prof.recs.back().b));
+  for (auto& r : g_prof.recs) {
+    float t = 0.f;
+    CSD_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    ms[r.cls] += t;
+    launches[r.cls] += 1;
+    flops[r.cls] += r.flops;
+    bytes[r.cls] += r.bytes;
+  }
+  g_prof.recs.clear();
+  g_prof.used = 0;
+  return CSD_OK;
+}
 
 extern "C" const char* csd_version(void) { return "csd-hip 0.1 (gfx950)"; }
 extern "C" const char* csd_last_error(void) { return get_error(); }
@@ -998,6 +1067,7 @@ extern "C" int csd_pc_sample(csd_unet* net, const void* packed, void* workspace,
       rc = run_plan(net->net, *pl, pk, ws, x, y, labels, net_out, zyp, perturb_y ? p->std_y[i] : 0.f, s);
       if (rc) return rc;
       const float* zp = next_noise(z, nx);
+      ProfScope prof(CSD_PROF_SAMPLER, 0, 8.0 * nx * 4, s);
       if (phase == 0) {
         if ((rc = sumsq_rows_launch(net_out, net_stride, zp, partial, B, per, nchunk, s))) return rc;
         rc = langevin_update_launch(x, x_mean, net_out, net_stride, zp, partial, nchunk, p->std_x[i], p->snr, B,

@@ -48,6 +48,24 @@ enum {
 const char* csd_version(void);
 const char* csd_last_error(void);
 
+/* In-library profiler: while enabled, every kernel launch of csd_unet_forward / csd_pc_sample is
+ * bracketed by HIP events on the caller's stream.  csd_profile_stop synchronises the last event
+ * and returns, per launch class, total milliseconds, launch count and the ALGORITHMIC flops/bytes
+ * of those launches (flops = 2*MACs; bytes = input + output tensor of the launch, fp32). */
+enum {
+  CSD_PROF_CONV3X3 = 0,           /* 3x3 stride-1 convolutions (the dominant kernel)        */
+  CSD_PROF_CONV3X3_RESAMPLE = 1,  /* stride-2 / nearest-x2-fused 3x3 convolutions            */
+  CSD_PROF_CONV1X1 = 2,           /* NIN / 1x1 contractions                                   */
+  CSD_PROF_GN_STATS = 3,
+  CSD_PROF_GN_FINAL = 4,
+  CSD_PROF_ATTENTION = 5,
+  CSD_PROF_SAMPLER = 6,           /* predictor / corrector updates (+ norms)                  */
+  CSD_PROF_OTHER = 7,             /* input assembly, time embedding, dense layers             */
+  CSD_PROF_NUM_CLASSES = 8
+};
+int csd_profile_start(void);
+int csd_profile_stop(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes);
+
 /* ------------------------------------------------------------------------------------------
  * Score network (U-Net) - replaces models/ddpm.py:80-213 (DDPM), :275-298 (DDPM_paired_SR3,
  * DDPM_paired) behind models/utils.py:27-47,114-120 (registry / create_model).
@@ -124,9 +142,6 @@ typedef struct csd_pc_params {
   /* noise source: a tape (parity mode) or on-device Philox (throughput mode) */
   const float* noise_tape;      /* draws in reference order, or NULL         */
   uint64_t seed;                /* Philox key when noise_tape == NULL                        */
-  /* F3: batch-mean norm coupling.  Optional callback-free hook: when
-   * `norm_exchange` is non-NULL the two per-step batch sums are written there (double[2]) and
-   * the host wrapper may all-reduce them; unused by the fused loop itself. */
   float* record;                /* optional [n_steps, B, C, S, S]: x after every step, or NULL*/
 } csd_pc_params;
 

@@ -396,7 +396,7 @@ def reverse_diffusion_update(score, x, z, G):
 
 
 def pc_sample_conditional(p, cfg, y, noise, sigma_x, sigma_y=None, sr3=True, p_steps=1000,
-                          snr=0.15, eps=1e-5, denoise=True, N=1000, record=None):
+                          snr=0.15, eps=1e-5, denoise=True, N=1000, record=None, max_steps=None):
     """Default (non-use_path) loop of get_pc_conditional_sampler (sampling/conditional.py:180-226).
 
     noise: NoiseTape; draw order = prior, then per step [z_y(corr)], z_corr, [z_y(pred)], z_pred
@@ -409,7 +409,7 @@ def pc_sample_conditional(p, cfg, y, noise, sigma_x, sigma_y=None, sr3=True, p_s
     x = noise(torch.empty(xshape)) * ve_x.sigma_max
     timesteps = torch.linspace(ve_x.T, eps, p_steps)
     x_mean = x
-    for i in range(p_steps):
+    for i in range(p_steps if max_steps is None else min(p_steps, max_steps)):   # max_steps: bounded bench sample
         vec_t = torch.ones(B) * timesteps[i]
         for phase in ('corrector', 'predictor'):
             if ve_y is not None:
