@@ -51,7 +51,7 @@ def synth_y(B, seed=123):
     return torch.from_numpy(np.repeat(np.repeat(lr, 8, axis=2), 8, axis=3))
 
 
-def cpu_baseline(cfg, steps=1, B=2):
+def cpu_baseline(cfg, steps=4, B=4):
     """The CPU oracle (oracle/score_oracle.py, a validated port of the reference's PyTorch CPU path)
     on a bounded sample of the same workload: B images, `steps` PC iterations at 160x160."""
     import cases  # noqa: F401
@@ -80,7 +80,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=1)
+    ap.add_argument('--cpu-steps', type=int, default=4)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -197,7 +197,9 @@ def main():
             'kernel_time_fraction_of_wall': kernel_ms / (dt * 1e3),
         }
         if not args.no_cpu_baseline and world == 1:
-            torch.set_num_threads(os.cpu_count() or 1)
+            # oneDNN conv scaling collapses past ~16-32 threads on this host (measured: 16 thr 0.12 s, 64 thr
+            # 0.38 s, 256 thr 45 s per evaluation), so the baseline uses the best setting, not all cores
+            torch.set_num_threads(min(16, os.cpu_count() or 1))
             res['cpu_baseline'] = cpu_baseline(cfg, steps=args.cpu_steps)
         else:
             res['cpu_baseline'] = None

@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libcsd_hip.so')
+LIB_PATH = os.environ.get('CSD_LIB_PATH', os.path.join(_HERE, 'libcsd_hip.so'))   # override: tuning builds only
 CSRC = os.path.join(_HERE, 'csrc')
 
 MAX_LEVELS = 8

@@ -19,12 +19,17 @@
 //   B operand: weights are pre-packed in fragment order, so each lane fetches one 16-byte
 //            vector per 4 MFMAs straight from L2/L1 (1 KiB per wave-instruction, fully coalesced)
 //            - no LDS traffic for weights; the stream is linear and prefetched one step ahead.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace csd {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+#ifndef CSD_CONV_ABLATE
+#define CSD_CONV_ABLATE 0   // tuning aid: 1 no B prefetch loads, 2 no A LDS reads, 4 no staging/barriers, 8 no MFMA
+#endif
 #define CONV_THREADS 256
 #define CONV_MAX_SLOTS 9     // float4 staging slots per thread per chunk
 #define CONV_PAD 4           // floats of padding per staged pixel (LDS bank spread)
@@ -47,7 +52,9 @@ __device__ __forceinline__ float4 gload4(const float* p) {
 
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
-    case CSD_ACT_SWISH: return v / (1.0f + expf(-v));
+    // v_exp_f32 + v_rcp_f32 (each <= 1 ulp): ~6 VALU ops instead of ~35 for expf + IEEE divide; the
+    // result differs from the libm form by < 1e-6 relative - this runs on every staged element
+    case CSD_ACT_SWISH: return v * __frcp_rn(1.0f + __expf(-v));
     case CSD_ACT_RELU: return v > 0.f ? v : 0.f;
     case CSD_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
     case CSD_ACT_ELU: return v > 0.f ? v : expm1f(v);
@@ -56,7 +63,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 }
 
 template <int NT, int TAPS, int KC, int SLOTS>
-__global__ __launch_bounds__(CONV_THREADS) void conv_f32_kernel(const float* __restrict__ g_src0,
+__global__ __launch_bounds__(CONV_THREADS, 1) void conv_f32_kernel(const float* __restrict__ g_src0,
                                                                 const float* __restrict__ g_src1,
                                                                 const float* __restrict__ g_wpack,
                                                                 const ConvKArgs k) {
@@ -130,6 +137,28 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_f32_kernel(const float* __r
   const int total4 = k.PH * k.PW * N4;
   const int Cin = k.C0 + k.C1;
 
+  // Per-thread staging slots are the same for every K chunk: precompute, per slot, the source pixel
+  // (or -1 outside the image), the LDS destination and the sample index (for the norm lookup).
+  int s_pix[SLOTS], s_lds[SLOTS], s_nrm[SLOTS];
+#pragma unroll
+  for (int j = 0; j < SLOTS; ++j) {
+    const int e = tid + j * CONV_THREADS;
+    s_pix[j] = -1; s_lds[j] = -1; s_nrm[j] = 0;
+    if (e < total4) {
+      const int pix = e / N4;
+      const int c4 = e - pix * N4;
+      const int pr = pix / k.PW;
+      const int pc = pix - pr * k.PW;
+      const int vr = prow0 + pr, col = pcol0 + pc;
+      s_lds[j] = pix * PS + c4 * 4;
+      if (vr >= 0 && vr < k.B * k.IH && col >= 0 && col < k.IW) {
+        s_pix[j] = vr * k.IW + col;
+        s_nrm[j] = (vr / k.IH) * Cin + c4 * 4;
+      }
+    }
+  }
+  const int my_c4 = (tid % N4) * 4;   // CONV_THREADS % N4 == 0: same channel group in every slot
+
   // stage_load only ISSUES the global loads (raw values stay in flight under the MFMA block);
   // stage_write applies the GroupNorm affine + activation and stores to LDS afterwards.
   float4 stage[SLOTS];
@@ -139,19 +168,11 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_f32_kernel(const float* __r
     int Cs, coff;
     if (cb < k.C0) { src = g_src0; Cs = k.C0; coff = cb; }
     else { src = g_src1; Cs = k.C1; coff = cb - k.C0; }
+    src += coff + my_c4;
 #pragma unroll
     for (int j = 0; j < SLOTS; ++j) {
-      const int e = tid + j * CONV_THREADS;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < total4) {
-        const int pix = e / N4;
-        const int c4 = e - pix * N4;
-        const int pr = pix / k.PW;
-        const int pc = pix - pr * k.PW;
-        const int vr = prow0 + pr, col = pcol0 + pc;
-        if (vr >= 0 && vr < k.B * k.IH && col >= 0 && col < k.IW)
-          v = gload4(src + ((size_t)vr * k.IW + col) * Cs + coff + c4 * 4);
-      }
+      if (s_pix[j] >= 0) v = gload4(src + (size_t)s_pix[j] * Cs);
       stage[j] = v;
     }
   };
@@ -159,24 +180,17 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_f32_kernel(const float* __r
     const int cb = ck * KC;
 #pragma unroll
     for (int j = 0; j < SLOTS; ++j) {
-      const int e = tid + j * CONV_THREADS;
-      if (e < total4) {
-        const int pix = e / N4;
-        const int c4 = e - pix * N4;
+      if (s_lds[j] >= 0) {
         float4 v = stage[j];
-        if (k.a.nscale) {
-          const int pr = pix / k.PW;
-          int vr = prow0 + pr;
-          vr = vr < 0 ? 0 : (vr >= k.B * k.IH ? k.B * k.IH - 1 : vr);   // out-of-image rows are masked later
-          const int b = vr / k.IH;
-          const float4 sc = *reinterpret_cast<const float4*>(k.a.nscale + (size_t)b * Cin + cb + c4 * 4);
-          const float4 sh = *reinterpret_cast<const float4*>(k.a.nshift + (size_t)b * Cin + cb + c4 * 4);
+        if (k.a.nscale && s_pix[j] >= 0) {
+          const float4 sc = *reinterpret_cast<const float4*>(k.a.nscale + s_nrm[j] + cb);
+          const float4 sh = *reinterpret_cast<const float4*>(k.a.nshift + s_nrm[j] + cb);
           v.x = act_apply(v.x * sc.x + sh.x, k.a.act);
           v.y = act_apply(v.y * sc.y + sh.y, k.a.act);
           v.z = act_apply(v.z * sc.z + sh.z, k.a.act);
           v.w = act_apply(v.w * sc.w + sh.w, k.a.act);
         }
-        *reinterpret_cast<float4*>(buf + pix * PS + c4 * 4) = v;
+        *reinterpret_cast<float4*>(buf + s_lds[j]) = v;
       }
     }
   };
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_f32_kernel(const float* __r
   constexpr int STEPS = TAPS * KK;                // steps per chunk
   for (int ck = 0; ck < k.nck; ++ck) {
     const float* buf = (ck & 1) ? buf1 : buf0;
-    if (ck + 1 < k.nck) stage_load(ck + 1);       // global loads fly under the MFMA block
+    if (!(CSD_CONV_ABLATE & 4) && ck + 1 < k.nck) stage_load(ck + 1);       // global loads fly under the MFMA block
     areg[0] = *reinterpret_cast<const float4*>(buf + off[0]);
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
@@ -218,11 +232,14 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_f32_kernel(const float* __r
       // ---- issue the loads of step st+1 ----
       wstep += 256;
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
-        breg[nxt][n] = gload4(wstep + n * tile_stride + lane4);   // 1 step of slack past the end
+      for (int n = 0; n < NT; ++n) {
+        if (CSD_CONV_ABLATE & 1) breg[nxt][n] = breg[cur][n];
+        else breg[nxt][n] = gload4(wstep + n * tile_stride + lane4);   // 1 step of slack past the end
+      }
       if (st + 1 < STEPS) {
         const int tap1 = (st + 1) / KK, kk1 = (st + 1) % KK;
-        areg[nxt] = *reinterpret_cast<const float4*>(buf + off[tap1] + kk1 * 8);
+        if (CSD_CONV_ABLATE & 2) areg[nxt] = areg[cur];
+        else areg[nxt] = *reinterpret_cast<const float4*>(buf + off[tap1] + kk1 * 8);
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- MFMAs of step st ----
@@ -230,6 +247,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_f32_kernel(const float* __r
       if (!((vmask >> tap) & 1u)) a4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
+        if (CSD_CONV_ABLATE & 8) { acc[n][0] += a4.x * breg[cur][n].x + a4.y * breg[cur][n].y + a4.z * breg[cur][n].z + a4.w * breg[cur][n].w; continue; }
         acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, breg[cur][n].x, acc[n], 0, 0, 0);
         acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, breg[cur][n].y, acc[n], 0, 0, 0);
         acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, breg[cur][n].z, acc[n], 0, 0, 0);
@@ -241,8 +259,10 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_f32_kernel(const float* __r
 #pragma unroll
       for (int n = 0; n < NT; ++n) breg[0][n] = breg[1][n];
     }
-    if (ck + 1 < k.nck) stage_write((ck & 1) ? buf0 : buf1, ck + 1);
-    __syncthreads();
+    if (!(CSD_CONV_ABLATE & 4)) {
+      if (ck + 1 < k.nck) stage_write((ck & 1) ? buf0 : buf1, ck + 1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: bias + time embedding + residual, NHWC (or NCHW) store ----
@@ -288,8 +308,6 @@ int conv_plan_tiles(ConvPlan* p) {
               p->OW, p->stride, p->up);
   p->KC = (p->C0 % 16 == 0 && p->C1 % 16 == 0) ? 16 : 8;
   const int ntiles = cdiv(p->Cout, 32);
-  p->NT = (ntiles % 3 == 0) ? 3 : (ntiles % 2 == 0) ? 2 : 1;
-  p->n_groups = ntiles / p->NT;
   p->CoutPad = ntiles * 32;
   // tile: TW divides OW when possible; maximise covered pixels, then minimise the staged patch.
   // Patch extents are the worst case over tile origins (the +1 covers odd origins in `up` mode).
@@ -318,6 +336,27 @@ int conv_plan_tiles(ConvPlan* p) {
   p->PW = extent(p->TW);
   p->tiles_x = cdiv(p->OW, p->TW);
   p->tiles_y = cdiv(p->B * p->OH, p->TH);
+  // cout tiles per workgroup: 3 amortises the staged patch best, but the low-resolution levels
+  // (5x5 / 10x10 / 20x20) have so few pixel tiles that the chip is latency-bound on one
+  // workgroup's serial K loop - there, narrower workgroups (more of them) win.
+  {
+    const int slots = 256 * 3;                    // resident workgroups (256 CUs x 3)
+    const int tiles = p->tiles_x * p->tiles_y;
+    double best = 1e30;
+    int best_nt = 1;
+    for (int nt = 3; nt >= 1; --nt) {
+      if (ntiles % nt) continue;
+      const int nwg = tiles * (ntiles / nt);
+      const double t = (double)cdiv(nwg, slots) * nt * (1.0 + 0.05 * (3 - nt));
+      if (t < best - 1e-9) { best = t; best_nt = nt; }
+    }
+    if (const char* f = getenv("CSD_FORCE_NT")) {   // tuning aid
+      const int v = atoi(f);
+      if (v >= 1 && v <= 3 && ntiles % v == 0) best_nt = v;
+    }
+    p->NT = best_nt;
+    p->n_groups = ntiles / p->NT;
+  }
   p->lds_bytes = (size_t)2 * p->PH * p->PW * (p->KC + CONV_PAD) * sizeof(float) + 256 * sizeof(int);
   CSD_REQUIRE(p->PH * p->PW * (p->KC / 4) <= CONV_MAX_SLOTS * CONV_THREADS, "conv: patch too large");
   CSD_REQUIRE(p->lds_bytes <= 160 * 1024, "conv: LDS budget exceeded");

@@ -510,7 +510,8 @@ struct Builder {
     o.cp.stride = stride; o.cp.pad = pad; o.cp.up = up;
     o.cp.OH = (ih << up) / stride; o.cp.OW = (iw << up) / stride;
     if (conv_plan_tiles(&o.cp)) { rc = CSD_ERR_INVALID; return NONE; }
-    if (o.cp.KC != pc.proto.KC || o.cp.NT != pc.proto.NT) { set_error("conv plan/pack mismatch"); rc = CSD_ERR_INVALID; return NONE; }
+    // the packed layout depends on KC only (not on NT / tile shape)
+    if (o.cp.KC != pc.proto.KC) { set_error("conv plan/pack mismatch"); rc = CSD_ERR_INVALID; return NONE; }
     o.a = src0; o.b = src1; o.pk0 = pc.w_off; o.pk1 = pc.b_off;
     o.c = res;
     o.d = norm ? nscale : NONE;

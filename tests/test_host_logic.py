@@ -1,0 +1,187 @@
+"""CPU-only tests (-m "not gpu"): the C-ABI library loads and exports every symbol include/csd.h
+declares, the host-side planning entry points work without a GPU, the host mirror of the
+reference interface (registries, sde_lib, per-step scalars) behaves like the reference, and the
+product path fails loudly instead of falling back when no GPU is present."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import score_oracle as so
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from conditional_score_diffusion_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'csd.h')).read()
+    declared = set(re.findall(r'\b(csd_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'csd_status'}
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'libcsd_hip.so does not export %s' % name
+    # and the ctypes signature table covers the header one to one
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert b'gfx950' in _lib.lib().csd_version()
+
+
+def test_param_table_matches_reference_state_dict_layout():
+    from conditional_score_diffusion_amd.models import utils as mutils
+    for case in cases.CASES:
+        cfg, _ = cases.case_config(case)
+        model = mutils.create_model(cfg)
+        want = so.ddpm_param_shapes(so.NetCfg.from_config(cfg))
+        got = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        assert got == want
+        assert list(got) == list(want)      # same order as the reference's state_dict
+
+
+def test_full_size_plan_counts_match_survey():
+    """SR3-160 = 43.48 M parameters, 107.0 GFLOP per image-evaluation."""
+    import bench
+    from conditional_score_diffusion_amd.models import utils as mutils
+    model = mutils.create_model(bench.sr3_160_config())
+    assert sum(p.numel() for p in model.parameters()) == 43479267
+    launches, flops, nbytes = model.stats(1)
+    assert abs(flops / 1e9 - 107.0) < 0.5
+    assert 850e6 < nbytes - 43479267 * 4 < 1000e6      # ~923.5 MB activations (+ parameters once)
+    l64, f64, b64 = model.stats(64)
+    assert l64 == launches and abs(f64 / flops - 64) < 1e-6
+
+
+def test_init_distribution_follows_reference_rules():
+    from conditional_score_diffusion_amd.models import utils as mutils
+    torch.manual_seed(0)
+    cfg, _ = cases.case_config('sr3_tiny')
+    sd = mutils.create_model(cfg).state_dict()
+    w = sd['all_modules.3.Conv_0.weight']               # default_init(1.0): U(+-sqrt(3/fan_avg))
+    lim = (3.0 / ((w.shape[1] * 9 + w.shape[0] * 9) / 2)) ** 0.5
+    assert float(w.abs().max()) <= lim and float(w.abs().max()) > 0.9 * lim
+    assert float(sd['all_modules.3.Conv_1.weight'].abs().max()) < 1e-4      # init_scale=0 -> 1e-10
+    assert float(sd['all_modules.3.Conv_0.bias'].abs().max()) == 0
+    assert torch.equal(sd['all_modules.3.GroupNorm_0.weight'], torch.ones_like(sd['all_modules.3.GroupNorm_0.weight']))
+
+
+def test_registries_behave_like_the_reference():
+    from conditional_score_diffusion_amd.models import utils as mutils
+    from conditional_score_diffusion_amd.sampling import correctors, predictors
+    for n in ('ddpm', 'ddpm_paired', 'ddpm_paired_SR3'):
+        assert mutils.get_model(n).__name__.lower().startswith('ddpm')
+    with pytest.raises(ValueError):
+        mutils.register_model(type('X', (), {}), name='ddpm')
+    with pytest.raises(KeyError):
+        mutils.get_model('nope')
+    assert predictors.get_predictor('conditional_reverse_diffusion').__name__ == 'conditionalReverseDiffusionPredictor'
+    assert correctors.get_corrector('conditional_langevin').__name__ == 'conditionalLangevinCorrector'
+    with pytest.raises(ValueError):
+        predictors.register_predictor(type('P', (), {}), name='reverse_diffusion')
+    with pytest.raises(NotImplementedError):
+        predictors.get_predictor('euler_maruyama')(None, None)
+
+
+def test_sde_lib_matches_reference_tables(golden_dir):
+    from conditional_score_diffusion_amd import sde_lib
+    g = np.load(os.path.join(golden_dir, 'sde_tables.npz'))
+    sde = sde_lib.cVESDE(5e-3, np.sqrt(np.prod([3, 160, 160])), 1000)
+    assert np.array_equal(sde.discrete_sigmas.numpy(), g['discrete_sigmas'])
+    for n in (50, 1000):
+        ts = torch.linspace(sde.T, 1e-5, n)
+        x = torch.zeros(n, 1, 1, 1)
+        assert np.array_equal(sde.discretize(x, ts)[1].numpy(), g['G%d' % n])
+        assert np.array_equal(sde.marginal_prob(x, ts)[1].numpy(), g['std%d' % n])
+        assert np.array_equal(sde.sde(x, ts)[1].numpy(), g['g%d' % n])
+        assert np.array_equal((ts * (sde.N - 1) / sde.T).long().numpy(), g['index%d' % n])
+    vy = sde_lib.VESDE(5e-3, 1.0, 1000)
+    ts = torch.linspace(1, 1e-5, 8)
+    x0, x1 = torch.ones(8, 1, 2, 2) * 0.3, torch.ones(8, 1, 2, 2) * 0.7
+    m, s = vy.compute_backward_kernel(x0, x1, ts, torch.ones(8) * 0.02)
+    assert np.array_equal(m.numpy(), g['bk_mean']) and np.array_equal(s.numpy(), g['bk_std'])
+    assert np.array_equal(vy.sde(x0, ts)[1].numpy(), g['vy_g'])
+    vp = sde_lib.VPSDE(0.1, 20., 1000)
+    for a, b in zip(vp.marginal_prob(x0, ts), (g['vp_mean'], g['vp_std'])):
+        assert np.array_equal(a.numpy(), b)
+    for a, b in zip(vp.discretize(x0, ts), (g['vp_f'], g['vp_G'])):
+        assert np.array_equal(a.numpy(), b)
+    for a, b in zip(vp.sde(x0, ts), (g['vp_drift'], g['vp_diff'])):
+        assert np.array_equal(a.numpy(), b)
+
+
+def test_reverse_sde_objects():
+    """reverse() returns a subclass instance with the reference's rsde algebra (sde_lib.py:65-142)."""
+    from conditional_score_diffusion_amd import sde_lib
+    sde = sde_lib.VESDE(0.01, 50., 100)
+    score = lambda x, t: -x                      # noqa: E731
+    r = sde.reverse(score)
+    assert isinstance(r, sde_lib.VESDE) and r.N == 100 and r.T == 1
+    x, t = torch.randn(3, 1, 2, 2), torch.tensor([0.9, 0.5, 0.1])
+    f, G = r.discretize(x, t)
+    f0, G0 = sde.discretize(x, t)
+    assert torch.allclose(f, f0 - G0[:, None, None, None] ** 2 * score(x, t)) and torch.equal(G, G0)
+    rp = sde.reverse(score, probability_flow=True)
+    f, G = rp.discretize(x, t)
+    assert torch.allclose(f, f0 - G0[:, None, None, None] ** 2 * score(x, t) * 0.5) and float(G.abs().max()) == 0
+    csde = sde_lib.cVESDE(0.01, 50., 100)
+    rc = csde.reverse(lambda x, y, t: -(x - y))
+    f, G = rc.discretize(x, x * 0, t)
+    assert torch.allclose(f, f0 + G0[:, None, None, None] ** 2 * x)
+
+
+def test_fused_step_scalars_match_golden(golden_dir):
+    from conditional_score_diffusion_amd import sde_lib
+    from conditional_score_diffusion_amd.sampling import fused
+    g = np.load(os.path.join(golden_dir, 'sde_tables.npz'))
+    sde = sde_lib.cVESDE(5e-3, np.sqrt(np.prod([3, 160, 160])), 1000)
+    for n in (50, 1000):
+        ts, labels, std_x, G, std_y = fused.step_scalars(sde, n, 1e-5)
+        assert std_y is None
+        assert np.array_equal(labels.numpy(), g['labels%d' % n])
+        assert np.array_equal(std_x.numpy(), g['std%d' % n])
+        assert np.array_equal(G.numpy(), g['G%d' % n])
+    pair = {'x': sde, 'y': sde_lib.VESDE(5e-3, 1.0, 1000)}
+    assert fused.step_scalars(pair, 10, 1e-5)[4].shape == (10,)
+
+
+def test_no_cpu_fallback():
+    """CPU tensors must be refused by the product path - loudly."""
+    from conditional_score_diffusion_amd import ops
+    from conditional_score_diffusion_amd.models import utils as mutils
+    cfg, B = cases.case_config('sr3_tiny')
+    model = mutils.create_model(cfg).eval()
+    x = torch.zeros(B, 3, 20, 20)
+    with pytest.raises(RuntimeError):
+        model({'x': x, 'y': x}, torch.zeros(B))
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 8, 8, 8), torch.zeros(8, 8, 3, 3))
+    with pytest.raises(RuntimeError):
+        ops.groupnorm_act(torch.zeros(1, 32, 4, 4), torch.ones(32), torch.zeros(32))
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'conditional_score_diffusion_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert 'score_oracle' not in txt and 'import oracle' not in txt and 'from oracle' not in txt, f
+
+
+def test_config_dict_loads_reference_style_config(tmp_path):
+    from conditional_score_diffusion_amd.config_dict import ConfigDict, load_reference_config
+    p = tmp_path / 'cfg.py'
+    p.write_text('import ml_collections\n'
+                 'def get_config():\n'
+                 '  config = ml_collections.ConfigDict()\n'
+                 '  config.model = model = ml_collections.ConfigDict()\n'
+                 '  model.nf = 96\n'
+                 '  model.ch_mult = (1, 1, 2)\n'
+                 '  config.seed = 42\n'
+                 '  return config\n')
+    c = load_reference_config(str(p))
+    assert isinstance(c, ConfigDict) and c.model.nf == 96 and c.model.ch_mult == (1, 1, 2) and c.seed == 42
+    with pytest.raises(AttributeError):
+        c.model.missing

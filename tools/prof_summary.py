@@ -1,0 +1,43 @@
+"""Summarise a rocprofv3 kernel-trace csv per (kernel, grid) and PMC counter csv per kernel."""
+import collections
+import csv
+import sys
+
+
+def trace(path, filt='conv_f32'):
+    rows = list(csv.DictReader(open(path)))
+    agg = collections.OrderedDict()
+    for r in rows:
+        n = r['Kernel_Name']
+        if filt not in n:
+            continue
+        key = (n.split('(')[0].replace('void csd::', ''), int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']),
+               r['VGPR_Count'], r['Accum_VGPR_Count'], r['LDS_Block_Size'])
+        d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+        a = agg.setdefault(key, [0, 0, 10 ** 18])
+        a[0] += 1
+        a[1] += d
+        a[2] = min(a[2], d)
+    for k, v in agg.items():
+        print('%-34s wgs=%-6d vgpr=%s agpr=%s lds=%s  n=%d avg=%.1f us min=%.1f us' % (k + (v[0], v[1] / v[0] / 1e3, v[2] / 1e3)))
+
+
+def counters(path, filt='conv_f32'):
+    rows = list(csv.DictReader(open(path)))
+    agg = collections.OrderedDict()
+    for r in rows:
+        n = r['Kernel_Name']
+        if filt not in n:
+            continue
+        key = (n.split('(')[0].replace('void csd::', ''), int(r['Grid_Size']) // int(r['Workgroup_Size']), r['Counter_Name'])
+        a = agg.setdefault(key, [0, 0.0])
+        a[0] += 1
+        a[1] += float(r['Counter_Value'])
+    for k, v in agg.items():
+        print('%-34s wgs=%-6d %-28s avg=%.4g (n=%d)' % (k + (v[1] / v[0], v[0])))
+
+
+if __name__ == '__main__':
+    kind, path = sys.argv[1], sys.argv[2]
+    filt = sys.argv[3] if len(sys.argv) > 3 else 'conv_f32'
+    (trace if kind == 'trace' else counters)(path, filt)
