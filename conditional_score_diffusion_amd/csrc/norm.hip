@@ -132,6 +132,74 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
   }
 }
 
+// GroupNorm affine + activation + fp16 split, ONCE per element (consumer: conv_f16_kernel<IN16>).
+// HBM-bound stream: grid (chunks, B); a thread owns 8 fixed channels (its scale/shift live in registers
+// for the whole block), sweeps pixel rows: two float4 in, one 16-byte store per plane out.
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+#define GA_THREADS 256
+__global__ __launch_bounds__(GA_THREADS) void gn_apply16_kernel(
+    const float* __restrict__ src0, const float* __restrict__ src1, int C0, int C1,
+    const float* __restrict__ nscale, const float* __restrict__ nshift, half8_t* __restrict__ hi,
+    half8_t* __restrict__ lo, int HW, int act, int nchunk) {
+  const int C = C0 + C1;
+  const int C8 = C >> 3;
+  const int rows = GA_THREADS / C8;           // pixel rows per sweep (>= 1: C <= 2048)
+  const int tid = threadIdx.x;
+  const int row = tid / C8;
+  const int c = (tid - row * C8) * 8;
+  if (row >= rows) return;
+  const int b = blockIdx.y;
+  const int per = (HW + nchunk - 1) / nchunk;
+  const int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
+  const float* src;
+  int Cs;
+  if (c < C0) { src = src0 + (size_t)b * HW * C0 + c; Cs = C0; }
+  else { src = src1 + (size_t)b * HW * C1 + (c - C0); Cs = C1; }
+  const float4 sca = *reinterpret_cast<const float4*>(nscale + (size_t)b * C + c);
+  const float4 scb = *reinterpret_cast<const float4*>(nscale + (size_t)b * C + c + 4);
+  const float4 sha = *reinterpret_cast<const float4*>(nshift + (size_t)b * C + c);
+  const float4 shb = *reinterpret_cast<const float4*>(nshift + (size_t)b * C + c + 4);
+  const float sc[8] = {sca.x, sca.y, sca.z, sca.w, scb.x, scb.y, scb.z, scb.w};
+  const float sh[8] = {sha.x, sha.y, sha.z, sha.w, shb.x, shb.y, shb.z, shb.w};
+  half8_t* hdst = hi + ((size_t)b * HW * C + c) / 8;
+  half8_t* ldst = lo ? lo + ((size_t)b * HW * C + c) / 8 : nullptr;
+  for (int p = p0 + row; p < p1; p += rows) {
+    const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)p * Cs);
+    const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)p * Cs + 4);
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    half8_t h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = v[j] * sc[j] + sh[j];
+      switch (act) {
+        case CSD_ACT_SWISH: t = t * __frcp_rn(1.0f + __expf(-t)); break;
+        case CSD_ACT_RELU: t = t > 0.f ? t : 0.f; break;
+        case CSD_ACT_LRELU: t = t > 0.f ? t : 0.2f * t; break;
+        case CSD_ACT_ELU: t = t > 0.f ? t : expm1f(t); break;
+        default: break;
+      }
+      h[j] = (_Float16)t;
+      l[j] = (_Float16)(t - (float)h[j]);
+    }
+    hdst[(size_t)p * C8] = h;
+    if (ldst) ldst[(size_t)p * C8] = l;
+  }
+}
+
+int gn_apply16_launch(const float* src0, const float* src1, int C0, int C1, const float* nscale, const float* nshift,
+                      void* hi, void* lo, int B, int HW, int act, hipStream_t s) {
+  const int C = C0 + C1;
+  CSD_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && C / 8 <= GA_THREADS, "gn_apply16: channels must be multiples of 8, <= 2048");
+  int nchunk = cdiv(4096, B);
+  const int maxchunk = cdiv(HW, 16);
+  if (nchunk > maxchunk) nchunk = maxchunk;
+  if (nchunk < 1) nchunk = 1;
+  hipLaunchKernelGGL(gn_apply16_kernel, dim3(nchunk, B), dim3(GA_THREADS), 0, s, src0, src1, C0, C1, nscale, nshift,
+                     static_cast<half8_t*>(hi), static_cast<half8_t*>(lo), HW, act, nchunk);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
 int gn_plan(GNPlan* p, int B, int HW, int C0, int C1, int G) {
   const int C = C0 + C1;
   CSD_REQUIRE(C % 4 == 0 && C0 % 4 == 0 && C <= 1024, "groupnorm: C=%d+%d unsupported", C0, C1);

@@ -11,6 +11,7 @@ using namespace csd;
 
 namespace {
 inline int ceil8(int v) { return (v + 7) / 8 * 8; }
+inline int ceil16(int v) { return (v + 15) / 16 * 16; }
 inline size_t al64(size_t v) { return (v + 63) / 64 * 64; }
 }  // namespace
 
@@ -69,31 +70,42 @@ static int conv_api_plan(ConvPlan* p, int B, int Cin, int Cout, int H, int W, in
 extern "C" size_t csd_conv_scratch_bytes(int B, int Cin, int Cout, int H, int W, int ksize, int up2) {
   ConvPlan p;
   if (conv_api_plan(&p, B, Cin, Cout, H, W, ksize, 1, 0, up2)) return 0;
-  return (al64((size_t)B * H * W * p.C0) + al64(conv_packed_floats(p)) + al64((size_t)p.CoutPad)) * sizeof(float) + 1024;
+  // sized for the largest packed layout (fp32 fragments; the fp16 hi+lo layout is the same size)
+  return (al64((size_t)B * H * W * ceil16(Cin)) + al64(conv_packed_floats(p)) * 2 + al64((size_t)p.CoutPad) +
+          al64((size_t)B * p.OH * p.OW * Cout)) * sizeof(float) + 4096;
 }
 
 extern "C" int csd_conv2d(const float* x, const float* weight, const float* bias, float* y, int B, int Cin, int Cout,
                           int H, int W, int ksize, int stride, int pad_mode, int up2, int precision, void* scratch,
                           void* stream) {
   CSD_REQUIRE(x && weight && y && scratch, "conv2d: null argument");
-  CSD_REQUIRE(precision == CSD_PREC_F32, "conv2d: precision %d not available in this build", precision);
+  CSD_REQUIRE(precision >= CSD_PREC_F32 && precision <= CSD_PREC_F16, "conv2d: bad precision id %d", precision);
   hipStream_t s = (hipStream_t)stream;
   ConvPlan p;
   int rc = conv_api_plan(&p, B, Cin, Cout, H, W, ksize, stride, pad_mode, up2);
   if (rc) return rc;
+  int ns = precision_ns(precision);
+  if (ns) {   // fp16 MFMA kernel where it applies (3x3 stride 1, Cin padded to 16), else fp32 kernel
+    ConvPlan q = p;
+    q.C0 = ceil16(Cin);
+    if (conv16_supported(q) && conv16_plan_tiles(&q, ns) == CSD_OK) p = q; else ns = 0;
+  }
   float* f = static_cast<float*>(scratch);
-  float* xh = f; f += al64((size_t)B * H * W * p.C0);
-  float* wp = f; f += al64(conv_packed_floats(p));
-  float* bp = f;
+  float* xh = f; f += al64((size_t)B * H * W * ceil16(Cin));
+  float* wp = f; f += al64(conv_packed_floats(p)) * 2;
+  float* bp = f; f += al64((size_t)p.CoutPad);
+  float* yh = f;
   if ((rc = nchw_to_nhwc_launch(x, xh, B, Cin, H * W, p.C0, p.C0, s))) return rc;
-  if ((rc = conv_pack_weight(p, weight, 0, Cin, Cout, 0, wp, s))) return rc;
+  rc = ns ? conv16_pack_weight(p, ns, weight, 0, Cin, Cout, 0, wp, s) : conv_pack_weight(p, weight, 0, Cin, Cout, 0, wp, s);
+  if (rc) return rc;
   CSD_CHECK_HIP(hipMemsetAsync(bp, 0, (size_t)p.CoutPad * sizeof(float), s));
   if (bias) CSD_CHECK_HIP(hipMemcpyAsync(bp, bias, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.src0 = xh; a.wpack = wp; a.bias = bp; a.out = y;
-  a.out_stride = Cout; a.out_nchw = 1; a.out_scale = 1.f;
-  return conv_launch(p, a, s);
+  a.src0 = xh; a.wpack = wp; a.bias = bp; a.out = yh;
+  a.out_stride = Cout; a.out_nchw = 0; a.out_scale = 1.f;
+  if ((rc = ns ? conv16_launch(p, ns, a, s) : conv_launch(p, a, s))) return rc;
+  return nhwc_to_nchw_launch(yh, y, B, Cout, p.OH * p.OW, Cout, s);
 }
 
 // ---- attention ------------------------------------------------------------------------------------------

@@ -83,6 +83,7 @@ struct Module {
 struct PackedConv {
   ConvPlan proto;          // channel-level fields only (C0,C1,Cout,taps,KC,NT,CoutPad)
   size_t w_off = 0, b_off = 0;   // float offsets in the packed buffer
+  int ns = 0;                    // 0: fp32 kernel layout; 1/2: fp16 kernel layout with ns planes
   struct Src { int param_w, param_b, layout, cout_src, cout_off, cin_src; };
   std::vector<Src> srcs;
 };
@@ -92,8 +93,8 @@ struct Net;
 // ---------------------------------------------------------------------------------------------
 // execution plan for one batch size
 // ---------------------------------------------------------------------------------------------
-enum OpKind { OP_ASSEMBLE, OP_TEMB, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_CONV, OP_ATTN, OP_AVGPOOL, OP_UPNEAR,
-              OP_TO_NCHW };
+enum OpKind { OP_ASSEMBLE, OP_TEMB, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_GN_APPLY16, OP_CONV, OP_ATTN, OP_AVGPOOL,
+              OP_UPNEAR, OP_TO_NCHW };
 
 static const size_t NONE = (size_t)-1;
 
@@ -222,7 +223,7 @@ static int build_modules(Net& n) {
               c.image_size, c.n_levels - 1);
   CSD_REQUIRE(c.x_channels >= 1 && c.x_channels + c.y_channels <= 8, "unet: x+y channels must be <= 8");
   CSD_REQUIRE(c.act >= CSD_ACT_SWISH && c.act <= CSD_ACT_ELU, "unet: bad activation id %d", c.act);
-  CSD_REQUIRE(c.precision == CSD_PREC_F32, "unet: precision %d not available in this build", c.precision);
+  CSD_REQUIRE(c.precision >= CSD_PREC_F32 && c.precision <= CSD_PREC_F16, "unet: bad precision id %d", c.precision);
   auto add = [&](ModKind k, int cin, int cout) {
     Module m;
     m.kind = k; m.idx = (int)n.mods.size(); m.cin = cin; m.cout = cout;
@@ -340,12 +341,19 @@ static int build_packed_layout(Net& n) {
     n.copies.push_back(cpy);
     n.copy_off[pname] = cpy.off;
   };
+  const int net_ns = precision_ns(n.cfg.precision);
   auto add_conv = [&](const std::string& key, int c0, int c1, int cout, int taps,
-                      std::vector<PackedConv::Src> srcs) -> int {
+                      std::vector<PackedConv::Src> srcs, bool stride1 = true) -> int {
     PackedConv pc;
     int rc = proto_conv(&pc.proto, c0, c1, cout, taps);
     if (rc) return rc;
-    pc.w_off = take(conv_packed_floats(pc.proto));
+    if (net_ns && stride1 && conv16_supported(pc.proto)) {
+      pc.ns = net_ns;
+      if ((rc = conv16_plan_tiles(&pc.proto, pc.ns))) return rc;
+      pc.w_off = take(conv16_packed_bytes(pc.proto, pc.ns) / sizeof(float) + 1);
+    } else {
+      pc.w_off = take(conv_packed_floats(pc.proto));
+    }
     pc.b_off = take((size_t)pc.proto.CoutPad);
     pc.srcs = srcs;
     n.pconv_by_name[key] = (int)n.pconvs.size();
@@ -411,7 +419,8 @@ static int build_packed_layout(Net& n) {
   auto resample_layout = [&](Module& m) -> int {
     if (!c.resamp_with_conv) return CSD_OK;
     return add_conv(std::to_string(m.idx) + ".Conv_0", m.cin, 0, m.cin, 9,
-                    {{n.P(mname(m.idx, "Conv_0.weight")), n.P(mname(m.idx, "Conv_0.bias")), 0, m.cin, 0}});
+                    {{n.P(mname(m.idx, "Conv_0.weight")), n.P(mname(m.idx, "Conv_0.bias")), 0, m.cin, 0}},
+                    /*stride1=*/m.kind != M_DOWN);
   };
   auto is_attn = [&](int res) {
     for (int i = 0; i < c.n_attn; ++i) if (c.attn_resolutions[i] == res) return true;
@@ -509,13 +518,34 @@ struct Builder {
     o.cp.B = B; o.cp.IH = ih; o.cp.IW = iw;
     o.cp.stride = stride; o.cp.pad = pad; o.cp.up = up;
     o.cp.OH = (ih << up) / stride; o.cp.OW = (iw << up) / stride;
-    if (conv_plan_tiles(&o.cp)) { rc = CSD_ERR_INVALID; return NONE; }
+    o.i4 = pc.ns;
+    if (pc.ns ? conv16_plan_tiles(&o.cp, pc.ns) : conv_plan_tiles(&o.cp)) { rc = CSD_ERR_INVALID; return NONE; }
     // the packed layout depends on KC only (not on NT / tile shape)
     if (o.cp.KC != pc.proto.KC) { set_error("conv plan/pack mismatch"); rc = CSD_ERR_INVALID; return NONE; }
     o.a = src0; o.b = src1; o.pk0 = pc.w_off; o.pk1 = pc.b_off;
     o.c = res;
     o.d = norm ? nscale : NONE;
     o.e = norm ? nshift : NONE;
+    size_t hi16 = NONE, lo16 = NONE;
+    if (pc.ns && norm) {
+      // fp16 kernel: normalise + activate + split ONCE per element into fp16 planes, conv copies them
+      const size_t nh = ((size_t)B * ih * iw * (o.cp.C0 + o.cp.C1) + 1) / 2;      // halves -> floats
+      Op ap;
+      ap.kind = OP_GN_APPLY16;
+      ap.a = src0; ap.b = src1; ap.i0 = o.cp.C0; ap.i1 = o.cp.C1; ap.i2 = ih * iw;
+      ap.d = nscale; ap.e = nshift; ap.act = act;
+      hi16 = ar.alloc(nh);
+      if (pc.ns == 2) lo16 = ar.alloc(nh);
+      ap.out = hi16; ap.c = lo16;
+      ap.cls = CSD_PROF_GN_APPLY;
+      ap.bytes = (double)B * ih * iw * (o.cp.C0 + o.cp.C1) * (4 + 2 * pc.ns);
+      pl.ops.push_back(ap);
+      pl.launches += 1;
+      o.a = hi16; o.b = lo16;
+      o.cp.C0 = o.cp.C0 + o.cp.C1; o.cp.C1 = 0;
+      o.d = NONE; o.e = NONE;
+      o.i3 = 1;                                   // in16
+    }
     o.temb_base = dense_all;
     o.act = act;
     o.temb_col = temb_col;
@@ -525,6 +555,8 @@ struct Builder {
     o.out = external_nchw ? NONE : ar.alloc(out_elems);
     o.cls = o.cp.taps == 1 ? CSD_PROF_CONV1X1 : ((stride == 1 && !up) ? CSD_PROF_CONV3X3 : CSD_PROF_CONV3X3_RESAMPLE);
     pl.ops.push_back(o);
+    ar.release(hi16);      // (plan-time lifetimes: the planes die right after this conv)
+    ar.release(lo16);
     const int cin = real_cin > 0 ? real_cin : (o.cp.C0 + o.cp.C1);
     count(2.0 * out_elems * cin * o.cp.taps, ((double)B * ih * iw * cin + (double)out_elems) * 4);
     return o.out;
@@ -776,6 +808,9 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         rc = gn_finalize_launch(o.gp, reinterpret_cast<const double*>(W(o.a)), pk + o.pk0, pk + o.pk1, 1e-6f,
                                 W(o.out), W(o.b), s);
         break;
+      case OP_GN_APPLY16:
+        rc = gn_apply16_launch(W(o.a), W(o.b), o.i0, o.i1, W(o.d), W(o.e), W(o.out), W(o.c), B, o.i2, o.act, s);
+        break;
       case OP_CONV: {
         ConvArgs a;
         a.src0 = W(o.a); a.src1 = W(o.b);
@@ -790,7 +825,7 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         a.out_nchw = o.out_external;
         a.act = o.act;
         a.out_scale = 1.f;
-        rc = conv_launch(o.cp, a, s);
+        rc = o.i4 ? conv16_launch(o.cp, o.i4, a, s, o.i3 != 0) : conv_launch(o.cp, a, s);
         break;
       }
       case OP_ATTN:
@@ -847,8 +882,11 @@ static int pack_all(Net& n, float* pk, hipStream_t s) {
     if ((rc = dev_fill(pk + pc.b_off, 0.f, (size_t)pc.proto.CoutPad, s))) return rc;
     for (auto& src : pc.srcs) {   // sources are listed with ascending cout_off, first one clears the tensor
       const int cin_src = src.cin_src > 0 ? src.cin_src : pc.proto.C0 + pc.proto.C1;
-      if ((rc = conv_pack_weight(pc.proto, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
-                                 src.cout_off, pk + pc.w_off, s))) return rc;
+      rc = pc.ns ? conv16_pack_weight(pc.proto, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
+                                      src.cout_off, pk + pc.w_off, s)
+                 : conv_pack_weight(pc.proto, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
+                                    src.cout_off, pk + pc.w_off, s);
+      if (rc) return rc;
       if ((rc = dev_copy(n.params[src.param_b].ptr, pk + pc.b_off + src.cout_off, (size_t)src.cout_src, s))) return rc;
     }
   }

@@ -15,6 +15,7 @@ arithmetic runs in libcsd_hip.so.  There is no PyTorch fallback.
 """
 import ctypes
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -44,9 +45,18 @@ class HipUNet(nn.Module):
 
     arch = 0
 
-    def __init__(self, config, precision='fp32'):
+    def __init__(self, config, precision=None):
         super().__init__()
         m, d = config.model, config.data
+        # arithmetic of the 3x3 contractions: 'fp32' (exact fp32 MFMA), 'fp16x3' (split-fp16, fp32-class
+        # accuracy), 'fp16'.  Not a reference key: config.model.csd_precision or $CSD_PRECISION select it.
+        if precision is None:
+            precision = m.get('csd_precision', None) if hasattr(m, 'get') else getattr(m, 'csd_precision', None)
+        if precision is None:
+            precision = os.environ.get('CSD_PRECISION', 'fp32')
+        if precision not in _lib.PREC_IDS:
+            raise ValueError('unknown csd precision %r (choose from %s)' % (precision, sorted(_lib.PREC_IDS)))
+        self.precision = precision
         self.nf = m.nf
         self.num_res_blocks = m.num_res_blocks
         self.attn_resolutions = tuple(m.attn_resolutions)

@@ -61,7 +61,8 @@ enum {
   CSD_PROF_ATTENTION = 5,
   CSD_PROF_SAMPLER = 6,           /* predictor / corrector updates (+ norms)                  */
   CSD_PROF_OTHER = 7,             /* input assembly, time embedding, dense layers             */
-  CSD_PROF_NUM_CLASSES = 8
+  CSD_PROF_GN_APPLY = 8,          /* GroupNorm+activation+fp16 split pass (fp16 conv modes)   */
+  CSD_PROF_NUM_CLASSES = 9
 };
 int csd_profile_start(void);
 int csd_profile_stop(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes);

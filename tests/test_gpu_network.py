@@ -22,9 +22,10 @@ def rel(a, b, floor=0.0):
     return np.abs(a - b).max() / max(np.abs(b).max(), floor, 1e-30)
 
 
-def build(case_or_cfg):
+def build(case_or_cfg, precision='fp32'):
     from conditional_score_diffusion_amd.models import utils as mutils
     cfg = cases.case_config(case_or_cfg)[0] if isinstance(case_or_cfg, str) else case_or_cfg
+    cfg.model.csd_precision = precision
     nc = so.NetCfg.from_config(cfg)
     p = so.synth_params(so.ddpm_param_shapes(nc), 0)
     model = mutils.create_model(cfg)
@@ -101,6 +102,36 @@ def test_pc_trajectory_vs_golden(golden_dir, case, p_steps):
     assert err < 2e-4, (case, p_steps, err)          # what the fp32-MFMA path should comfortably hold
     if ev is not None:
         assert np.abs(ev.numpy() - g['pc10_evolution']).max() / smax < 2e-4
+
+
+@pytest.mark.parametrize('precision,tol_net,tol_traj', [('fp16x3', 1e-4, 2e-4), ('fp16', 2e-2, 1e-3)])
+@pytest.mark.parametrize('case', ['sr3_tiny', 'cmde_tiny'])
+def test_fp16_mfma_modes_vs_golden(golden_dir, case, precision, tol_net, tol_traj):
+    """the reduced-precision conv modes against the SAME reference fixtures: split-fp16 must hold the
+    fp32 bounds, plain fp16 must hold the north-star 1e-3 trajectory tolerance (50 steps)"""
+    from conditional_score_diffusion_amd.sampling import conditional
+    from conditional_score_diffusion_amd.sampling.correctors import get_corrector
+    from conditional_score_diffusion_amd.sampling.predictors import get_predictor
+    g = np.load(os.path.join(golden_dir, case + '.npz'))
+    cfg, nc, p, model = build(case, precision)
+    sde = sdes_for(cfg)
+    y = cases.case_y(case).to(dev())
+    B = y.shape[0]
+    x = torch.from_numpy(g['x1']).to(dev())
+    t = torch.ones(B, device=dev()) * 0.5
+    with torch.no_grad():
+        net = model({'x': x, 'y': y}, t * (cfg.model.num_scales - 1))
+    if isinstance(net, dict):
+        net = torch.cat([net['x'], net['y']], 1)
+    e_net = rel(net.cpu().numpy(), g['net1'])
+    xs = (B,) + tuple(cfg.data.shape_x)
+    sampler = conditional.get_pc_conditional_sampler(
+        sde, xs, get_predictor(cfg.sampling.predictor), get_corrector(cfg.sampling.corrector),
+        snr=cfg.sampling.snr, p_steps=50, c_steps=1, continuous=True, denoise=True, eps=1e-5)
+    res, _ = sampler(model, y, noise_tape=cases.tape(cases.pc_tape_shapes(case, 50)))
+    e_traj = rel(res.cpu().numpy(), g['pc50'], floor=cfg.model.sigma_max_x)
+    print('precision %s %s: net err %.3e, 50-step trajectory err %.3e' % (precision, case, e_net, e_traj))
+    assert e_net < tol_net and e_traj < tol_traj, (e_net, e_traj)
 
 
 def test_generic_per_step_path_matches_fused():

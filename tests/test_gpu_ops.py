@@ -59,6 +59,23 @@ def test_conv2d(B, Cin, Cout, H, ks, stride, up2):
     assert rel(out, ref) < 2e-6 * max(1, (Cin * ks * ks) ** 0.5 / 8)   # fp32 dot of length K
 
 
+F16_CASES = [c for c in CONV_CASES if c[4] == 3 and c[5] == 1]
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,ks,stride,up2', F16_CASES)
+@pytest.mark.parametrize('precision,tol', [('fp16x3', 2e-6), ('fp16', 2e-3)])
+def test_conv2d_fp16_mfma(B, Cin, Cout, H, ks, stride, up2, precision, tol):
+    """split-fp16 (3 MFMAs) must be fp32-class; plain fp16 is bounded by the operand rounding (2^-11)"""
+    from conditional_score_diffusion_amd import ops
+    x = rnd(B, Cin, H, H, seed=1)
+    w = rnd(Cout, Cin, ks, ks, seed=2, scale=(1.0 / (Cin * ks * ks)) ** 0.5)
+    b = rnd(Cout, seed=3, scale=0.1)
+    xin = F.interpolate(x, scale_factor=2, mode='nearest') if up2 else x
+    ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1)
+    out = ops.conv2d(x.to(dev()), w.to(dev()), b.to(dev()), up2=up2, precision=precision)
+    assert rel(out, ref) < tol * max(1, (Cin * 9) ** 0.5 / 8)
+
+
 @pytest.mark.parametrize('B,C,H,G,act', [(2, 32, 20, 32, 'swish'), (3, 96, 10, 32, 'none'), (2, 288, 5, 32, 'swish'),
                                          (1, 96, 160, 32, 'swish'), (2, 64, 8, 16, 'relu')])
 def test_groupnorm_act(B, C, H, G, act):

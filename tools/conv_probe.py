@@ -33,7 +33,7 @@ def main():
         w = torch.randn(Cout, Cin, ks, ks, device=dev) * (1.0 / (Cin * ks * ks)) ** 0.5
         b = torch.randn(Cout, device=dev)
         for _ in range(reps):
-            y = ops.conv2d(x, w, b)
+            y = ops.conv2d(x, w, b, precision=os.environ.get('PREC', 'fp32'))
         torch.cuda.synchronize()
         fl = 2.0 * B * H * H * Cout * Cin * ks * ks
         print('shape', (B, Cin, Cout, H, ks), 'GFLOP %.1f' % (fl / 1e9), float(y.abs().mean()))

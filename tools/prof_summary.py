@@ -4,7 +4,7 @@ import csv
 import sys
 
 
-def trace(path, filt='conv_f32'):
+def trace(path, filt='conv_f'):
     rows = list(csv.DictReader(open(path)))
     agg = collections.OrderedDict()
     for r in rows:
@@ -22,7 +22,7 @@ def trace(path, filt='conv_f32'):
         print('%-34s wgs=%-6d vgpr=%s agpr=%s lds=%s  n=%d avg=%.1f us min=%.1f us' % (k + (v[0], v[1] / v[0] / 1e3, v[2] / 1e3)))
 
 
-def counters(path, filt='conv_f32'):
+def counters(path, filt='conv_f'):
     rows = list(csv.DictReader(open(path)))
     agg = collections.OrderedDict()
     for r in rows:
@@ -39,5 +39,5 @@ def counters(path, filt='conv_f32'):
 
 if __name__ == '__main__':
     kind, path = sys.argv[1], sys.argv[2]
-    filt = sys.argv[3] if len(sys.argv) > 3 else 'conv_f32'
+    filt = sys.argv[3] if len(sys.argv) > 3 else 'conv_f'
     (trace if kind == 'trace' else counters)(path, filt)
