@@ -375,30 +375,55 @@ __global__ __launch_bounds__(192, 1) void conv_f16_kernel(const void* __restrict
   }
 
   // ---- epilogue: this wave's 32 couts for all MT*32 pixels ----
+  // Every global read of the epilogue (residual, time embedding) is issued up front, back to back, so the
+  // workgroup pays ONE memory round trip - a load-use-load chain here costs 16 dependent HBM latencies per
+  // workgroup and was the single largest inefficiency of the first version (profiles/).
   const int ohw = k.OH * k.OW;
   const float wunscale = 1.0f / C16_WSCALE;
   const int col = (ng * k.nw + wave) * 32 + (lane & 31);
   if (col < k.Cout) {
     const float bv = k.a.bias ? k.a.bias[col] : 0.f;
+#ifndef CSD_C16_GRP
+#define CSD_C16_GRP 2
+#endif
+    constexpr int GRP = CSD_C16_GRP;       // M tiles per batch of epilogue loads (16 loads per lane each)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int g0 = 0; g0 < MT; g0 += GRP) {
+      int oidx[GRP][16];
+      float addv[GRP][16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
-        const int m = mt * 32 + row;
-        const int o = otab[m];
-        if (o < 0) continue;
-        float val = acc[mt][r] * wunscale + bv;
-        const int b = btab[m];
-        if (k.a.temb) val += k.a.temb[(size_t)b * k.a.temb_stride + col];
-        if (k.a.res) val += k.a.res[(size_t)o * k.Cout + col];
-        val *= k.a.out_scale;
-        if (k.a.out_nchw)
-          k.a.out[((size_t)b * k.Cout + col) * ohw + (o - b * ohw)] = val;
-        else
-          k.a.out[(size_t)o * k.a.out_stride + k.a.out_coff + col] = val;
-        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the loads hoisted ahead (VGPR pressure)
+      for (int g = 0; g < GRP; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oidx[g][r] = otab[(g0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
+#pragma unroll
+      for (int g = 0; g < GRP; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = oidx[g][r];
+          float a = 0.f;
+          if (o >= 0) {
+            if (k.a.res) a = k.a.res[(size_t)o * k.Cout + col];
+            if (k.a.temb) a += k.a.temb[(size_t)btab[(g0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] * k.a.temb_stride + col];
+          }
+          addv[g][r] = a;
+        }
+#pragma unroll
+      for (int g = 0; g < GRP; ++g) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = oidx[g][r];
+          if (o < 0) continue;
+          // (acc*2^-8 + bias) + temb + residual: same association as the reference's h + Dense(temb), x + h
+          const float val = ((acc[g0 + g][r] * wunscale + bv) + addv[g][r]) * k.a.out_scale;
+          if (k.a.out_nchw) {
+            const int b = btab[(g0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
+            k.a.out[((size_t)b * k.Cout + col) * ohw + (o - b * ohw)] = val;
+          } else {
+            k.a.out[(size_t)o * k.a.out_stride + k.a.out_coff + col] = val;
+          }
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }

@@ -266,28 +266,43 @@ __global__ __launch_bounds__(CONV_THREADS, 1) void conv_f32_kernel(const float* 
   }
 
   // ---- epilogue: bias + time embedding + residual, NHWC (or NCHW) store ----
+  // all global reads (residual / time embedding) are issued first, back to back: one memory round trip
+  // per workgroup instead of a load-use chain
   const int ohw = k.OH * k.OW;
+  int oidx[16], bidx[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    oidx[r] = otab[m];
+    bidx[r] = btab[m];
+  }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int col = (ng * NT + n) * 32 + (lane & 31);
-    if (col >= k.Cout) continue;
-    const float bv = k.a.bias ? k.a.bias[col] : 0.f;
+    if (col < k.Cout) {
+      float addv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int m = wave * 32 + row;
-      const int o = otab[m];
-      if (o < 0) continue;
-      float val = acc[n][r] + bv;
-      const int b = btab[m];
-      if (k.a.temb) val += k.a.temb[(size_t)b * k.a.temb_stride + col];
-      if (k.a.res) val += k.a.res[(size_t)o * k.Cout + col];
-      val *= k.a.out_scale;
-      if (k.a.out_nchw)
-        k.a.out[((size_t)b * k.Cout + col) * ohw + (o - b * ohw)] = val;
-      else
-        k.a.out[(size_t)o * k.a.out_stride + k.a.out_coff + col] = val;
+      for (int r = 0; r < 16; ++r) {
+        float a = 0.f;
+        if (oidx[r] >= 0) {
+          if (k.a.res) a = k.a.res[(size_t)oidx[r] * k.Cout + col];
+          if (k.a.temb) a += k.a.temb[(size_t)bidx[r] * k.a.temb_stride + col];
+        }
+        addv[r] = a;
+      }
+      const float bv = k.a.bias ? k.a.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = oidx[r];
+        if (o < 0) continue;
+        const float val = ((acc[n][r] + bv) + addv[r]) * k.a.out_scale;
+        if (k.a.out_nchw)
+          k.a.out[((size_t)bidx[r] * k.Cout + col) * ohw + (o - bidx[r] * ohw)] = val;
+        else
+          k.a.out[(size_t)o * k.a.out_stride + k.a.out_coff + col] = val;
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
