@@ -57,7 +57,8 @@ struct ConvPlan {
   // tiling (filled by conv_plan_tiles)
   int KC;                   // channels per LDS chunk (8 or 16)
   int NT;                   // 32-wide cout tiles per workgroup (1..3)
-  int MT;                   // fp16 kernel: 32-pixel M tiles per workgroup (2/4/8); fp32 kernel: unused
+  int MT;                   // fp16 kernel: 32-pixel M tiles per workgroup (2/4); fp32 kernel: unused
+  int KCS;                  // fp16 kernel, fp16 source: 16-channel sub-chunks per K stage (1 = chunk-wise)
   int TH, TW;               // output tile, TH*TW <= 128
   int PH, PW;               // staged source patch
   int tiles_x, tiles_y;     // tiles over (B*OH virtual rows, OW)
@@ -96,7 +97,8 @@ int conv_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s);
 // ns = 1 -> plain fp16 operands (F16).  Covers 3x3 stride-1 (optionally nearest-x2-fused) layers whose
 // Cin is a multiple of 16; everything else stays on the fp32 kernel.
 bool conv16_supported(const ConvPlan& p);
-int conv16_plan_tiles(ConvPlan* p, int ns);
+int conv16_kcs(int ns, int cin);
+int conv16_plan_tiles(ConvPlan* p, int ns, int kcs = 1);
 size_t conv16_packed_bytes(const ConvPlan& p, int ns);
 int conv16_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int cin_src, int cout_src,
                        int cout_off, void* wpack, hipStream_t s);

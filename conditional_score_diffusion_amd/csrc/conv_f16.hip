@@ -1,432 +1,8 @@
-// conv_f16.hip - 3x3 (stride 1, optional fused nearest-x2) convolution as an implicit GEMM on the
-// gfx950 fp16 matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate).
-//
-// Why: in fp32 the network is compute-bound at 157 TFLOP/s; the fp16 MFMA rate is
-// 16x higher.  Two arithmetic modes share this kernel (template NS):
-//   NS = 2  "F16X3": every operand is carried as hi + lo fp16 (hi = fp16(v), lo = fp16(v - hi)), and
-//           each product is formed as ah*bh + ah*bl + al*bh (three MFMAs, the 2^-22-relative al*bl
-//           term is dropped).  hi*hi is exact in fp32, accumulation is fp32 -> fp32-class results
-//           (1.7e-6 on the whole network, tests/) at 1/3 of the fp16 rate = 5.3x the fp32 rate.
-//   NS = 1  "F16":   plain fp16 operands, fp32 accumulate.
-// Weights are pre-scaled by 2^8 at pack time (exact) so their lo parts stay in the fp16 normal
-// range; the epilogue multiplies by 2^-8 (exact).
-//
-// Work decomposition ("waves split N"): a workgroup owns MT*32 output pixels (MT in {2,4,8}) of the
-// virtual tall image x NW cout tiles; it has NW waves and wave w owns ALL the pixels x cout tile w.
-//   * weights: every weight byte is fetched by exactly ONE wave of the workgroup, straight from L2
-//     in MFMA-fragment order (1 KiB per wave-instruction), and reused for MT MFMAs per product term
-//     - the earlier "waves split M" layout re-fetched each fragment in all 4 waves and was bound by
-//     the 64 B/clk/CU L1 path (ablation in profiles/);
-//   * activations: the staged halo patch (fp16 hi|lo planes, 16 channels per K chunk, built WHILE
-//     staging with the fused GroupNorm affine + SiLU) is read by every wave - 1 KiB of ds_read_b128
-//     per MFMA, i.e. 128 B/clk/CU at the full fp16 rate = half the LDS peak;
-//   * staging is cut into pieces interleaved with the K steps of the current chunk, so its VALU work
-//     (norm, SiLU, fp16 split) hides under the MFMAs and only 2 float4 per lane are in flight.
-//   One barrier per K chunk (double-buffered patch); no barrier on the weight path.
-#include <hip/hip_fp16.h>
-#include <stdlib.h>
-
-#include "common.h"
+// conv_f16.hip - host side of the fp16-MFMA convolution (planning, weight packing, launch) + the
+// instantiations for fp32 sources; the fp16-source (IN16) instantiations live in conv_f16_in16.hip.
+#include "conv_f16_kernel.h"
 
 namespace csd {
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-
-#ifndef CSD_CONV_ABLATE
-#define CSD_CONV_ABLATE 0   // tuning aid: 1 no B loads, 2 no A LDS reads, 4 no staging/barriers, 8 no masks, 16 no norm/act
-#endif
-#define C16_KC 16               // channels per K chunk (= one MFMA K step per tap)
-#define C16_PIECE 2             // staging slots (float4 per lane) per interleaved piece
-#define C16_MAX_PIECES 5
-#define C16_WSCALE 256.0f       // weight pre-scale (power of two: exact)
-// LDS patch row pitch in pixels is a template parameter (24 or 34): compile-time, so every tap offset is
-// an immediate.  34 serves TW = 32 tiles (one 32-pixel row per M tile: conflict-free ds_read_b128).
-#define C16_LDS_LIMIT (72 * 1024)   // patch double buffer budget: keeps 2 workgroups per CU
-
-struct Conv16KArgs {
-  ConvArgs a;
-  int B, IH, IW, OH, OW, C0, C1, Cout;
-  int stride, pad, up;
-  int TH, TW, PH, PW, tiles_x, n_groups, nblocks;
-  int nck, nw;              // K chunks; waves (= cout tiles) per workgroup
-};
-
-__device__ __forceinline__ float4 gload4f(const float* p) {
-  const v4f_t v = *(const __attribute__((address_space(1))) v4f_t*)(p);
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ half8 gload_h8(const char* p) {
-  return *(const __attribute__((address_space(1))) half8*)(p);
-}
-
-__device__ __forceinline__ float act16(float v, int act) {
-  switch (act) {
-    case CSD_ACT_SWISH: return v * __frcp_rn(1.0f + __expf(-v));
-    case CSD_ACT_RELU: return v > 0.f ? v : 0.f;
-    case CSD_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
-    case CSD_ACT_ELU: return v > 0.f ? v : expm1f(v);
-    default: return v;
-  }
-}
-
-// MASK: per-tap validity masks are only needed when a pixel tile can straddle two images of the
-// virtual tall image (TH does not divide OH: the 20x20 / 10x10 / 5x5 levels).  Otherwise every
-// out-of-image tap reads a zero the staging wrote, and no VALU is spent on masking.
-// IN16: the source is already fp16 (hi plane = g_src0, lo plane = g_src1 when NS == 2; one tensor of
-// C0 channels) - written by gn_apply16_kernel (GroupNorm affine + activation + fp16 split applied ONCE
-// per element) - and staging is a pure 16-byte copy.  Otherwise the source is fp32 NHWC (two-source
-// virtual concat allowed) and norm/act/convert run while staging (measured: that VALU work, repeated for
-// every halo pixel and every cout group, costs as much as all the MFMAs of the F16 mode).
-template <int MT, int NS, bool MASK, int PWC, bool IN16>
-__global__ __launch_bounds__(192, 1) void conv_f16_kernel(const void* __restrict__ g_src0v,
-                                                         const void* __restrict__ g_src1v,
-                                                         const char* __restrict__ g_wpack,
-                                                         const Conv16KArgs k) {
-  constexpr int TAPS = 9, KS = 3;
-  constexpr int PSB = 32 * NS + 16;          // bytes per staged pixel: [hi 16ch][lo 16ch] + pad
-  constexpr int NPIX = MT * 32;
-  extern __shared__ __attribute__((aligned(16))) char smem16[];
-  const float* const g_src0 = static_cast<const float*>(g_src0v);
-  const float* const g_src1 = static_cast<const float*>(g_src1v);
-
-  const int tid = threadIdx.x;
-  const int nthr = k.nw * 64;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kg = lane >> 5;                  // which 8 of the 16 K values this lane feeds
-
-  int w;
-  {
-    const int bid = blockIdx.x, nb = k.nblocks;
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int q = nb >> 3, r = nb & 7;
-    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  }
-  const int ng = w % k.n_groups;
-  const int tile = w / k.n_groups;
-  const int tile_y = tile / k.tiles_x;
-  const int tile_x = tile - tile_y * k.tiles_x;
-  const int ov0 = tile_y * k.TH;
-  const int ox0 = tile_x * k.TW;
-
-  const int S = k.stride, P = k.pad, U = k.up;
-  const int prow0 = (ov0 * S - P) >> U;
-  const int pcol0 = (ox0 * S - P) >> U;
-  const int patch_bytes = k.PH * PWC * PSB;
-  char* const buf0 = smem16;
-  char* const buf1 = smem16 + patch_bytes;
-  int* const otab = reinterpret_cast<int*>(smem16 + 2 * patch_bytes);   // [NPIX] output pixel index
-  int* const btab = otab + NPIX;                                        // [NPIX] sample index
-  const int npatch = k.PH * k.PW;
-  int* const stab = btab + NPIX;          // [npatch] staging: source pixel index (or -1)
-  int* const dtab = stab + npatch;        // [npatch] staging: LDS byte offset of the pixel inside a patch buffer
-  int* const ntab = dtab + npatch;        // [npatch] staging: sample * Cin (GroupNorm scale/shift row)
-
-  // ---- per-lane pixels: one per M tile.  LDS byte offset of tap (0,0) (+ this lane's K half),
-  // 3+3 validity bits and (x2-upsample mode) the two parity bits that make the tap map non-affine.
-  int base[MT];
-  unsigned vbits[MT];         // bit r: row tap r valid; bit 3+s: col tap s valid; bit 6/7: row/col parity
-  constexpr int rstride = PWC * PSB;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = mt * 32 + (lane & 31);
-    const int ty = m / k.TW;
-    const int tx = m - ty * k.TW;
-    const int ov = ov0 + ty, ox = ox0 + tx;
-    const bool mv = (m < k.TH * k.TW) && (ov < k.B * k.OH) && (ox < k.OW);
-    const int b = ov / k.OH;
-    const int oy = ov - b * k.OH;
-    if (wave == 0 && kg == 0) {
-      otab[m] = mv ? ov * k.OW + ox : -1;
-      btab[m] = mv ? b : 0;
-    }
-    const int IHe = k.IH << U, IWe = k.IW << U;
-    unsigned vb = 0;
-#pragma unroll
-    for (int r = 0; r < KS; ++r) {
-      const int iy = oy * S + r - P, ix = ox * S + r - P;
-      vb |= ((mv && iy >= 0 && iy < IHe) ? 1u : 0u) << r;
-      vb |= ((mv && ix >= 0 && ix < IWe) ? 1u : 0u) << (3 + r);
-    }
-    const int r0 = ov * S - P, c0 = ox * S - P;          // tap (0,0) coordinate before the >> U
-    vb |= (unsigned)(r0 & U) << 6;
-    vb |= (unsigned)(c0 & U) << 7;
-    vbits[mt] = vb;
-    base[mt] = mv ? ((r0 >> U) - prow0) * rstride + ((c0 >> U) - pcol0) * PSB + kg * 16 : kg * 16;
-  }
-  // tap (r,s) of pixel mt lives at base + roff(r) + coff(s):  U == 0: r*rstride, s*PSB
-  //                                                          U == 1: ((r + parity) >> 1) * stride
-  auto tap_off = [&](int mt, int r, int s) -> int {
-    if (U == 0) return base[mt] + r * rstride + s * PSB;
-    const int pr = (vbits[mt] >> 6) & 1, pc = (vbits[mt] >> 7) & 1;
-    return base[mt] + ((r + pr) >> 1) * rstride + ((s + pc) >> 1) * PSB;
-  };
-
-  // ---- staging, in pieces of C16_PIECE 16-byte slots per lane ----
-  // fp32 source: a slot = 4 channels of one patch pixel (4 slots per pixel per chunk)
-  // fp16 source: a slot = 8 channels of one plane    (2*NS slots per pixel per chunk)
-  // The pixel -> (source pixel, LDS destination, sample) map is the same for every K chunk: it is
-  // computed once (integer divisions, image-border tests) into three small LDS tables.
-  constexpr int SPP = IN16 ? 2 * NS : 4;          // slots per patch pixel
-  const int total4 = npatch * SPP;
-  const int Cin = k.C0 + k.C1;
-  for (int pix = tid; pix < npatch; pix += nthr) {
-    const int pr = pix / k.PW;
-    const int pc = pix - pr * k.PW;
-    const int vr = prow0 + pr, col = pcol0 + pc;
-    const bool inimg = vr >= 0 && vr < k.B * k.IH && col >= 0 && col < k.IW;
-    stab[pix] = inimg ? vr * k.IW + col : -1;
-    dtab[pix] = (pr * PWC + pc) * PSB;
-    ntab[pix] = inimg ? (vr / k.IH) * Cin : 0;
-  }
-  __syncthreads();
-  const int per_piece = nthr * C16_PIECE;
-  const int npieces = (total4 + per_piece - 1) / per_piece;            // <= C16_MAX_PIECES (host checked)
-  float4 stage[C16_PIECE], st_sc[C16_PIECE], st_sh[C16_PIECE];   // raw 16 bytes (+ GroupNorm scale/shift)
-  int st_pix[C16_PIECE];      // source pixel index (or -1) of the slots of the piece in flight
-  const bool has_norm = !IN16 && !(CSD_CONV_ABLATE & 16) && k.a.nscale != nullptr;
-  // slot e of the patch -> {source address, LDS byte offset}
-  auto slot_load = [&](int e, int cb, float4& v, float4& sc, float4& sh) -> int {
-    int sp = -1;
-    v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e < total4) {
-      const int pix = e / SPP, sub = e - pix * SPP;
-      sp = stab[pix];
-      if (sp >= 0) {
-        if (IN16) {
-          const _Float16* plane = static_cast<const _Float16*>((sub >> 1) ? g_src1v : g_src0v);
-          v = gload4f(reinterpret_cast<const float*>(plane + (size_t)sp * Cin + cb + (sub & 1) * 8));
-        } else {
-          const float* src;
-          int Cs, coff;
-          if (cb < k.C0) { src = g_src0; Cs = k.C0; coff = cb; }
-          else { src = g_src1; Cs = k.C1; coff = cb - k.C0; }
-          v = gload4f(src + (size_t)sp * Cs + coff + sub * 4);
-          if (has_norm) {     // issued together with the data: no dependent L2 round trip at conversion time
-            const int nb = ntab[pix] + cb + sub * 4;
-            sc = gload4f(k.a.nscale + nb);
-            sh = gload4f(k.a.nshift + nb);
-          }
-        }
-      }
-    }
-    return sp;
-  };
-  auto slot_store = [&](char* buf, int e, int sp, float4 v, const float4& sc, const float4& sh) {
-    if (e >= total4) return;
-    const int pix = e / SPP, sub = e - pix * SPP;
-    char* dst = buf + dtab[pix];
-    if (IN16) {
-      *reinterpret_cast<float4*>(dst + (sub >> 1) * 32 + (sub & 1) * 16) = v;     // raw copy of 8 halves
-      return;
-    }
-    if (has_norm && sp >= 0) {
-      v.x = act16(v.x * sc.x + sh.x, k.a.act);
-      v.y = act16(v.y * sc.y + sh.y, k.a.act);
-      v.z = act16(v.z * sc.z + sh.z, k.a.act);
-      v.w = act16(v.w * sc.w + sh.w, k.a.act);
-    }
-    dst += sub * 8;
-    half4 hi;
-    hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
-    *reinterpret_cast<half4*>(dst) = hi;
-    if (NS == 2) {
-      half4 lo;
-      lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
-      lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
-      *reinterpret_cast<half4*>(dst + 32) = lo;
-    }
-  };
-  auto stage_load = [&](int ck, int piece) {
-#pragma unroll
-    for (int j = 0; j < C16_PIECE; ++j)
-      st_pix[j] = slot_load(piece * per_piece + j * nthr + tid, ck * C16_KC, stage[j], st_sc[j], st_sh[j]);
-  };
-  auto stage_write_slot = [&](char* buf, int ck, int piece, int j) {
-    slot_store(buf, piece * per_piece + j * nthr + tid, st_pix[j], stage[j], st_sc[j], st_sh[j]);
-  };
-  auto stage_write = [&](char* buf, int ck, int piece) {
-#pragma unroll
-    for (int j = 0; j < C16_PIECE; ++j) stage_write_slot(buf, ck, piece, j);
-  };
-
-  floatx16 acc[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-
-  // weight stream of THIS wave's cout tile: [chunk][tap][plane hi|lo][lane][8 halves]; NS KiB per step
-  constexpr int STEP_BYTES = NS * 1024;
-  const size_t tile_stride = (size_t)k.nck * TAPS * STEP_BYTES;
-  const char* wstep = g_wpack + (size_t)(ng * k.nw + wave) * tile_stride + lane * 16;
-
-  // weight-fragment ring, BR-1 K steps ahead of the MFMAs: one step is only MT*32 (F16) / MT*96 (F16X3)
-  // MFMA cycles while an L2 hit costs ~500-800, so the prefetch distance must be several steps.
-  // BR divides the 9 steps of a chunk, which keeps the ring index a compile-time constant.
-#ifdef CSD_C16_BR
-  constexpr int BR = CSD_C16_BR;
-#else
-  constexpr int BR = 3;
-#endif
-  half8 breg[BR][NS];
-#pragma unroll
-  for (int q = 0; q < BR - 1; ++q)
-#pragma unroll
-    for (int p = 0; p < NS; ++p) breg[q][p] = gload_h8(wstep + (size_t)q * STEP_BYTES + p * 1024);
-  wstep += (size_t)(BR - 2) * STEP_BYTES;     // points at the newest prefetched step
-
-  // first chunk: issue EVERY piece's loads before converting any (one HBM round trip, not one per
-  // piece; the accumulators are not live yet, so the registers are free)
-  {
-    constexpr int N0 = C16_MAX_PIECES * C16_PIECE;
-    float4 v0[N0], sc0[N0], sh0[N0];
-    int sp0[N0];
-#pragma unroll
-    for (int j = 0; j < N0; ++j) sp0[j] = slot_load(j * nthr + tid, 0, v0[j], sc0[j], sh0[j]);
-#pragma unroll
-    for (int j = 0; j < N0; ++j) slot_store(buf0, j * nthr + tid, sp0[j], v0[j], sc0[j], sh0[j]);
-  }
-  __syncthreads();
-
-  for (int ck = 0; ck < k.nck; ++ck) {
-    const char* buf = (ck & 1) ? buf1 : buf0;
-    char* nbuf = (ck & 1) ? buf0 : buf1;
-    const bool more = !(CSD_CONV_ABLATE & 4) && (ck + 1 < k.nck);
-    // A-fragment ring, RING-1 fragments ahead of the MFMAs (statically indexed: everything below is
-    // unrolled).  One M-tile iteration is 32 (F16) / 96 (F16X3) MFMA cycles against ~120+ cycles of
-    // LDS latency, hence the deeper ring in F16 mode.
-#ifdef CSD_C16_RING
-    constexpr int RING = CSD_C16_RING;
-#else
-    constexpr int RING = 2;
-#endif
-    half8 areg[RING][NS];
-    auto load_frag = [&](int q) {      // q = st * MT + mt (compile-time after unrolling)
-      const int st_ = q / MT, mt_ = q % MT;
-      const char* p = buf + tap_off(mt_, st_ / KS, st_ % KS);
-#pragma unroll
-      for (int pl = 0; pl < NS; ++pl) areg[q % RING][pl] = *reinterpret_cast<const half8*>(p + pl * 32);
-    };
-#pragma unroll
-    for (int q = 0; q < RING - 1; ++q) load_frag(q);
-#pragma unroll
-    for (int st = 0; st < TAPS; ++st) {
-      const int bc = st % BR, bn = (st + BR - 1) % BR;
-      const int r = st / KS, s = st % KS;
-      // ---- weights of step st+BR-1 (BR-1 steps of slack past the end of the stream) ----
-      wstep += STEP_BYTES;
-#pragma unroll
-      for (int p = 0; p < NS; ++p) {
-        if (CSD_CONV_ABLATE & 1) breg[bn][p] = breg[bc][p];
-        else breg[bn][p] = gload_h8(wstep + p * 1024);
-      }
-      // ---- staging pieces of the NEXT chunk ride along: load at even steps, convert+store at odd ----
-      if (more && (st & 1) == 0 && (st >> 1) < (TAPS >> 1) && (st >> 1) < npieces) stage_load(ck + 1, st >> 1);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int q = st * MT + mt;
-        const int ac = q % RING;
-        // prefetch the fragment RING-1 iterations ahead
-        if (q + RING - 1 < TAPS * MT) {
-          if (!(CSD_CONV_ABLATE & 2)) load_frag(q + RING - 1);
-          else {
-#pragma unroll
-            for (int pl = 0; pl < NS; ++pl) areg[(q + RING - 1) % RING][pl] = areg[ac][pl];
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        half8 a[NS];
-        const bool v = !MASK || (((vbits[mt] >> r) & 1u) && ((vbits[mt] >> (3 + s)) & 1u));
-#pragma unroll
-        for (int pl = 0; pl < NS; ++pl) {
-          a[pl] = areg[ac][pl];
-          if (MASK && !(CSD_CONV_ABLATE & 8) && !v) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a[pl][e] = (_Float16)0.f;
-          }
-        }
-        if (NS == 2) {
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], breg[bc][0], acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], breg[bc][1], acc[mt], 0, 0, 0);
-        }
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], breg[bc][0], acc[mt], 0, 0, 0);
-        // odd steps: convert + store one staged slot of the next chunk INSIDE an MFMA block, so its
-        // VALU work issues while the matrix pipe is busy
-        if ((st & 1) == 1 && (st >> 1) < (TAPS >> 1)) {
-#pragma unroll
-          for (int j = 0; j < C16_PIECE; ++j)
-            if (mt == (j * MT) / C16_PIECE + (MT > 2 ? 1 : 0) && more && (st >> 1) < npieces)
-              stage_write_slot(nbuf, ck + 1, st >> 1, j);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (more && npieces > (TAPS >> 1)) {     // pieces that did not fit between the steps (large patches)
-      for (int piece = TAPS >> 1; piece < npieces; ++piece) {
-        stage_load(ck + 1, piece);
-        stage_write(nbuf, ck + 1, piece);
-      }
-    }
-    if (!(CSD_CONV_ABLATE & 4)) __syncthreads();
-  }
-
-  // ---- epilogue: this wave's 32 couts for all MT*32 pixels ----
-  // Every global read of the epilogue (residual, time embedding) is issued up front, back to back, so the
-  // workgroup pays ONE memory round trip - a load-use-load chain here costs 16 dependent HBM latencies per
-  // workgroup and was the single largest inefficiency of the first version (profiles/).
-  const int ohw = k.OH * k.OW;
-  const float wunscale = 1.0f / C16_WSCALE;
-  const int col = (ng * k.nw + wave) * 32 + (lane & 31);
-  if (col < k.Cout) {
-    const float bv = k.a.bias ? k.a.bias[col] : 0.f;
-#ifndef CSD_C16_GRP
-#define CSD_C16_GRP 2
-#endif
-    constexpr int GRP = CSD_C16_GRP;       // M tiles per batch of epilogue loads (16 loads per lane each)
-#pragma unroll
-    for (int g0 = 0; g0 < MT; g0 += GRP) {
-      int oidx[GRP][16];
-      float addv[GRP][16];
-#pragma unroll
-      for (int g = 0; g < GRP; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oidx[g][r] = otab[(g0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
-#pragma unroll
-      for (int g = 0; g < GRP; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o = oidx[g][r];
-          float a = 0.f;
-          if (o >= 0) {
-            if (k.a.res) a = k.a.res[(size_t)o * k.Cout + col];
-            if (k.a.temb) a += k.a.temb[(size_t)btab[(g0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] * k.a.temb_stride + col];
-          }
-          addv[g][r] = a;
-        }
-#pragma unroll
-      for (int g = 0; g < GRP; ++g) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o = oidx[g][r];
-          if (o < 0) continue;
-          // (acc*2^-8 + bias) + temb + residual: same association as the reference's h + Dense(temb), x + h
-          const float val = ((acc[g0 + g][r] * wunscale + bv) + addv[g][r]) * k.a.out_scale;
-          if (k.a.out_nchw) {
-            const int b = btab[(g0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
-            k.a.out[((size_t)b * k.Cout + col) * ohw + (o - b * ohw)] = val;
-          } else {
-            k.a.out[(size_t)o * k.a.out_stride + k.a.out_coff + col] = val;
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -441,7 +17,16 @@ bool conv16_supported(const ConvPlan& p) {
   return p.taps == 9 && p.stride == 1 && Cin % C16_KC == 0 && p.C0 % C16_KC == 0;
 }
 
-int conv16_plan_tiles(ConvPlan* p, int ns) {
+int conv16_kcs(int ns, int cin) {   // sub-chunks per stage for an fp16-source convolution
+  if (const char* f = getenv("CSD_FORCE_KCS")) {   // tuning aid
+    const int v = atoi(f);
+    if (v == 1 || (cin % (16 * v) == 0 && (v == 2 || (v == 3 && ns == 1)))) return v;
+  }
+  if (ns == 1) return cin % 48 == 0 ? 3 : (cin % 32 == 0 ? 2 : 1);
+  return cin % 32 == 0 ? 2 : 1;
+}
+
+int conv16_plan_tiles(ConvPlan* p, int ns, int kcs) {
   const int Cin = p->C0 + p->C1;
   CSD_REQUIRE(conv16_supported(*p), "conv16: unsupported shape (taps=%d stride=%d Cin=%d+%d)", p->taps, p->stride,
               p->C0, p->C1);
@@ -466,7 +51,10 @@ int conv16_plan_tiles(ConvPlan* p, int ns) {
     const int v = atoi(f);
     if (v == 2 || v == 4) mt_max = v;
   }
-  const int psb = 32 * ns + 16;
+  const int psb = 32 * ns * kcs + 16;
+  const int nbuf = kcs > 1 ? 1 : 2;
+  const int max_units = kcs > 1 ? 9 : C16_MAX_PIECES * C16_PIECE;
+  const int spp = kcs > 1 ? 2 * ns * kcs : 4;
   auto pitch = [&](int tw) { return extent(tw) <= 24 ? 24 : 34; };
   for (int mt = mt_max; mt >= 2; mt >>= 1) {
     const int npix = mt * 32;
@@ -476,9 +64,9 @@ int conv16_plan_tiles(ConvPlan* p, int ns) {
       if (extent(tw) > 34) continue;
       for (int th = npix / tw; th >= 1; --th) {
         const int patch = extent(th) * extent(tw);
-        const int lds = 2 * extent(th) * pitch(tw) * psb;
+        const int lds = nbuf * extent(th) * pitch(tw) * psb;
         if (lds > C16_LDS_LIMIT) continue;
-        if (patch * 4 > C16_MAX_PIECES * C16_PIECE * nw * 64) continue;
+        if (patch * spp > max_units * nw * 64) continue;
         const int cov = th * tw;
         if (cov > bcov || (cov == bcov && lds < blds)) { bcov = cov; blds = lds; btw = tw; bth = th; }
         break;
@@ -496,7 +84,8 @@ int conv16_plan_tiles(ConvPlan* p, int ns) {
   p->tiles_x = cdiv(p->OW, p->TW);
   p->tiles_y = cdiv(p->B * p->OH, p->TH);
   const int mt_sel = best_mt;
-  p->lds_bytes = (size_t)2 * p->PH * pitch(p->TW) * (32 * ns + 16) + (size_t)2 * mt_sel * 32 * sizeof(int) +
+  p->KCS = kcs;
+  p->lds_bytes = (size_t)nbuf * p->PH * pitch(p->TW) * psb + (size_t)2 * mt_sel * 32 * sizeof(int) +
                  (size_t)3 * p->PH * p->PW * sizeof(int);
   p->MT = mt_sel;
   CSD_REQUIRE(p->lds_bytes <= 160 * 1024, "conv16: LDS budget exceeded");
@@ -554,9 +143,9 @@ int conv16_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, in
   return CSD_OK;
 }
 
-template <int MT, int NS, bool MASK, int PWC, bool IN16>
+template <int MT, int NS, bool MASK, int PWC>
 static int launch16(const Conv16KArgs& k, size_t lds, hipStream_t s) {
-  auto kern = conv_f16_kernel<MT, NS, MASK, PWC, IN16>;
+  auto kern = conv_f16_kernel<MT, NS, MASK, PWC, false, 1>;
   static bool attr_set = false;
   if (!attr_set) {
     CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -568,6 +157,8 @@ static int launch16(const Conv16KArgs& k, size_t lds, hipStream_t s) {
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
+
+int conv16_launch_in16(const Conv16KArgs& k, const ConvPlan& p, int ns, bool mask, hipStream_t s);   // conv_f16_in16.hip
 
 int conv16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s, bool in16) {
   Conv16KArgs k;
@@ -581,26 +172,23 @@ int conv16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s, b
   k.nck = (p.C0 + p.C1) / C16_KC;
   k.nw = p.NT;
   CSD_REQUIRE(p.taps == 9, "conv16: only 3x3 kernels");
-  CSD_REQUIRE(cdiv(p.PH * p.PW * 4, k.nw * 64 * C16_PIECE) <= C16_MAX_PIECES, "conv16: patch too large");
   CSD_REQUIRE(!in16 || (p.C1 == 0 && a.nscale == nullptr), "conv16: fp16 sources are single-tensor and pre-normalised");
+  CSD_REQUIRE(in16 || p.KCS == 1, "conv16: multi-chunk stages need an fp16 source");
   // masks are needed iff a tile can straddle two images (or the x2-upsample parity map is in use)
   const bool mask = (p.OH % p.TH) != 0 || p.up != 0;
-#define CSD_C16_CASE2(MT_, NS_, MASK_, PWC_)                                      \
-  return in16 ? launch16<MT_, NS_, MASK_, PWC_, true>(k, p.lds_bytes, s)           \
-              : launch16<MT_, NS_, MASK_, PWC_, false>(k, p.lds_bytes, s);
+  if (in16) return conv16_launch_in16(k, p, ns, mask, s);
 #define CSD_C16_CASE(MT_, NS_)                                                   \
   if (p.MT == MT_ && ns == NS_) {                                                \
     if (p.PW <= 24) {                                                            \
-      if (mask) { CSD_C16_CASE2(MT_, NS_, true, 24) }                            \
-      CSD_C16_CASE2(MT_, NS_, false, 24)                                         \
+      if (mask) return launch16<MT_, NS_, true, 24>(k, p.lds_bytes, s);          \
+      return launch16<MT_, NS_, false, 24>(k, p.lds_bytes, s);                   \
     }                                                                            \
-    if (mask) { CSD_C16_CASE2(MT_, NS_, true, 34) }                              \
-    CSD_C16_CASE2(MT_, NS_, false, 34)                                           \
+    if (mask) return launch16<MT_, NS_, true, 34>(k, p.lds_bytes, s);            \
+    return launch16<MT_, NS_, false, 34>(k, p.lds_bytes, s);                     \
   }
   CSD_C16_CASE(4, 1) CSD_C16_CASE(2, 1)
   CSD_C16_CASE(4, 2) CSD_C16_CASE(2, 2)
 #undef CSD_C16_CASE
-#undef CSD_C16_CASE2
   set_error("conv16: no kernel for MT=%d ns=%d", p.MT, ns);
   return CSD_ERR_INVALID;
 }

@@ -519,7 +519,8 @@ struct Builder {
     o.cp.stride = stride; o.cp.pad = pad; o.cp.up = up;
     o.cp.OH = (ih << up) / stride; o.cp.OW = (iw << up) / stride;
     o.i4 = pc.ns;
-    if (pc.ns ? conv16_plan_tiles(&o.cp, pc.ns) : conv_plan_tiles(&o.cp)) { rc = CSD_ERR_INVALID; return NONE; }
+    const int kcs = (pc.ns && norm) ? conv16_kcs(pc.ns, o.cp.C0 + o.cp.C1) : 1;    // fp16-source convs stage in bursts
+    if (pc.ns ? conv16_plan_tiles(&o.cp, pc.ns, kcs) : conv_plan_tiles(&o.cp)) { rc = CSD_ERR_INVALID; return NONE; }
     // the packed layout depends on KC only (not on NT / tile shape)
     if (o.cp.KC != pc.proto.KC) { set_error("conv plan/pack mismatch"); rc = CSD_ERR_INVALID; return NONE; }
     o.a = src0; o.b = src1; o.pk0 = pc.w_off; o.pk1 = pc.b_off;

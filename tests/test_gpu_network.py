@@ -134,6 +134,24 @@ def test_fp16_mfma_modes_vs_golden(golden_dir, case, precision, tol_net, tol_tra
     assert e_net < tol_net and e_traj < tol_traj, (e_net, e_traj)
 
 
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('fp16x3', 2e-5), ('fp16', 5e-3)])
+def test_nf96_batch_unmasked_tiles(precision, tol):
+    """nf=96 (3 cout tiles per workgroup), 32x32 images, B=3: pixel tiles lie inside one image, so the
+    fp16 kernel runs WITHOUT tap masks and must zero the halo rows that belong to the neighbouring image of
+    the batch (regression: they leaked in as padding)"""
+    cfg = cases.make_config(name='ddpm_paired_SR3', nf=96, ch_mult=(1, 1), num_res_blocks=1, attn_resolutions=(),
+                            image_size=32)
+    cfg, nc, p, model = build(cfg, precision)
+    rs = np.random.RandomState(0)
+    x = torch.from_numpy(rs.standard_normal((3, 3, 32, 32)).astype(np.float32) * 5)
+    y = torch.from_numpy(rs.uniform(0, 1, (3, 3, 32, 32)).astype(np.float32))
+    lab = torch.tensor([500., 20., 900.])
+    with torch.no_grad():
+        ref = so.paired_forward(p, nc, x, y, lab, True)
+        out = model({'x': x.to(dev()), 'y': y.to(dev())}, lab.to(dev()))
+    assert rel(out.cpu().numpy(), ref.numpy()) < tol
+
+
 def test_generic_per_step_path_matches_fused():
     """corrector/predictor objects driven step by step (reference protocol) == fused device loop"""
     from conditional_score_diffusion_amd import ops
