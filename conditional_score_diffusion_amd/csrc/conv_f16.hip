@@ -14,7 +14,7 @@ static int in_coord16(int o, int r, int S, int P, int U) {
 
 bool conv16_supported(const ConvPlan& p) {
   const int Cin = p.C0 + p.C1;
-  return p.taps == 9 && p.stride == 1 && Cin % C16_KC == 0 && p.C0 % C16_KC == 0;
+  return p.taps == 9 && (p.stride == 1 || (p.stride == 2 && p.up == 0)) && Cin % C16_KC == 0 && p.C0 % C16_KC == 0;
 }
 
 int conv16_kcs(int ns, int cin) {   // sub-chunks per stage for an fp16-source convolution

@@ -322,6 +322,9 @@ int conv_plan_tiles(ConvPlan* p) {
               "conv: size mismatch IH=%d IW=%d OH=%d OW=%d stride=%d up=%d", p->IH, p->IW, p->OH,
               p->OW, p->stride, p->up);
   p->KC = (p->C0 % 16 == 0 && p->C1 % 16 == 0) ? 16 : 8;
+  // 1x1: one K chunk is only 4*NT MFMAs per 16 channels - far less than an HBM round trip - so stage
+  // 32 channels per chunk: 2x fewer dependent memory latencies per workgroup
+  if (p->taps == 1 && p->C0 % 32 == 0 && p->C1 % 32 == 0) p->KC = 32;   // (256 threads % (KC/4) must be 0)
   const int ntiles = cdiv(p->Cout, 32);
   p->CoutPad = ntiles * 32;
   // tile: TW divides OW when possible; maximise covered pixels, then minimise the staged patch.
@@ -458,12 +461,14 @@ int conv_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s) {
 #define CSD_CONV_CASE(NT_, TAPS_, KC_)                                                              \
   if (p.NT == NT_ && p.taps == TAPS_ && p.KC == KC_) {                                              \
     if (slots <= 3) return launch_one<NT_, TAPS_, KC_, 3>(k, p.lds_bytes, k.nblocks, s);            \
+    if (slots <= 4) return launch_one<NT_, TAPS_, KC_, 4>(k, p.lds_bytes, k.nblocks, s);            \
     return launch_one<NT_, TAPS_, KC_, CONV_MAX_SLOTS>(k, p.lds_bytes, k.nblocks, s);               \
   }
   CSD_CONV_CASE(1, 9, 8) CSD_CONV_CASE(2, 9, 8) CSD_CONV_CASE(3, 9, 8)
   CSD_CONV_CASE(1, 9, 16) CSD_CONV_CASE(2, 9, 16) CSD_CONV_CASE(3, 9, 16)
   CSD_CONV_CASE(1, 1, 8) CSD_CONV_CASE(2, 1, 8) CSD_CONV_CASE(3, 1, 8)
   CSD_CONV_CASE(1, 1, 16) CSD_CONV_CASE(2, 1, 16) CSD_CONV_CASE(3, 1, 16)
+  CSD_CONV_CASE(1, 1, 32) CSD_CONV_CASE(2, 1, 32) CSD_CONV_CASE(3, 1, 32)
 #undef CSD_CONV_CASE
   set_error("conv: no kernel for NT=%d taps=%d KC=%d", p.NT, p.taps, p.KC);
   return CSD_ERR_INVALID;

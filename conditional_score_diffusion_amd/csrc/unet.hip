@@ -420,7 +420,7 @@ static int build_packed_layout(Net& n) {
     if (!c.resamp_with_conv) return CSD_OK;
     return add_conv(std::to_string(m.idx) + ".Conv_0", m.cin, 0, m.cin, 9,
                     {{n.P(mname(m.idx, "Conv_0.weight")), n.P(mname(m.idx, "Conv_0.bias")), 0, m.cin, 0}},
-                    /*stride1=*/m.kind != M_DOWN);
+                    /*stride1=*/true);   // (the fp16 kernel also covers the stride-2 Downsample)
   };
   auto is_attn = [&](int res) {
     for (int i = 0; i < c.n_attn; ++i) if (c.attn_resolutions[i] == res) return true;

@@ -59,7 +59,7 @@ def test_conv2d(B, Cin, Cout, H, ks, stride, up2):
     assert rel(out, ref) < 2e-6 * max(1, (Cin * ks * ks) ** 0.5 / 8)   # fp32 dot of length K
 
 
-F16_CASES = [c for c in CONV_CASES if c[4] == 3 and c[5] == 1]
+F16_CASES = [c for c in CONV_CASES if c[4] == 3]      # 3x3: stride 1, stride-2 Downsample, x2-upsample fused
 
 
 @pytest.mark.parametrize('B,Cin,Cout,H,ks,stride,up2', F16_CASES)
@@ -71,8 +71,12 @@ def test_conv2d_fp16_mfma(B, Cin, Cout, H, ks, stride, up2, precision, tol):
     w = rnd(Cout, Cin, ks, ks, seed=2, scale=(1.0 / (Cin * ks * ks)) ** 0.5)
     b = rnd(Cout, seed=3, scale=0.1)
     xin = F.interpolate(x, scale_factor=2, mode='nearest') if up2 else x
-    ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1)
-    out = ops.conv2d(x.to(dev()), w.to(dev()), b.to(dev()), up2=up2, precision=precision)
+    if stride == 2:
+        ref = F.conv2d(F.pad(xin.double(), (0, 1, 0, 1)), w.double(), b.double(), stride=2)
+    else:
+        ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1)
+    out = ops.conv2d(x.to(dev()), w.to(dev()), b.to(dev()), stride=stride, downsample_pad=(stride == 2), up2=up2,
+                     precision=precision)
     assert rel(out, ref) < tol * max(1, (Cin * 9) ** 0.5 / 8)
 
 
