@@ -83,6 +83,7 @@ struct ConvArgs {
   int out_nchw;             // 1: write [B,Cout,OH,OW]
   int act;                  // activation applied after the norm prologue
   float out_scale;          // multiplies the final value (1, or 1/sqrt(2) for skip_rescale)
+  long long* dbg;           // tuning builds only (CSD_C16_TIMING): per-workgroup phase timestamps, else null
 };
 
 int conv_plan_tiles(ConvPlan* p);                       // chooses KC/NT/tile, returns csd_status

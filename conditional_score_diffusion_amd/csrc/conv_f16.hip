@@ -53,7 +53,7 @@ int conv16_plan_tiles(ConvPlan* p, int ns, int kcs) {
   }
   const int psb = 32 * ns * kcs + 16;
   const int nbuf = kcs > 1 ? 1 : 2;
-  const int max_units = kcs > 1 ? 9 : C16_MAX_PIECES * C16_PIECE;
+  const int max_units = kcs > 1 ? (ns == 1 ? 7 : 9) : C16_MAX_PIECES * C16_PIECE;
   const int spp = kcs > 1 ? 2 * ns * kcs : 4;
   auto pitch = [&](int tw) { return extent(tw) <= 24 ? 24 : 34; };
   for (int mt = mt_max; mt >= 2; mt >>= 1) {
@@ -160,9 +160,14 @@ static int launch16(const Conv16KArgs& k, size_t lds, hipStream_t s) {
 
 int conv16_launch_in16(const Conv16KArgs& k, const ConvPlan& p, int ns, bool mask, hipStream_t s);   // conv_f16_in16.hip
 
+long long* g_c16_dbg = nullptr;     // tuning builds only
+int g_c16_dbg_blocks = 0;
+int g_c16_dbg_max = 0, g_c16_dbg_n = 0;
+
 int conv16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s, bool in16) {
   Conv16KArgs k;
   k.a = a;
+  k.a.dbg = nullptr;
   k.B = p.B; k.IH = p.IH; k.IW = p.IW; k.OH = p.OH; k.OW = p.OW;
   k.C0 = p.C0; k.C1 = p.C1; k.Cout = p.Cout;
   k.stride = p.stride; k.pad = p.pad; k.up = p.up;
@@ -176,6 +181,13 @@ int conv16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s, b
   CSD_REQUIRE(in16 || p.KCS == 1, "conv16: multi-chunk stages need an fp16 source");
   // masks are needed iff a tile can straddle two images (or the x2-upsample parity map is in use)
   const bool mask = (p.OH % p.TH) != 0 || p.up != 0;
+  if (g_c16_dbg && k.nblocks == g_c16_dbg_blocks && g_c16_dbg_n < g_c16_dbg_max) {
+    k.a.dbg = g_c16_dbg + (size_t)g_c16_dbg_n * 4096 * 8;
+    if (hipMemsetAsync(k.a.dbg, 0, 4096 * 8 * 8, s) != hipSuccess) return -1;
+    long long hdr[4] = {p.C0 + p.C1, p.Cout, in16 ? 1 : 0, (a.res ? 1 : 0) | (a.temb ? 2 : 0)};
+    if (hipMemcpyAsync(k.a.dbg + 4095 * 8, hdr, sizeof(hdr), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+    g_c16_dbg_n++;
+  }
   if (in16) return conv16_launch_in16(k, p, ns, mask, s);
 #define CSD_C16_CASE(MT_, NS_)                                                   \
   if (p.MT == MT_ && ns == NS_) {                                                \
@@ -194,3 +206,11 @@ int conv16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s, b
 }
 
 }  // namespace csd
+
+extern "C" int csd_debug_timing(long long* buf, int nblocks, int max_launches) {   // tuning aid, not part of include/csd.h
+  csd::g_c16_dbg = buf;
+  csd::g_c16_dbg_blocks = nblocks;
+  csd::g_c16_dbg_max = max_launches;
+  csd::g_c16_dbg_n = 0;
+  return 0;
+}

@@ -39,6 +39,11 @@ typedef float v4f_t __attribute__((ext_vector_type(4)));
 #ifndef CSD_CONV_ABLATE
 #define CSD_CONV_ABLATE 0   // tuning aid: 1 no B loads, 2 no A LDS reads, 4 no staging/barriers, 8 no masks, 16 no norm/act
 #endif
+#ifdef CSD_C16_TIMING
+#define C16_TSTAMP(i) do { if (k.a.dbg && tid == 0 && blockIdx.x < 4095) k.a.dbg[blockIdx.x * 8 + (i)] = clock64(); } while (0)
+#else
+#define C16_TSTAMP(i) do { } while (0)
+#endif
 #define C16_KC 16               // channels per K chunk (= one MFMA K step per tap)
 #define C16_PIECE 2             // staging slots (float4 per lane) per interleaved piece
 #define C16_MAX_PIECES 5
@@ -95,13 +100,14 @@ __global__ __launch_bounds__(192, 1) void conv_f16_kernel(const void* __restrict
   static_assert(KCS == 1 || IN16, "multi-chunk stages need an fp16 source");
   constexpr int LO = 32 * KCS;               // byte offset of the lo plane inside a staged pixel
   constexpr int PSB = 32 * KCS * NS + 16;    // bytes per staged pixel: [hi KCS*16 ch][lo KCS*16 ch] + pad
-  constexpr int NU = (KCS > 1) ? 9 : C16_MAX_PIECES * C16_PIECE;    // staging units per lane (max)
+  constexpr int NU = (KCS > 1) ? (NS == 1 ? 7 : 9) : C16_MAX_PIECES * C16_PIECE;    // staging units per lane (max)
   constexpr int NPIX = MT * 32;
   extern __shared__ __attribute__((aligned(16))) char smem16[];
   const float* const g_src0 = static_cast<const float*>(g_src0v);
   const float* const g_src1 = static_cast<const float*>(g_src1v);
 
   const int tid = threadIdx.x;
+  C16_TSTAMP(0);
   const int nthr = k.nw * 64;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(192, 1) void conv_f16_kernel(const void* __restrict
     const int b = ov / k.OH;
     const int oy = ov - b * k.OH;
     if (wave == 0 && kg == 0) {
-      otab[m] = mv ? ov * k.OW + ox : -1;
+      otab[m] = mv ? (ov - ov0) * k.OW + ox : -1;   // relative to the tile's first row
       btab[m] = mv ? b : 0;
     }
     const int IHe = k.IH << U, IWe = k.IW << U;
@@ -294,6 +300,8 @@ __global__ __launch_bounds__(192, 1) void conv_f16_kernel(const void* __restrict
     for (int p = 0; p < NS; ++p) breg[q][p] = gload_h8(wstep + (size_t)q * STEP_BYTES + p * 1024);
   wstep += (size_t)(BR - 2) * STEP_BYTES;     // points at the newest prefetched step
 
+  C16_TSTAMP(1);   // tables built
+  float4 sv_first[(KCS > 1 && NS == 1) ? NU : 1];   // staged mode: burst of stage 1, issued together with stage 0
   // first chunk: issue EVERY piece's loads before converting any (one HBM round trip, not one per
   // piece; the accumulators are not live yet, so the registers are free)
   {
@@ -302,6 +310,12 @@ __global__ __launch_bounds__(192, 1) void conv_f16_kernel(const void* __restrict
       float4 v0[N0], dz = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int j = 0; j < N0; ++j) slot_load(j * nthr + tid, 0, v0[j], dz, dz);
+      if constexpr (KCS > 1 && NS == 1) {      // the second stage's burst goes out with the first: 2x the bytes in flight
+        if (k.nck > KCS) {
+#pragma unroll
+          for (int j = 0; j < NU; ++j) slot_load(j * nthr + tid, KCS * C16_KC, sv_first[j], dz, dz);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < N0; ++j) slot_store(buf0, j * nthr + tid, -1, v0[j], dz, dz);
     } else {
@@ -314,6 +328,7 @@ __global__ __launch_bounds__(192, 1) void conv_f16_kernel(const void* __restrict
     }
   }
   __syncthreads();
+  C16_TSTAMP(2);   // first stage in LDS
 
   if constexpr (KCS > 1) {
     // ================= staged mode (fp16 source): one burst per stage, single LDS buffer =================
@@ -325,9 +340,14 @@ __global__ __launch_bounds__(192, 1) void conv_f16_kernel(const void* __restrict
       const bool more = stg + 1 < nstage;
       float4 sv[NU];
       if (more) {                                 // next stage's burst: in flight under this stage's MFMAs
-        float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (NS == 1 && stg == 0) {                // (stage 1 was requested in the prologue)
 #pragma unroll
-        for (int j = 0; j < NU; ++j) slot_load(j * nthr + tid, (stg + 1) * KCS * C16_KC, sv[j], dz, dz);
+          for (int j = 0; j < NU; ++j) sv[j] = sv_first[j];
+        } else {
+          float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int j = 0; j < NU; ++j) slot_load(j * nthr + tid, (stg + 1) * KCS * C16_KC, sv[j], dz, dz);
+        }
       }
       half8 areg[RING][NS];
       auto load_frag = [&](int q) {      // q = s * MT + mt, s = sub * TAPS + tap (compile-time after unrolling)
@@ -372,6 +392,7 @@ __global__ __launch_bounds__(192, 1) void conv_f16_kernel(const void* __restrict
         }
       }
       static_assert((KCS * 9) % 3 == 0, "weight ring phase");
+      if (stg == 0) C16_TSTAMP(3);                // stage 0 MFMAs done
       if (more) {
         __syncthreads();                          // everyone is done reading this stage's patch
         float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -465,58 +486,97 @@ __global__ __launch_bounds__(192, 1) void conv_f16_kernel(const void* __restrict
 
   }
 
+  C16_TSTAMP(4);   // K loop done
   // ---- epilogue: this wave's 32 couts for all MT*32 pixels ----
-  // Every global read of the epilogue (residual, time embedding) is issued up front, back to back, so the
-  // workgroup pays ONE memory round trip - a load-use-load chain here costs 16 dependent HBM latencies per
-  // workgroup and was the single largest inefficiency of the first version (profiles/).
+  // Straight-line and branch-free: every global access goes through a buffer descriptor based at the
+  // tile's first output row, and a lane whose pixel / cout does not exist uses an out-of-range offset
+  // (the hardware returns 0 for the load and drops the store).  Per-element `if`s here made the compiler
+  // put each access in its own basic block behind an s_waitcnt vmcnt(0) - on gfx9 that counter also
+  // tracks stores, so the 64 stores of a wave completed one HBM round trip at a time and the epilogue
+  // was 60% of the kernel (tools/phase_timing.py).
   const int ohw = k.OH * k.OW;
   const float wunscale = 1.0f / C16_WSCALE;
   const int col = (ng * k.nw + wave) * 32 + (lane & 31);
-  if (col < k.Cout) {
-    const float bv = k.a.bias ? k.a.bias[col] : 0.f;
+  const bool cv = col < k.Cout;
+  const int colc = cv ? col : 0;
+  const float bv = k.a.bias ? k.a.bias[colc] : 0.f;
+  constexpr unsigned OOB = 0x80000000u;            // >= num_records of every descriptor below
+  constexpr int RSRC_FLAGS = 0x00020000;           // raw dword buffer, gfx9 encoding
+  const size_t o_base = (size_t)ov0 * k.OW;        // first pixel of the tile's first row (tall image)
+  const int b0 = ov0 / k.OH;                       // first sample the tile touches
+  const bool has_res = k.a.res != nullptr, has_temb = k.a.temb != nullptr, nchw = k.a.out_nchw != 0;
+  float* const out_base = nchw ? k.a.out + (size_t)b0 * k.Cout * ohw : k.a.out + o_base * k.a.out_stride + k.a.out_coff;
+  const __amdgpu_buffer_rsrc_t out_r = __builtin_amdgcn_make_buffer_rsrc(out_base, 0, OOB, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(has_res ? k.a.res + o_base * k.Cout : k.a.out), 0, OOB, RSRC_FLAGS);
+  float tvu = 0.f;                                 // unmasked tiles lie inside one sample
+  if (!MASK && has_temb) tvu = k.a.temb[(size_t)b0 * k.a.temb_stride + colc];
+  const int pix0 = (int)(o_base - (size_t)b0 * ohw);   // tile origin relative to sample b0 (NCHW store)
 #ifndef CSD_C16_GRP
 #define CSD_C16_GRP 2
 #endif
-    constexpr int GRP = CSD_C16_GRP;       // M tiles per batch of epilogue loads (16 loads per lane each)
+  constexpr int GRP = CSD_C16_GRP;         // M tiles per batch of epilogue accesses (16 per lane each)
 #pragma unroll
-    for (int g0 = 0; g0 < MT; g0 += GRP) {
-      int oidx[GRP][16];
-      float addv[GRP][16];
+  for (int g0 = 0; g0 < MT; g0 += GRP) {
+    int oidx[GRP][16];                     // pixel index relative to o_base, or -1
+    float addv[GRP][16];
 #pragma unroll
-      for (int g = 0; g < GRP; ++g)
+    for (int g = 0; g < GRP; ++g)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oidx[g][r] = otab[(g0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
+      for (int r = 0; r < 16; ++r) {
+        const int o = otab[(g0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
+        oidx[g][r] = cv ? o : -1;
+        addv[g][r] = tvu;
+      }
+    if (has_res) {
 #pragma unroll
       for (int g = 0; g < GRP; ++g)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int o = oidx[g][r];
-          float a = 0.f;
-          if (o >= 0) {
-            if (k.a.res) a = k.a.res[(size_t)o * k.Cout + col];
-            if (k.a.temb) a += k.a.temb[(size_t)btab[(g0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] * k.a.temb_stride + col];
-          }
-          addv[g][r] = a;
+          const unsigned off = o >= 0 ? (unsigned)(o * k.Cout + col) * 4u : OOB;
+          const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(res_r, off, 0, 0));
+          addv[g][r] = (MASK || !has_temb) ? v : v + tvu;     // (res and temb never meet in the network; order kept anyway)
         }
+    }
+    if (MASK && has_temb) {
+      float tv[GRP][16];
 #pragma unroll
-      for (int g = 0; g < GRP; ++g) {
+      for (int g = 0; g < GRP; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          tv[g][r] = k.a.temb[(size_t)btab[(g0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] * k.a.temb_stride + colc];
+#pragma unroll
+      for (int g = 0; g < GRP; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) addv[g][r] += tv[g][r];
+    }
+    if (nchw) {
+#pragma unroll
+      for (int g = 0; g < GRP; ++g)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int o = oidx[g][r];
-          if (o < 0) continue;
+          const int db = btab[(g0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] - b0;
           // (acc*2^-8 + bias) + temb + residual: same association as the reference's h + Dense(temb), x + h
           const float val = ((acc[g0 + g][r] * wunscale + bv) + addv[g][r]) * k.a.out_scale;
-          if (k.a.out_nchw) {
-            const int b = btab[(g0 + g) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
-            k.a.out[((size_t)b * k.Cout + col) * ohw + (o - b * ohw)] = val;
-          } else {
-            k.a.out[(size_t)o * k.a.out_stride + k.a.out_coff + col] = val;
-          }
+          const unsigned off = o >= 0 ? (unsigned)((db * k.Cout + col) * ohw + (pix0 + o - db * ohw)) * 4u : OOB;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), out_r, off, 0, 0);
         }
-      }
-      __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+      for (int g = 0; g < GRP; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = oidx[g][r];
+          const float val = ((acc[g0 + g][r] * wunscale + bv) + addv[g][r]) * k.a.out_scale;
+          const unsigned off = o >= 0 ? (unsigned)(o * k.a.out_stride + col) * 4u : OOB;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), out_r, off, 0, 0);
+        }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
+  C16_TSTAMP(5);
 }
 
 }  // namespace csd

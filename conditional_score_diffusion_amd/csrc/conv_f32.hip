@@ -115,7 +115,7 @@ __global__ __launch_bounds__(CONV_THREADS, 1) void conv_f32_kernel(const float* 
     const int b = ov / k.OH;
     const int oy = ov - b * k.OH;
     if (half == 0) {
-      otab[m] = mv ? ov * k.OW + ox : -1;
+      otab[m] = mv ? (ov - ov0) * k.OW + ox : -1;   // relative to the tile's first row
       btab[m] = mv ? b : 0;
     }
     const int IHe = k.IH << U, IWe = k.IW << U;
@@ -266,10 +266,22 @@ __global__ __launch_bounds__(CONV_THREADS, 1) void conv_f32_kernel(const float* 
   }
 
   // ---- epilogue: bias + time embedding + residual, NHWC (or NCHW) store ----
-  // all global reads (residual / time embedding) are issued first, back to back: one memory round trip
-  // per workgroup instead of a load-use chain
+  // Straight-line and branch-free: accesses go through buffer descriptors based at the tile's first
+  // output row; a lane whose pixel / cout does not exist uses an out-of-range offset (load returns 0,
+  // store is dropped).  Per-element branches made every access wait on vmcnt(0) - which on gfx9 also
+  // counts stores - so the stores of a wave completed one memory round trip at a time.
   const int ohw = k.OH * k.OW;
-  int oidx[16], bidx[16];
+  constexpr unsigned OOB = 0x80000000u;            // >= num_records of every descriptor below
+  constexpr int RSRC_FLAGS = 0x00020000;           // raw dword buffer, gfx9 encoding
+  const size_t o_base = (size_t)ov0 * k.OW;
+  const int b0 = ov0 / k.OH;                       // first sample the tile touches
+  const bool has_res = k.a.res != nullptr, has_temb = k.a.temb != nullptr, nchw = k.a.out_nchw != 0;
+  float* const out_base = nchw ? k.a.out + (size_t)b0 * k.Cout * ohw : k.a.out + o_base * k.a.out_stride + k.a.out_coff;
+  const __amdgpu_buffer_rsrc_t out_r = __builtin_amdgcn_make_buffer_rsrc(out_base, 0, OOB, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(has_res ? k.a.res + o_base * k.Cout : k.a.out), 0, OOB, RSRC_FLAGS);
+  const int pix0 = (int)(o_base - (size_t)b0 * ohw);
+  int oidx[16], bidx[16];                          // pixel index relative to o_base (or -1), sample index
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -279,27 +291,40 @@ __global__ __launch_bounds__(CONV_THREADS, 1) void conv_f32_kernel(const float* 
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int col = (ng * NT + n) * 32 + (lane & 31);
-    if (col < k.Cout) {
-      float addv[16];
+    const bool cv = col < k.Cout;
+    const int colc = cv ? col : 0;
+    const float bv = k.a.bias ? k.a.bias[colc] : 0.f;
+    float addv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) addv[r] = 0.f;
+    if (has_res) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float a = 0.f;
-        if (oidx[r] >= 0) {
-          if (k.a.res) a = k.a.res[(size_t)oidx[r] * k.Cout + col];
-          if (k.a.temb) a += k.a.temb[(size_t)bidx[r] * k.a.temb_stride + col];
-        }
-        addv[r] = a;
+        const unsigned off = (cv && oidx[r] >= 0) ? (unsigned)(oidx[r] * k.Cout + col) * 4u : OOB;
+        addv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(res_r, off, 0, 0));
       }
-      const float bv = k.a.bias ? k.a.bias[col] : 0.f;
+    }
+    if (has_temb) {
+      float tv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tv[r] = k.a.temb[(size_t)bidx[r] * k.a.temb_stride + colc];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) addv[r] += tv[r];
+    }
+    if (nchw) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int o = oidx[r];
-        if (o < 0) continue;
+        const int o = oidx[r], db = bidx[r] - b0;
         const float val = ((acc[n][r] + bv) + addv[r]) * k.a.out_scale;
-        if (k.a.out_nchw)
-          k.a.out[((size_t)bidx[r] * k.Cout + col) * ohw + (o - bidx[r] * ohw)] = val;
-        else
-          k.a.out[(size_t)o * k.a.out_stride + k.a.out_coff + col] = val;
+        const unsigned off = (cv && o >= 0) ? (unsigned)((db * k.Cout + col) * ohw + (pix0 + o - db * ohw)) * 4u : OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), out_r, off, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float val = ((acc[n][r] + bv) + addv[r]) * k.a.out_scale;
+        const unsigned off = (cv && oidx[r] >= 0) ? (unsigned)(oidx[r] * k.a.out_stride + col) * 4u : OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), out_r, off, 0, 0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);

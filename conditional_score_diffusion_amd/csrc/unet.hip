@@ -826,6 +826,7 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         a.out_nchw = o.out_external;
         a.act = o.act;
         a.out_scale = 1.f;
+        a.dbg = nullptr;
         rc = o.i4 ? conv16_launch(o.cp, o.i4, a, s, o.i3 != 0) : conv_launch(o.cp, a, s);
         break;
       }
