@@ -104,6 +104,13 @@ size_t conv16_packed_bytes(const ConvPlan& p, int ns);
 int conv16_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int cin_src, int cout_src,
                        int cout_off, void* wpack, hipStream_t s);
 int conv16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s, bool in16 = false);
+// pointwise (1x1) layers on the fp16 MFMA path (conv_pw16.hip): fp32 NHWC in / out, optional GroupNorm affine on the
+// input, bias + residual epilogue; no LDS staging of activations - a pure HBM stream
+bool pw16_supported(const ConvPlan& p, int ns);
+size_t pw16_packed_bytes(const ConvPlan& p, int ns);
+int pw16_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int cin_src, int cout_src, int cout_off,
+                     void* wpack, hipStream_t s);
+int pw16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s);
 // y16 = fp16 split of act(x*scale + shift): hi plane (and lo plane when ns == 2), NHWC halves [B*HW][C0+C1]
 int gn_apply16_launch(const float* src0, const float* src1, int C0, int C1, const float* nscale, const float* nshift,
                       void* hi, void* lo, int B, int HW, int act, hipStream_t s);

@@ -67,11 +67,23 @@ static int conv_api_plan(ConvPlan* p, int B, int Cin, int Cout, int H, int W, in
   return conv_plan_tiles(p);
 }
 
+static int ceil32(int c) { return (c + 31) / 32 * 32; }
+static size_t api_packed_floats(const ConvPlan& p, int Cin) {
+  size_t n = al64(conv_packed_floats(p)) * 2;
+  if (p.taps == 1) {
+    ConvPlan q = p;
+    q.C0 = ceil32(Cin);
+    const size_t m = al64(pw16_packed_bytes(q, 2) / sizeof(float) + 1);
+    if (m > n) n = m;
+  }
+  return n;
+}
+
 extern "C" size_t csd_conv_scratch_bytes(int B, int Cin, int Cout, int H, int W, int ksize, int up2) {
   ConvPlan p;
   if (conv_api_plan(&p, B, Cin, Cout, H, W, ksize, 1, 0, up2)) return 0;
-  // sized for the largest packed layout (fp32 fragments; the fp16 hi+lo layout is the same size)
-  return (al64((size_t)B * H * W * ceil16(Cin)) + al64(conv_packed_floats(p)) * 2 + al64((size_t)p.CoutPad) +
+  // sized for the largest packed layout (fp32 fragments; the fp16 hi+lo layout is the same size; pointwise fp16)
+  return (al64((size_t)B * H * W * ceil32(Cin)) + api_packed_floats(p, Cin) + al64((size_t)p.CoutPad) +
           al64((size_t)B * p.OH * p.OW * Cout)) * sizeof(float) + 4096;
 }
 
@@ -85,18 +97,24 @@ extern "C" int csd_conv2d(const float* x, const float* weight, const float* bias
   int rc = conv_api_plan(&p, B, Cin, Cout, H, W, ksize, stride, pad_mode, up2);
   if (rc) return rc;
   int ns = precision_ns(precision);
+  bool pw = false;
   if (ns) {   // fp16 MFMA kernel where it applies (3x3 stride 1, Cin padded to 16), else fp32 kernel
     ConvPlan q = p;
     q.C0 = ceil16(Cin);
-    if (conv16_supported(q) && conv16_plan_tiles(&q, ns) == CSD_OK) p = q; else ns = 0;
+    ConvPlan q1 = p;
+    q1.C0 = ceil32(Cin);
+    if (conv16_supported(q) && conv16_plan_tiles(&q, ns) == CSD_OK) p = q;
+    else if (pw16_supported(q1, ns)) { p = q1; pw = true; }
+    else ns = 0;
   }
   float* f = static_cast<float*>(scratch);
-  float* xh = f; f += al64((size_t)B * H * W * ceil16(Cin));
-  float* wp = f; f += al64(conv_packed_floats(p)) * 2;
+  float* xh = f; f += al64((size_t)B * H * W * ceil32(Cin));
+  float* wp = f; f += api_packed_floats(p, Cin);
   float* bp = f; f += al64((size_t)p.CoutPad);
   float* yh = f;
   if ((rc = nchw_to_nhwc_launch(x, xh, B, Cin, H * W, p.C0, p.C0, s))) return rc;
-  rc = ns ? conv16_pack_weight(p, ns, weight, 0, Cin, Cout, 0, wp, s) : conv_pack_weight(p, weight, 0, Cin, Cout, 0, wp, s);
+  rc = pw ? pw16_pack_weight(p, ns, weight, 0, Cin, Cout, 0, wp, s)
+          : ns ? conv16_pack_weight(p, ns, weight, 0, Cin, Cout, 0, wp, s) : conv_pack_weight(p, weight, 0, Cin, Cout, 0, wp, s);
   if (rc) return rc;
   CSD_CHECK_HIP(hipMemsetAsync(bp, 0, (size_t)p.CoutPad * sizeof(float), s));
   if (bias) CSD_CHECK_HIP(hipMemcpyAsync(bp, bias, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -104,7 +122,7 @@ extern "C" int csd_conv2d(const float* x, const float* weight, const float* bias
   memset(&a, 0, sizeof(a));
   a.src0 = xh; a.wpack = wp; a.bias = bp; a.out = yh;
   a.out_stride = Cout; a.out_nchw = 0; a.out_scale = 1.f;
-  if ((rc = ns ? conv16_launch(p, ns, a, s) : conv_launch(p, a, s))) return rc;
+  if ((rc = pw ? pw16_launch(p, ns, a, s) : ns ? conv16_launch(p, ns, a, s) : conv_launch(p, a, s))) return rc;
   return nhwc_to_nchw_launch(yh, y, B, Cout, p.OH * p.OW, Cout, s);
 }
 

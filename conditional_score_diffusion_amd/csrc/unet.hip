@@ -84,6 +84,7 @@ struct PackedConv {
   ConvPlan proto;          // channel-level fields only (C0,C1,Cout,taps,KC,NT,CoutPad)
   size_t w_off = 0, b_off = 0;   // float offsets in the packed buffer
   int ns = 0;                    // 0: fp32 kernel layout; 1/2: fp16 kernel layout with ns planes
+  bool pw = false;               // ns != 0 and the layer runs on the pointwise fp16 kernel (conv_pw16.hip)
   struct Src { int param_w, param_b, layout, cout_src, cout_off, cin_src; };
   std::vector<Src> srcs;
 };
@@ -351,10 +352,20 @@ static int build_packed_layout(Net& n) {
       pc.ns = net_ns;
       if ((rc = conv16_plan_tiles(&pc.proto, pc.ns))) return rc;
       pc.w_off = take(conv16_packed_bytes(pc.proto, pc.ns) / sizeof(float) + 1);
+    } else if (net_ns && stride1 && pw16_supported(pc.proto, net_ns)) {
+      bool aligned = true;
+      for (const auto& sr : srcs) aligned = aligned && (sr.cout_off % 16 == 0);
+      if (aligned) {
+        pc.ns = net_ns;
+        pc.pw = true;
+        pc.w_off = take(pw16_packed_bytes(pc.proto, pc.ns) / sizeof(float) + 1);
+      } else {
+        pc.w_off = take(conv_packed_floats(pc.proto));
+      }
     } else {
       pc.w_off = take(conv_packed_floats(pc.proto));
     }
-    pc.b_off = take((size_t)pc.proto.CoutPad);
+    pc.b_off = take((size_t)pc.proto.CoutPad + 96);
     pc.srcs = srcs;
     n.pconv_by_name[key] = (int)n.pconvs.size();
     n.pconvs.push_back(pc);
@@ -519,8 +530,11 @@ struct Builder {
     o.cp.stride = stride; o.cp.pad = pad; o.cp.up = up;
     o.cp.OH = (ih << up) / stride; o.cp.OW = (iw << up) / stride;
     o.i4 = pc.ns;
-    const int kcs = (pc.ns && norm) ? conv16_kcs(pc.ns, o.cp.C0 + o.cp.C1) : 1;    // fp16-source convs stage in bursts
-    if (pc.ns ? conv16_plan_tiles(&o.cp, pc.ns, kcs) : conv_plan_tiles(&o.cp)) { rc = CSD_ERR_INVALID; return NONE; }
+    o.i2 = pc.pw ? 1 : 0;
+    const int kcs = (pc.ns && !pc.pw && norm) ? conv16_kcs(pc.ns, o.cp.C0 + o.cp.C1) : 1;    // fp16-source convs stage in bursts
+    if (pc.pw) {
+      if (act != CSD_ACT_NONE || temb_col != NONE || external_nchw) { set_error("pointwise fp16 layer with act/temb/NCHW"); rc = CSD_ERR_INVALID; return NONE; }
+    } else if (pc.ns ? conv16_plan_tiles(&o.cp, pc.ns, kcs) : conv_plan_tiles(&o.cp)) { rc = CSD_ERR_INVALID; return NONE; }
     // the packed layout depends on KC only (not on NT / tile shape)
     if (o.cp.KC != pc.proto.KC) { set_error("conv plan/pack mismatch"); rc = CSD_ERR_INVALID; return NONE; }
     o.a = src0; o.b = src1; o.pk0 = pc.w_off; o.pk1 = pc.b_off;
@@ -528,7 +542,7 @@ struct Builder {
     o.d = norm ? nscale : NONE;
     o.e = norm ? nshift : NONE;
     size_t hi16 = NONE, lo16 = NONE;
-    if (pc.ns && norm) {
+    if (pc.ns && !pc.pw && norm) {
       // fp16 kernel: normalise + activate + split ONCE per element into fp16 planes, conv copies them
       const size_t nh = ((size_t)B * ih * iw * (o.cp.C0 + o.cp.C1) + 1) / 2;      // halves -> floats
       Op ap;
@@ -827,7 +841,7 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         a.act = o.act;
         a.out_scale = 1.f;
         a.dbg = nullptr;
-        rc = o.i4 ? conv16_launch(o.cp, o.i4, a, s, o.i3 != 0) : conv_launch(o.cp, a, s);
+        rc = o.i2 ? pw16_launch(o.cp, o.i4, a, s) : (o.i4 ? conv16_launch(o.cp, o.i4, a, s, o.i3 != 0) : conv_launch(o.cp, a, s));
         break;
       }
       case OP_ATTN:
@@ -884,7 +898,9 @@ static int pack_all(Net& n, float* pk, hipStream_t s) {
     if ((rc = dev_fill(pk + pc.b_off, 0.f, (size_t)pc.proto.CoutPad, s))) return rc;
     for (auto& src : pc.srcs) {   // sources are listed with ascending cout_off, first one clears the tensor
       const int cin_src = src.cin_src > 0 ? src.cin_src : pc.proto.C0 + pc.proto.C1;
-      rc = pc.ns ? conv16_pack_weight(pc.proto, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
+      rc = pc.pw ? pw16_pack_weight(pc.proto, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
+                                    src.cout_off, pk + pc.w_off, s)
+         : pc.ns ? conv16_pack_weight(pc.proto, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
                                       src.cout_off, pk + pc.w_off, s)
                  : conv_pack_weight(pc.proto, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
                                     src.cout_off, pk + pc.w_off, s);

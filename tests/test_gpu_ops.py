@@ -36,6 +36,8 @@ CONV_CASES = [
     (3, 32, 32, 5, 3, 1, True),       # Upsample: nearest x2 then conv -> 10x10
     (2, 64, 96, 8, 3, 1, True),
     (2, 64, 96, 5, 1, 1, False),      # NIN / 1x1
+    (3, 192, 96, 20, 1, 1, False),    # NIN shortcut of an up-path block (fp16 modes: pointwise kernel, 64-pixel tiles)
+    (2, 40, 200, 7, 1, 1, False),     # 1x1 with Cin padded to 32, three cout groups, ragged pixel tail
     (4, 288, 288, 5, 3, 1, False),    # odd 5x5 level, tile straddles images
     (1, 192, 96, 40, 3, 1, False),
     (1, 96, 96, 160, 3, 1, False),    # full-resolution layer
@@ -59,7 +61,7 @@ def test_conv2d(B, Cin, Cout, H, ks, stride, up2):
     assert rel(out, ref) < 2e-6 * max(1, (Cin * ks * ks) ** 0.5 / 8)   # fp32 dot of length K
 
 
-F16_CASES = [c for c in CONV_CASES if c[4] == 3]      # 3x3: stride 1, stride-2 Downsample, x2-upsample fused
+F16_CASES = list(CONV_CASES)      # 3x3: stride 1, stride-2 Downsample, x2-upsample fused; 1x1: pointwise kernel
 
 
 @pytest.mark.parametrize('B,Cin,Cout,H,ks,stride,up2', F16_CASES)
@@ -74,7 +76,7 @@ def test_conv2d_fp16_mfma(B, Cin, Cout, H, ks, stride, up2, precision, tol):
     if stride == 2:
         ref = F.conv2d(F.pad(xin.double(), (0, 1, 0, 1)), w.double(), b.double(), stride=2)
     else:
-        ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1)
+        ref = F.conv2d(xin.double(), w.double(), b.double(), padding=ks // 2)
     out = ops.conv2d(x.to(dev()), w.to(dev()), b.to(dev()), stride=stride, downsample_pad=(stride == 2), up2=up2,
                      precision=precision)
     assert rel(out, ref) < tol * max(1, (Cin * 9) ** 0.5 / 8)
