@@ -83,6 +83,7 @@ struct ConvArgs {
   int out_nchw;             // 1: write [B,Cout,OH,OW]
   int act;                  // activation applied after the norm prologue
   float out_scale;          // multiplies the final value (1, or 1/sqrt(2) for skip_rescale)
+  double* stats;            // fp16 3x3 kernel: per-tile GroupNorm partials [tile][Cout][2] (sum, sum of squares) or null
   long long* dbg;           // tuning builds only (CSD_C16_TIMING): per-workgroup phase timestamps, else null
 };
 
@@ -130,6 +131,11 @@ int gn_stats_launch(const GNPlan& p, const float* src0, const float* src1, doubl
                     hipStream_t s);
 int gn_finalize_launch(const GNPlan& p, const double* partial, const float* gamma, const float* beta,
                        float eps, float* nscale, float* nshift, hipStream_t s);
+// finalize from the per-tile partials the conv epilogues wrote (ConvArgs::stats): source s has Cs channels and
+// tpi_s tiles per sample, laid out [B*tpi_s][Cs][2]; p1 may be null (single source)
+int gn_finalize_tiles_launch(const double* p0, int tpi0, int C0, const double* p1, int tpi1, int C1, int B, int HW, int G,
+                             const float* gamma, const float* beta, float eps, float* nscale, float* nshift,
+                             hipStream_t s);
 // stand-alone apply: y = act(x*scale + shift), NHWC
 int gn_apply_launch(const float* x, const float* nscale, const float* nshift, float* y, int B, int HW,
                     int C, int act, hipStream_t s);

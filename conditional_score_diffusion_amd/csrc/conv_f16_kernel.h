@@ -516,6 +516,7 @@ __global__ __launch_bounds__(192, 1) void conv_f16_kernel(const void* __restrict
 #define CSD_C16_GRP 2
 #endif
   constexpr int GRP = CSD_C16_GRP;         // M tiles per batch of epilogue accesses (16 per lane each)
+  double st_s = 0.0, st_q = 0.0;           // GroupNorm partials of this lane's column over the tile (fp64, fixed order)
 #pragma unroll
   for (int g0 = 0; g0 < MT; g0 += GRP) {
     int oidx[GRP][16];                     // pixel index relative to o_base, or -1
@@ -572,9 +573,25 @@ __global__ __launch_bounds__(192, 1) void conv_f16_kernel(const void* __restrict
           const float val = ((acc[g0 + g][r] * wunscale + bv) + addv[g][r]) * k.a.out_scale;
           const unsigned off = o >= 0 ? (unsigned)(o * k.a.out_stride + col) * 4u : OOB;
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), out_r, off, 0, 0);
+          const double dv = o >= 0 ? (double)val : 0.0;
+          st_s += dv;
+          st_q = fma(dv, dv, st_q);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+  }
+  // GroupNorm statistics of the tensor being written, for the GroupNorm that consumes it next: one
+  // (sum, sum of squares) pair per (tile, cout) - the finalize kernel reduces tiles in a fixed order, so
+  // the result is deterministic and the separate statistics pass over the tensor disappears.  The host
+  // sets `stats` only when a tile lies inside one sample (OH % TH == 0).
+  if (k.a.stats) {
+    st_s += __shfl_xor(st_s, 32);
+    st_q += __shfl_xor(st_q, 32);
+    if (lane < 32 && cv) {
+      double* dst = k.a.stats + ((size_t)tile * k.Cout + col) * 2;
+      dst[0] = st_s;
+      dst[1] = st_q;
+    }
   }
   C16_TSTAMP(5);
 }

@@ -280,7 +280,7 @@ static int pw16_launch_t(const PwKArgs& k, const ConvPlan& p, hipStream_t s) {
   }
   const int n_groups = cdiv(p.Cout, PW_NTL * 16);
   // persistent: two workgroups per CU (register bound) share the tiles of one cout group
-  int gx = (2 * 256) / n_groups;
+  int gx = (OCC * 256) / n_groups;
   if (gx < 1) gx = 1;
   if (gx > k.ntiles) gx = k.ntiles;
   hipLaunchKernelGGL(kern, dim3(gx, n_groups), dim3(PW_THREADS), lds, s, k.a.src0, k.a.src1,
@@ -298,13 +298,12 @@ int pw16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
   k.npix = p.B * p.OH * p.OW;
   k.hw = p.OH * p.OW;
   k.ks = (p.C0 + p.C1) / 32;
-  const int t256 = cdiv(k.npix, 256);
-  const bool big = t256 >= 512;
-  k.ntiles = big ? t256 : cdiv(k.npix, 64);
-  if (ns == 2) return big ? pw16_launch_t<2, 4, 2>(k, p, s) : pw16_launch_t<2, 1, 2>(k, p, s);
-  if (getenv("CSD_PW_MT2")) return pw16_launch_t<1, 2, 4>(k, p, s);
-  if (getenv("CSD_PW_MT2B")) return pw16_launch_t<1, 2, 3>(k, p, s);
-  return big ? pw16_launch_t<1, 4, 2>(k, p, s) : pw16_launch_t<1, 1, 2>(k, p, s);
+  // big layers: 128-pixel tiles (2 x 16 pixels per wave) - 150 registers, three workgroups per CU measured
+  // fastest (more waves in flight beat more bytes per wave); small layers: 64-pixel tiles to fill the chip
+  const bool big = cdiv(k.npix, 128) >= 768;
+  k.ntiles = cdiv(k.npix, big ? 128 : 64);
+  if (ns == 2) return big ? pw16_launch_t<2, 2, 2>(k, p, s) : pw16_launch_t<2, 1, 2>(k, p, s);
+  return big ? pw16_launch_t<1, 2, 3>(k, p, s) : pw16_launch_t<1, 1, 2>(k, p, s);
 }
 
 }  // namespace csd

@@ -101,6 +101,47 @@ __global__ void gn_finalize_kernel(const double* __restrict__ partial, const flo
   }
 }
 
+// finalize from conv-epilogue partials: one workgroup per (group, sample); 64 threads stride over the
+// (tile, channel-of-group) pairs in a fixed order and a fixed-shape tree combines them (deterministic)
+__global__ void gn_finalize_tiles_kernel(const double* __restrict__ p0, int tpi0, int C0, const double* __restrict__ p1,
+                                         int tpi1, int C1, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float eps, float* __restrict__ nscale, float* __restrict__ nshift, int HW, int G) {
+  __shared__ double red[2][64];
+  const int g = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const int C = C0 + C1;
+  const int cpg = C / G;
+  double s = 0, q = 0;
+  for (int j = 0; j < cpg; ++j) {
+    const int c = g * cpg + j;
+    const bool s1 = c >= C0;
+    const double* p = s1 ? p1 : p0;
+    const int Cs = s1 ? C1 : C0, cl = s1 ? c - C0 : c, tpi = s1 ? tpi1 : tpi0;
+    for (int i = t; i < tpi; i += 64) {
+      const double* e = p + (((size_t)b * tpi + i) * Cs + cl) * 2;
+      s += e[0];
+      q += e[1];
+    }
+  }
+  red[0][t] = s;
+  red[1][t] = q;
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (t < w) { red[0][t] += red[0][t + w]; red[1][t] += red[1][t + w]; }
+    __syncthreads();
+  }
+  if (t < cpg) {
+    const int c = g * cpg + t;
+    const double n = (double)HW * cpg;
+    const double mean = red[0][0] / n;
+    double var = red[1][0] / n - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = rstd * gamma[c];
+    nscale[(size_t)b * C + c] = sc;
+    nshift[(size_t)b * C + c] = beta[c] - (float)mean * sc;
+  }
+}
+
 __device__ __forceinline__ float gn_act(float v, int act) {
   switch (act) {
     case CSD_ACT_SWISH: return v / (1.0f + expf(-v));
@@ -231,6 +272,16 @@ int gn_finalize_launch(const GNPlan& p, const double* partial, const float* gamm
                        float eps, float* nscale, float* nshift, hipStream_t s) {
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B), dim3(256), 0, s, partial, gamma, beta, eps, nscale,
                      nshift, p.HW, p.C0 + p.C1, p.G, p.nchunk);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+int gn_finalize_tiles_launch(const double* p0, int tpi0, int C0, const double* p1, int tpi1, int C1, int B, int HW, int G,
+                             const float* gamma, const float* beta, float eps, float* nscale, float* nshift,
+                             hipStream_t s) {
+  CSD_REQUIRE((C0 + C1) % G == 0 && (C0 + C1) / G <= 64, "gn finalize: %d channels in %d groups", C0 + C1, G);
+  hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(G, B), dim3(64), 0, s, p0, tpi0, C0, p1, tpi1, C1, gamma, beta, eps,
+                     nscale, nshift, HW, G);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }

@@ -94,7 +94,7 @@ struct Net;
 // ---------------------------------------------------------------------------------------------
 // execution plan for one batch size
 // ---------------------------------------------------------------------------------------------
-enum OpKind { OP_ASSEMBLE, OP_TEMB, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_GN_APPLY16, OP_CONV, OP_ATTN, OP_AVGPOOL,
+enum OpKind { OP_ASSEMBLE, OP_TEMB, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_GN_FINAL_TILES, OP_GN_APPLY16, OP_CONV, OP_ATTN, OP_AVGPOOL,
               OP_UPNEAR, OP_TO_NCHW };
 
 static const size_t NONE = (size_t)-1;
@@ -103,6 +103,7 @@ struct Op {
   OpKind kind;
   // generic offsets (floats) into workspace unless stated
   size_t a = NONE, b = NONE, c = NONE, d = NONE, e = NONE, out = NONE;
+  size_t stats = NONE;                // conv: per-tile GroupNorm partials it writes; GN_FINAL_TILES: a = source 0's, b = source 1's
   size_t temb_base = NONE;            // offset of dense_all (conv epilogue time-embedding source)
   size_t pk0 = NONE, pk1 = NONE;      // offsets into the packed buffer
   int i0 = 0, i1 = 0, i2 = 0, i3 = 0, i4 = 0;
@@ -492,8 +493,18 @@ struct Builder {
   size_t gn_partial = NONE, nscale = NONE, nshift = NONE;   // shared scratch
   size_t dense_all = NONE;
   int rc = CSD_OK;
+  // tensors whose producing conv left per-tile GroupNorm partials behind: workspace offset -> (partials, tiles per sample)
+  struct TileStats { size_t off; int tpi; };
+  std::map<size_t, TileStats> tile_stats;
 
   Builder(Net& n_, Plan& p_, int B_) : n(n_), pl(p_), B(B_) {}
+
+  // every workspace allocation goes through here: a new tensor at an offset invalidates what was known about the old one
+  size_t alloc_(size_t nfloats) {
+    const size_t off = ar.alloc(nfloats);
+    tile_stats.erase(off);
+    return off;
+  }
 
   void count(double flops, double bytes) {
     pl.flops += flops; pl.bytes += bytes; pl.launches += 1;
@@ -502,6 +513,23 @@ struct Builder {
 
   // GroupNorm statistics of (src0|src1) -> nscale/nshift
   void gn(size_t src0, size_t src1, int c0, int c1, int hw, const std::string& gname, const std::string& bname) {
+    const auto t0 = tile_stats.find(src0);
+    const auto t1 = src1 == NONE ? tile_stats.end() : tile_stats.find(src1);
+    if (t0 != tile_stats.end() && (src1 == NONE || t1 != tile_stats.end())) {
+      // both sources were written by convs that accumulated the statistics in their epilogue: no pass over the tensor
+      Op f;
+      f.kind = OP_GN_FINAL_TILES;
+      f.a = t0->second.off; f.i0 = t0->second.tpi; f.i1 = c0;
+      f.b = src1 == NONE ? NONE : t1->second.off; f.i2 = src1 == NONE ? 0 : t1->second.tpi; f.i3 = c1;
+      f.i4 = hw;
+      f.pk0 = n.copy_off.at(gname); f.pk1 = n.copy_off.at(bname);
+      f.out = nscale; f.c = nshift;
+      f.cls = CSD_PROF_GN_FINAL;
+      pl.ops.push_back(f);
+      pl.launches += 1;
+      pl.bytes += 2.0 * B * hw * (c0 + c1) * 4;   // SURVEY 8(d) algorithmic bytes are those of the unfused op
+      return;
+    }
     Op s;
     s.kind = OP_GN_STATS;
     if (gn_plan(&s.gp, B, hw, c0, c1, 32)) { rc = CSD_ERR_INVALID; return; }
@@ -549,8 +577,8 @@ struct Builder {
       ap.kind = OP_GN_APPLY16;
       ap.a = src0; ap.b = src1; ap.i0 = o.cp.C0; ap.i1 = o.cp.C1; ap.i2 = ih * iw;
       ap.d = nscale; ap.e = nshift; ap.act = act;
-      hi16 = ar.alloc(nh);
-      if (pc.ns == 2) lo16 = ar.alloc(nh);
+      hi16 = alloc_(nh);
+      if (pc.ns == 2) lo16 = alloc_(nh);
       ap.out = hi16; ap.c = lo16;
       ap.cls = CSD_PROF_GN_APPLY;
       ap.bytes = (double)B * ih * iw * (o.cp.C0 + o.cp.C1) * (4 + 2 * pc.ns);
@@ -567,7 +595,13 @@ struct Builder {
     o.temb_stride = n.dense_total;
     o.out_external = external_nchw ? 1 : 0;
     const size_t out_elems = (size_t)B * o.cp.OH * o.cp.OW * o.cp.Cout;
-    o.out = external_nchw ? NONE : ar.alloc(out_elems);
+    o.out = external_nchw ? NONE : alloc_(out_elems);
+    if (pc.ns && !pc.pw && !external_nchw && o.cp.OH % o.cp.TH == 0 && !getenv("CSD_NO_FUSED_STATS")) {
+      // every tile lies inside one sample: the epilogue also leaves (sum, sumsq) per (tile, cout) for the next GroupNorm
+      const int tpi = (o.cp.OH / o.cp.TH) * o.cp.tiles_x;
+      o.stats = alloc_((size_t)B * tpi * o.cp.Cout * 2 * 2);      // doubles; never released (small)
+      tile_stats[o.out] = TileStats{o.stats, tpi};
+    }
     o.cls = o.cp.taps == 1 ? CSD_PROF_CONV1X1 : ((stride == 1 && !up) ? CSD_PROF_CONV3X3 : CSD_PROF_CONV3X3_RESAMPLE);
     pl.ops.push_back(o);
     ar.release(hi16);      // (plan-time lifetimes: the planes die right after this conv)
@@ -606,7 +640,7 @@ struct Builder {
     Op a;
     a.kind = OP_ATTN;
     a.a = qkv; a.i0 = L; a.i1 = C;
-    a.out = ar.alloc((size_t)B * L * C);
+    a.out = alloc_((size_t)B * L * C);
     a.cls = CSD_PROF_ATTENTION;
     pl.ops.push_back(a);
     count(4.0 * B * (double)L * L * C, 0);
@@ -638,9 +672,9 @@ static int build_plan(Net& n, int B, Plan** out) {
       gn_plan(&g, B, side * side, cmax, 0, 32);
       worst = std::max(worst, gn_partial_bytes(g));
     }
-    bd.gn_partial = bd.ar.alloc(worst / sizeof(float) + 64);
-    bd.nscale = bd.ar.alloc((size_t)B * cmax);
-    bd.nshift = bd.ar.alloc((size_t)B * cmax);
+    bd.gn_partial = bd.alloc_(worst / sizeof(float) + 64);
+    bd.nscale = bd.alloc_((size_t)B * cmax);
+    bd.nshift = bd.alloc_((size_t)B * cmax);
   }
   size_t mi = 0;
   auto next_mod = [&]() -> const Module& { return n.mods[mi++]; };
@@ -648,7 +682,7 @@ static int build_plan(Net& n, int B, Plan** out) {
   // ---- input + time embedding ----
   Op as;
   as.kind = OP_ASSEMBLE;
-  as.out = bd.ar.alloc((size_t)B * S * S * n.in_cpad);
+  as.out = bd.alloc_((size_t)B * S * S * n.in_cpad);
   pl.ops.push_back(as);
   pl.launches += 1;
   if (c.conditional) {
@@ -656,24 +690,24 @@ static int build_plan(Net& n, int B, Plan** out) {
     const Module& l1 = next_mod();
     Op e;
     e.kind = OP_TEMB;
-    e.out = bd.ar.alloc((size_t)B * nf);
+    e.out = bd.alloc_((size_t)B * nf);
     e.i0 = nf;
     pl.ops.push_back(e);
     Op a;
     a.kind = OP_LINEAR;
-    a.a = e.out; a.out = bd.ar.alloc((size_t)B * 4 * nf);
+    a.a = e.out; a.out = bd.alloc_((size_t)B * 4 * nf);
     a.pk0 = n.copy_off.at(mname(l0.idx, "weight")); a.pk1 = n.copy_off.at(mname(l0.idx, "bias"));
     a.i0 = nf; a.i1 = 4 * nf; a.act = CSD_ACT_NONE;
     pl.ops.push_back(a);
     Op b2;
     b2.kind = OP_LINEAR;
-    b2.a = a.out; b2.out = bd.ar.alloc((size_t)B * 4 * nf);
+    b2.a = a.out; b2.out = bd.alloc_((size_t)B * 4 * nf);
     b2.pk0 = n.copy_off.at(mname(l1.idx, "weight")); b2.pk1 = n.copy_off.at(mname(l1.idx, "bias"));
     b2.i0 = 4 * nf; b2.i1 = 4 * nf; b2.act = c.act;
     pl.ops.push_back(b2);
     Op d;
     d.kind = OP_LINEAR;   // every ResnetBlock's Dense_0(act(temb)) in one launch
-    d.a = b2.out; d.out = bd.ar.alloc((size_t)B * n.dense_total);
+    d.a = b2.out; d.out = bd.alloc_((size_t)B * n.dense_total);
     d.pk0 = n.dense_all_off; d.pk1 = n.dense_all_bias_off;
     d.i0 = 4 * nf; d.i1 = n.dense_total; d.act = c.act;
     pl.ops.push_back(d);
@@ -720,7 +754,7 @@ static int build_plan(Net& n, int B, Plan** out) {
         Op p;
         p.kind = OP_AVGPOOL;
         p.a = hs.back().off; p.i0 = side; p.i1 = in_ch;
-        p.out = bd.ar.alloc((size_t)B * (side / 2) * (side / 2) * in_ch);
+        p.out = bd.alloc_((size_t)B * (side / 2) * (side / 2) * in_ch);
         pl.ops.push_back(p);
         pl.launches += 1;
         d = p.out;
@@ -768,7 +802,7 @@ static int build_plan(Net& n, int B, Plan** out) {
         Op p;
         p.kind = OP_UPNEAR;
         p.a = h; p.i0 = side; p.i1 = in_ch;
-        p.out = bd.ar.alloc((size_t)B * side * 2 * side * 2 * in_ch);
+        p.out = bd.alloc_((size_t)B * side * 2 * side * 2 * in_ch);
         pl.ops.push_back(p);
         pl.launches += 1;
         o = p.out;
@@ -823,6 +857,11 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         rc = gn_finalize_launch(o.gp, reinterpret_cast<const double*>(W(o.a)), pk + o.pk0, pk + o.pk1, 1e-6f,
                                 W(o.out), W(o.b), s);
         break;
+      case OP_GN_FINAL_TILES:
+        rc = gn_finalize_tiles_launch(reinterpret_cast<const double*>(W(o.a)), o.i0, o.i1,
+                                      reinterpret_cast<const double*>(W(o.b)), o.i2, o.i3, B, o.i4, 32, pk + o.pk0,
+                                      pk + o.pk1, 1e-6f, W(o.out), W(o.c), s);
+        break;
       case OP_GN_APPLY16:
         rc = gn_apply16_launch(W(o.a), W(o.b), o.i0, o.i1, W(o.d), W(o.e), W(o.out), W(o.c), B, o.i2, o.act, s);
         break;
@@ -841,6 +880,7 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         a.act = o.act;
         a.out_scale = 1.f;
         a.dbg = nullptr;
+        a.stats = reinterpret_cast<double*>(W(o.stats));
         rc = o.i2 ? pw16_launch(o.cp, o.i4, a, s) : (o.i4 ? conv16_launch(o.cp, o.i4, a, s, o.i3 != 0) : conv_launch(o.cp, a, s));
         break;
       }
