@@ -320,11 +320,26 @@ __global__ __launch_bounds__(CONV_THREADS, 1) void conv_f32_kernel(const float* 
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), out_r, off, 0, 0);
       }
     } else {
+      double st_s = 0.0, st_q = 0.0;       // GroupNorm partials of this lane's column over the wave's 32 pixels
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float val = ((acc[n][r] + bv) + addv[r]) * k.a.out_scale;
         const unsigned off = (cv && oidx[r] >= 0) ? (unsigned)(oidx[r] * k.a.out_stride + col) * 4u : OOB;
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), out_r, off, 0, 0);
+        const double dv = oidx[r] >= 0 ? (double)val : 0.0;
+        st_s += dv;
+        st_q = fma(dv, dv, st_q);
+      }
+      // statistics for the GroupNorm that reads this tensor next (see conv_f16_kernel.h): one (sum, sumsq)
+      // pair per (tile, wave, cout); the host sets `stats` only when a tile lies inside one sample
+      if (k.a.stats) {
+        st_s += __shfl_xor(st_s, 32);
+        st_q += __shfl_xor(st_q, 32);
+        if (lane < 32 && cv) {
+          double* dst = k.a.stats + (((size_t)tile * 4 + wave) * k.Cout + col) * 2;
+          dst[0] = st_s;
+          dst[1] = st_q;
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);

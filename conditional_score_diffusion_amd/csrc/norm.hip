@@ -101,39 +101,51 @@ __global__ void gn_finalize_kernel(const double* __restrict__ partial, const flo
   }
 }
 
-// finalize from conv-epilogue partials: one workgroup per (group, sample); 64 threads stride over the
-// (tile, channel-of-group) pairs in a fixed order and a fixed-shape tree combines them (deterministic)
+// finalize from conv-epilogue partials.  One workgroup per (block of GB groups, sample): thread (ti, c) strides over
+// the tiles ti, ti+TL, ... of channel c - the cb = cpg*GB channels of one tile row are contiguous, so the reads
+// coalesce - then fixed-order sums over the TL tile lanes and over the channels of each group (deterministic).
+#define GNF_THREADS 256
 __global__ void gn_finalize_tiles_kernel(const double* __restrict__ p0, int tpi0, int C0, const double* __restrict__ p1,
                                          int tpi1, int C1, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                         float eps, float* __restrict__ nscale, float* __restrict__ nshift, int HW, int G) {
-  __shared__ double red[2][64];
-  const int g = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+                                         float eps, float* __restrict__ nscale, float* __restrict__ nshift, int HW, int G,
+                                         int GB) {
+  __shared__ double red[2][GNF_THREADS];
+  __shared__ double chs[2][64];
+  const int b = blockIdx.y, t = threadIdx.x;
   const int C = C0 + C1;
   const int cpg = C / G;
+  const int cb = cpg * GB;                 // channels per workgroup (<= 64)
+  const int TL = GNF_THREADS / cb;         // tile lanes
+  const int cl = t % cb, ti = t / cb;
+  const int c = blockIdx.x * cb + cl;
   double s = 0, q = 0;
-  for (int j = 0; j < cpg; ++j) {
-    const int c = g * cpg + j;
+  if (ti < TL && c < C) {
     const bool s1 = c >= C0;
     const double* p = s1 ? p1 : p0;
-    const int Cs = s1 ? C1 : C0, cl = s1 ? c - C0 : c, tpi = s1 ? tpi1 : tpi0;
-    for (int i = t; i < tpi; i += 64) {
-      const double* e = p + (((size_t)b * tpi + i) * Cs + cl) * 2;
-      s += e[0];
-      q += e[1];
+    const int Cs = s1 ? C1 : C0, cs = s1 ? c - C0 : c, tpi = s1 ? tpi1 : tpi0;
+    const double* e = p + ((size_t)b * tpi * Cs + cs) * 2;
+    for (int i = ti; i < tpi; i += TL) {
+      s += e[(size_t)i * Cs * 2];
+      q += e[(size_t)i * Cs * 2 + 1];
     }
   }
   red[0][t] = s;
   red[1][t] = q;
   __syncthreads();
-  for (int w = 32; w > 0; w >>= 1) {
-    if (t < w) { red[0][t] += red[0][t + w]; red[1][t] += red[1][t + w]; }
-    __syncthreads();
+  if (t < cb) {
+    double cs_ = 0, cq_ = 0;
+    for (int j = 0; j < TL; ++j) { cs_ += red[0][j * cb + t]; cq_ += red[1][j * cb + t]; }
+    chs[0][t] = cs_;
+    chs[1][t] = cq_;
   }
-  if (t < cpg) {
-    const int c = g * cpg + t;
+  __syncthreads();
+  if (t < cb && c < C) {
+    const int g0 = (t / cpg) * cpg;
+    double gs = 0, gq = 0;
+    for (int j = 0; j < cpg; ++j) { gs += chs[0][g0 + j]; gq += chs[1][g0 + j]; }
     const double n = (double)HW * cpg;
-    const double mean = red[0][0] / n;
-    double var = red[1][0] / n - mean * mean;
+    const double mean = gs / n;
+    double var = gq / n - mean * mean;
     if (var < 0) var = 0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = rstd * gamma[c];
@@ -280,8 +292,12 @@ int gn_finalize_tiles_launch(const double* p0, int tpi0, int C0, const double* p
                              const float* gamma, const float* beta, float eps, float* nscale, float* nshift,
                              hipStream_t s) {
   CSD_REQUIRE((C0 + C1) % G == 0 && (C0 + C1) / G <= 64, "gn finalize: %d channels in %d groups", C0 + C1, G);
-  hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(G, B), dim3(64), 0, s, p0, tpi0, C0, p1, tpi1, C1, gamma, beta, eps,
-                     nscale, nshift, HW, G);
+  const int cpg = (C0 + C1) / G;
+  int GB = 32 / cpg;                       // groups per workgroup: about 32 channels (a 512-byte row of partials)
+  if (GB < 1) GB = 1;
+  if (GB > G) GB = G;
+  hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(cdiv(G, GB), B), dim3(GNF_THREADS), 0, s, p0, tpi0, C0, p1, tpi1, C1,
+                     gamma, beta, eps, nscale, nshift, HW, G, GB);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }

@@ -596,9 +596,10 @@ struct Builder {
     o.out_external = external_nchw ? 1 : 0;
     const size_t out_elems = (size_t)B * o.cp.OH * o.cp.OW * o.cp.Cout;
     o.out = external_nchw ? NONE : alloc_(out_elems);
-    if (pc.ns && !pc.pw && !external_nchw && o.cp.OH % o.cp.TH == 0 && !getenv("CSD_NO_FUSED_STATS")) {
-      // every tile lies inside one sample: the epilogue also leaves (sum, sumsq) per (tile, cout) for the next GroupNorm
-      const int tpi = (o.cp.OH / o.cp.TH) * o.cp.tiles_x;
+    if (!pc.pw && !external_nchw && o.cp.taps == 9 && o.cp.OH % o.cp.TH == 0 && !getenv("CSD_NO_FUSED_STATS")) {
+      // every tile lies inside one sample: the epilogue also leaves (sum, sumsq) per (tile, cout) for the next
+      // GroupNorm (the fp32 kernel: per (tile, wave, cout))
+      const int tpi = (o.cp.OH / o.cp.TH) * o.cp.tiles_x * (pc.ns ? 1 : 4);
       o.stats = alloc_((size_t)B * tpi * o.cp.Cout * 2 * 2);      // doubles; never released (small)
       tile_stats[o.out] = TileStats{o.stats, tpi};
     }
