@@ -184,6 +184,19 @@ def main():
         else:
             dom_kernel, dom_peak = 'conv_f16_kernel<NS=1> (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x16_f16)', F16_MFMA_PEAK_TF
             dom_note = 'fp16 MFMA dense peak'
+        # which roof bounds the dominant kernel: arithmetic intensity of its launches vs the ridge of its MFMA peak
+        dom_gbs = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9 if dom['ms'] > 0 else 0.0
+        dom_ai = dom['flops'] / max(dom['bytes'], 1.0)
+        ridge = dom_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+        if dom_ai < ridge:
+            roof = {'bound': 'hbm', 'achieved': dom_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dom_gbs / HBM_PEAK_GBS}
+        else:
+            roof = {'bound': 'mfma', 'achieved': dom_tf, 'peak': dom_peak, 'unit': 'TFLOP/s', 'frac': dom_tf / dom_peak}
+        roof.update({'kernel': dom_kernel, 'traffic': None, 'peak_note': dom_note,
+                     'arithmetic_intensity_flop_per_byte': dom_ai, 'ridge_flop_per_byte': ridge,
+                     'achieved_TFLOPs': dom_tf, 'achieved_GBs': dom_gbs,
+                     'launches': dom['launches'], 'avg_launch_ms': dom['ms'] / max(dom['launches'], 1),
+                     'share_of_kernel_time': dom['ms'] / max(kernel_ms, 1e-9)})
         # north_star yardstick: HBM roofline of the whole sampling run
         bytes_per_img = 2000 * (ALG_BYTES_PER_IMG_NFE + ALG_WEIGHT_BYTES_PER_NFE / B)
         hbm_roof = HBM_PEAK_GBS * 1e9 / bytes_per_img                      # images/s/GPU
@@ -199,10 +212,7 @@ def main():
                                    'batch %d per GPU, random-init weights, synthetic LR inputs' % B,
                        'images_per_gpu': B, 'global_batch': total_images, 'pc_steps_timed': K,
                        'nfe_per_step': 2, 'noise': 'on-device Philox4x32-10', 'precision_mode': args.precision},
-            'roofline': {'kernel': dom_kernel, 'bound': 'mfma', 'achieved': dom_tf, 'peak': dom_peak, 'unit': 'TFLOP/s',
-                         'frac': dom_tf / dom_peak, 'traffic': None, 'peak_note': dom_note,
-                         'launches': dom['launches'], 'avg_launch_ms': dom['ms'] / max(dom['launches'], 1),
-                         'share_of_kernel_time': dom['ms'] / max(kernel_ms, 1e-9)},
+            'roofline': roof,
             'hbm_roofline': {'images_per_sec_per_gpu': hbm_roof, 'frac': value / world / hbm_roof,
                              'achieved_GBs': value / world * bytes_per_img / 1e9, 'peak_GBs': HBM_PEAK_GBS},
             'flop_roofline_f32': {'images_per_sec_per_gpu': flop_roof, 'frac': value / world / flop_roof,

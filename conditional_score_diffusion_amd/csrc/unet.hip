@@ -609,6 +609,10 @@ struct Builder {
     ar.release(lo16);
     const int cin = real_cin > 0 ? real_cin : (o.cp.C0 + o.cp.C1);
     count(2.0 * out_elems * cin * o.cp.taps, ((double)B * ih * iw * cin + (double)out_elems) * 4);
+    // the profiler's per-launch bytes are what THIS kernel has to move (fp16 planes in, fp32 out, residual in);
+    // the plan totals above stay the SURVEY 8(d) algorithmic figures
+    pl.ops.back().bytes = (double)B * ih * iw * (o.cp.C0 + o.cp.C1) * (o.i3 ? 2.0 * pc.ns : 4.0) +
+                          (double)out_elems * 4 * (res != NONE ? 2 : 1);
     return o.out;
   }
 
