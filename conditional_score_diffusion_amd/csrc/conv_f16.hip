@@ -40,9 +40,11 @@ int conv16_plan_tiles(ConvPlan* p, int ns, int kcs) {
            (p->up ? 1 : 0);
   };
   // waves (= cout tiles) per workgroup: 3 when the tile count allows, else 2 / 1
-  const int nw = (ntiles % 3 == 0) ? 3 : (ntiles % 2 == 0) ? 2 : 1;
+  // (a single-tile layer - the 96 -> 3 output conv - still runs 3 waves: staging bandwidth, not MFMA, is its limit;
+  // the two extra waves recompute tile 0 and store nothing)
+  const int nw = (ntiles % 3 == 0 || ntiles == 1) ? 3 : (ntiles % 2 == 0) ? 2 : 1;
   p->NT = nw;                       // (field reused: cout tiles per workgroup)
-  p->n_groups = ntiles / nw;
+  p->n_groups = cdiv(ntiles, nw);
   // pixels per workgroup MT*32, MT in {8,4,2}: the largest that still yields >= ~2 workgroups per CU;
   // tile shape: TW divides OW when possible, maximise covered pixels, then minimise the staged patch
   int best_mt = 0, best_tw = 0, best_th = 0;
@@ -58,7 +60,9 @@ int conv16_plan_tiles(ConvPlan* p, int ns, int kcs) {
   auto pitch = [&](int tw) { return extent(tw) <= 24 ? 24 : 34; };
   for (int mt = mt_max; mt >= 2; mt >>= 1) {
     const int npix = mt * 32;
-    int btw = 0, bth = 0, bcov = -1, blds = 1 << 30;
+    int btw = 0, bth = 0, blds = 1 << 30;
+    double bcov = -1;
+    bool bunm = false;
     for (int tw = 1; tw <= 32 && tw <= p->OW; ++tw) {
       if (p->OW % tw != 0 && !(tw == 32 && p->OW > 32)) continue;
       if (extent(tw) > 34) continue;
@@ -67,8 +71,13 @@ int conv16_plan_tiles(ConvPlan* p, int ns, int kcs) {
         const int lds = nbuf * extent(th) * pitch(tw) * psb;
         if (lds > C16_LDS_LIMIT) continue;
         if (patch * spp > max_units * nw * 64) continue;
-        const int cov = th * tw;
-        if (cov > bcov || (cov == bcov && lds < blds)) { bcov = cov; blds = lds; btw = tw; bth = th; }
+        // valid output pixels per tile (a TW that does not divide OW wastes the last tile of every row), then
+        // tiles that stay inside one sample (no masks, fused GroupNorm statistics), then the smaller patch
+        const double cov = (double)th * tw * p->OW / ((double)cdiv(p->OW, tw) * tw);
+        const bool unm = (p->OH % th) == 0;
+        if (cov > bcov + 1e-9 || (cov > bcov - 1e-9 && ((unm && !bunm) || (unm == bunm && lds < blds)))) {
+          bcov = cov; blds = lds; btw = tw; bth = th; bunm = unm;
+        }
         break;
       }
     }
@@ -176,6 +185,7 @@ int conv16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s, b
   k.nblocks = p.tiles_x * p.tiles_y * p.n_groups;
   k.nck = (p.C0 + p.C1) / C16_KC;
   k.nw = p.NT;
+  k.ntiles_n = p.CoutPad / 32;
   CSD_REQUIRE(p.taps == 9, "conv16: only 3x3 kernels");
   CSD_REQUIRE(!in16 || (p.C1 == 0 && a.nscale == nullptr), "conv16: fp16 sources are single-tensor and pre-normalised");
   CSD_REQUIRE(in16 || p.KCS == 1, "conv16: multi-chunk stages need an fp16 source");

@@ -1,4 +1,6 @@
 // conv_f16_in16.hip - instantiations of conv_f16_kernel for fp16 sources (written by gn_apply16).
+#include <stdlib.h>
+
 #include "conv_f16_kernel.h"
 
 namespace csd {
@@ -12,6 +14,7 @@ static int launch_in16(const Conv16KArgs& k, size_t lds, hipStream_t s) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
+  if (const char* f = getenv("CSD_C16_LDS_PAD")) lds += (size_t)atoi(f);   // tuning aid: lower the occupancy
   hipLaunchKernelGGL(kern, dim3(k.nblocks), dim3(k.nw * 64), lds, s, static_cast<const void*>(k.a.src0),
                      static_cast<const void*>(k.a.src1), reinterpret_cast<const char*>(k.a.wpack), k);
   CSD_LAUNCH_CHECK();

@@ -58,6 +58,7 @@ struct Conv16KArgs {
   int stride, pad, up;
   int TH, TW, PH, PW, tiles_x, n_groups, nblocks;
   int nck, nw;              // K chunks; waves (= cout tiles) per workgroup
+  int ntiles_n;             // 32-cout tiles of the layer
 };
 
 __device__ __forceinline__ float4 gload4f(const float* p) {
@@ -92,7 +93,7 @@ __device__ __forceinline__ float act16(float v, int act) {
 // ~21-29 KB) is fetched in ONE burst - for Cin <= 96 that is the entire K extent - and the next stage's
 // burst is issued a full stage (>= 1.4 us of MFMAs) before it is needed.  Single LDS buffer.
 template <int MT, int NS, bool MASK, int PWC, bool IN16, int KCS>
-__global__ __launch_bounds__(192, 1) void conv_f16_kernel(const void* __restrict__ g_src0v,
+__global__ __launch_bounds__(192, 2) void conv_f16_kernel(const void* __restrict__ g_src0v,
                                                          const void* __restrict__ g_src1v,
                                                          const char* __restrict__ g_wpack,
                                                          const Conv16KArgs k) {
@@ -283,7 +284,10 @@ __global__ __launch_bounds__(192, 1) void conv_f16_kernel(const void* __restrict
   // weight stream of THIS wave's cout tile: [chunk][tap][plane hi|lo][lane][8 halves]; NS KiB per step
   constexpr int STEP_BYTES = NS * 1024;
   const size_t tile_stride = (size_t)k.nck * TAPS * STEP_BYTES;     // k.nck counts 16-channel chunks
-  const char* wstep = g_wpack + (size_t)(ng * k.nw + wave) * tile_stride + lane * 16;
+  // (a wave beyond the last cout tile - tiny-Cout layers run 3 waves for the staging bandwidth - recomputes
+  // the last tile and stores nothing: its columns are >= Cout)
+  const int wtile = min(ng * k.nw + wave, k.ntiles_n - 1);
+  const char* wstep = g_wpack + (size_t)wtile * tile_stride + lane * 16;
 
   // weight-fragment ring, BR-1 K steps ahead of the MFMAs: one step is only MT*32 (F16) / MT*96 (F16X3)
   // MFMA cycles while an L2 hit costs ~500-800, so the prefetch distance must be several steps.
@@ -332,7 +336,13 @@ __global__ __launch_bounds__(192, 1) void conv_f16_kernel(const void* __restrict
 
   if constexpr (KCS > 1) {
     // ================= staged mode (fp16 source): one burst per stage, single LDS buffer =================
-    constexpr int RING = 2;
+    // A-fragment ring: a fragment must be requested an LDS latency (~130+ cycles under load) before its MFMAs;
+    // one M-tile iteration is 32 (F16) / 96 (F16X3) MFMA cycles
+#ifdef CSD_C16_SRING
+    constexpr int RING = CSD_C16_SRING;
+#else
+    constexpr int RING = (NS == 1) ? 4 : 3;
+#endif
     constexpr int SSTEPS = KCS * TAPS;            // K steps per stage (sub-chunk major, tap minor = stream order)
     const int nstage = k.nck / KCS;
     const char* buf = buf0;
@@ -345,8 +355,13 @@ __global__ __launch_bounds__(192, 1) void conv_f16_kernel(const void* __restrict
           for (int j = 0; j < NU; ++j) sv[j] = sv_first[j];
         } else {
           float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef CSD_C16_NOBURST   // tuning aid: no mid-kernel burst (results are garbage) - isolates its cost
+#pragma unroll
+          for (int j = 0; j < NU; ++j) sv[j] = dz;
+#else
 #pragma unroll
           for (int j = 0; j < NU; ++j) slot_load(j * nthr + tid, (stg + 1) * KCS * C16_KC, sv[j], dz, dz);
+#endif
         }
       }
       half8 areg[RING][NS];
