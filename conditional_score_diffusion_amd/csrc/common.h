@@ -59,6 +59,7 @@ struct ConvPlan {
   int NT;                   // 32-wide cout tiles per workgroup (1..3)
   int MT;                   // fp16 kernel: 32-pixel M tiles per workgroup (2/4); fp32 kernel: unused
   int KCS;                  // fp16 kernel, fp16 source: 16-channel sub-chunks per K stage (1 = chunk-wise)
+  int LC;                   // fp16 kernel, fp16 source: 1 = loader/consumer persistent schedule (conv_f16_lc.h)
   int TH, TW;               // output tile, TH*TW <= 128
   int PH, PW;               // staged source patch
   int tiles_x, tiles_y;     // tiles over (B*OH virtual rows, OW)
@@ -100,11 +101,18 @@ int conv_launch(const ConvPlan& p, const ConvArgs& a, hipStream_t s);
 // Cin is a multiple of 16; everything else stays on the fp32 kernel.
 bool conv16_supported(const ConvPlan& p);
 int conv16_kcs(int ns, int cin);
-int conv16_plan_tiles(ConvPlan* p, int ns, int kcs = 1);
+int conv16_plan_tiles(ConvPlan* p, int ns, int kcs = 1, bool lc = false);
 size_t conv16_packed_bytes(const ConvPlan& p, int ns);
 int conv16_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int cin_src, int cout_src,
                        int cout_off, void* wpack, hipStream_t s);
 int conv16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s, bool in16 = false);
+// "quad" schedule (conv_f16_q.hip): fp16-source 3x3 stride-1 layers with Cout % 96 == 0, four balanced waves
+bool conv16q_supported(const ConvPlan& p, int ns);
+size_t conv16q_packed_bytes(const ConvPlan& p, int ns);
+int conv16q_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int cin_src, int cout_src, int cout_off,
+                        void* wpack, hipStream_t s);
+int conv16q_plan_tiles(ConvPlan* p, int ns);
+int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s);
 // pointwise (1x1) layers on the fp16 MFMA path (conv_pw16.hip): fp32 NHWC in / out, optional GroupNorm affine on the
 // input, bias + residual epilogue; no LDS staging of activations - a pure HBM stream
 bool pw16_supported(const ConvPlan& p, int ns);

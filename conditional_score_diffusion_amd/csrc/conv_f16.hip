@@ -26,7 +26,8 @@ int conv16_kcs(int ns, int cin) {   // sub-chunks per stage for an fp16-source c
   return cin % 32 == 0 ? 2 : 1;
 }
 
-int conv16_plan_tiles(ConvPlan* p, int ns, int kcs) {
+int conv16_plan_tiles(ConvPlan* p, int ns, int kcs, bool lc) {
+  lc = lc && kcs > 1 && p->stride == 1 && p->up == 0;
   const int Cin = p->C0 + p->C1;
   CSD_REQUIRE(conv16_supported(*p), "conv16: unsupported shape (taps=%d stride=%d Cin=%d+%d)", p->taps, p->stride,
               p->C0, p->C1);
@@ -54,7 +55,7 @@ int conv16_plan_tiles(ConvPlan* p, int ns, int kcs) {
     if (v == 2 || v == 4) mt_max = v;
   }
   const int psb = 32 * ns * kcs + 16;
-  const int nbuf = kcs > 1 ? 1 : 2;
+  const int nbuf = (kcs > 1 && !lc) ? 1 : 2;
   const int max_units = kcs > 1 ? (ns == 1 ? 7 : 9) : C16_MAX_PIECES * C16_PIECE;
   const int spp = kcs > 1 ? 2 * ns * kcs : 4;
   auto pitch = [&](int tw) { return extent(tw) <= 24 ? 24 : 34; };
@@ -70,7 +71,7 @@ int conv16_plan_tiles(ConvPlan* p, int ns, int kcs) {
         const int patch = extent(th) * extent(tw);
         const int lds = nbuf * extent(th) * pitch(tw) * psb;
         if (lds > C16_LDS_LIMIT) continue;
-        if (patch * spp > max_units * nw * 64) continue;
+        if (lc ? patch > 208 : patch * spp > max_units * nw * 64) continue;   // (208 = C16_LC_MAXPATCH)
         // valid output pixels per tile (a TW that does not divide OW wastes the last tile of every row), then
         // tiles that stay inside one sample (no masks, fused GroupNorm statistics), then the smaller patch
         const double cov = (double)th * tw * p->OW / ((double)cdiv(p->OW, tw) * tw);
@@ -94,6 +95,7 @@ int conv16_plan_tiles(ConvPlan* p, int ns, int kcs) {
   p->tiles_y = cdiv(p->B * p->OH, p->TH);
   const int mt_sel = best_mt;
   p->KCS = kcs;
+  p->LC = lc ? 1 : 0;
   p->lds_bytes = (size_t)nbuf * p->PH * pitch(p->TW) * psb + (size_t)2 * mt_sel * 32 * sizeof(int) +
                  (size_t)3 * p->PH * p->PW * sizeof(int);
   p->MT = mt_sel;
@@ -168,6 +170,7 @@ static int launch16(const Conv16KArgs& k, size_t lds, hipStream_t s) {
 }
 
 int conv16_launch_in16(const Conv16KArgs& k, const ConvPlan& p, int ns, bool mask, hipStream_t s);   // conv_f16_in16.hip
+int conv16_launch_lc(const Conv16KArgs& k, const ConvPlan& p, int ns, bool mask, hipStream_t s);     // conv_f16_lc.hip
 
 long long* g_c16_dbg = nullptr;     // tuning builds only
 int g_c16_dbg_blocks = 0;
@@ -191,13 +194,14 @@ int conv16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s, b
   CSD_REQUIRE(in16 || p.KCS == 1, "conv16: multi-chunk stages need an fp16 source");
   // masks are needed iff a tile can straddle two images (or the x2-upsample parity map is in use)
   const bool mask = (p.OH % p.TH) != 0 || p.up != 0;
-  if (g_c16_dbg && k.nblocks == g_c16_dbg_blocks && g_c16_dbg_n < g_c16_dbg_max) {
+  if (g_c16_dbg && k.nblocks == g_c16_dbg_blocks && g_c16_dbg_n < g_c16_dbg_max) {   // (tuning builds)
     k.a.dbg = g_c16_dbg + (size_t)g_c16_dbg_n * 4096 * 8;
     if (hipMemsetAsync(k.a.dbg, 0, 4096 * 8 * 8, s) != hipSuccess) return -1;
     long long hdr[4] = {p.C0 + p.C1, p.Cout, in16 ? 1 : 0, (a.res ? 1 : 0) | (a.temb ? 2 : 0)};
     if (hipMemcpyAsync(k.a.dbg + 4095 * 8, hdr, sizeof(hdr), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
     g_c16_dbg_n++;
   }
+  if (in16 && p.LC) return conv16_launch_lc(k, p, ns, mask, s);
   if (in16) return conv16_launch_in16(k, p, ns, mask, s);
 #define CSD_C16_CASE(MT_, NS_)                                                   \
   if (p.MT == MT_ && ns == NS_) {                                                \

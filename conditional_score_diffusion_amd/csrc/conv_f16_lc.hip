@@ -1,0 +1,56 @@
+// conv_f16_lc.hip - instantiations + launch of the loader/consumer fp16-source convolution (conv_f16_lc.h)
+#include <stdlib.h>
+
+#include "conv_f16_lc.h"
+
+namespace csd {
+
+size_t conv16_lc_lds_bytes(const ConvPlan& p, int ns, int pitch_px) {
+  const int psb = 32 * ns * p.KCS + 16;
+  return (size_t)2 * p.PH * pitch_px * psb + (size_t)9 * p.MT * 32 * sizeof(int);
+}
+
+template <int MT, int NS, bool MASK, int PWC, int KCS>
+static int launch_lc(const Conv16KArgs& k, const ConvPlan& p, hipStream_t s) {
+  auto kern = conv_f16_lc_kernel<MT, NS, MASK, PWC, KCS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  size_t lds = conv16_lc_lds_bytes(p, NS, PWC);
+  if (const char* f = getenv("CSD_C16_LDS_PAD")) lds += (size_t)atoi(f);   // tuning aid: lower the occupancy
+  CSD_REQUIRE(lds <= 160 * 1024 && p.PH * p.PW <= C16_LC_MAXPATCH, "conv16 lc: patch %dx%d does not fit", p.PH, p.PW);
+  // persistent: two workgroups per CU; a multiple of 8 keeps every item of a workgroup on its XCD's item range
+  int grid = k.nblocks;
+  if (grid > 512) grid = 512;
+  if (const char* f = getenv("CSD_C16_LC_GRID")) { const int v = atoi(f); if (v >= 8 && v % 8 == 0 && v < k.nblocks) grid = v; else if (v >= k.nblocks) grid = k.nblocks; }   // tuning aid
+  hipLaunchKernelGGL(kern, dim3(grid), dim3((k.nw + 1) * 64), lds, s, static_cast<const void*>(k.a.src0),
+                     static_cast<const void*>(k.a.src1), reinterpret_cast<const char*>(k.a.wpack), k);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+template <int MT, int NS, int KCS>
+static int pick_lc(const Conv16KArgs& k, const ConvPlan& p, bool mask, hipStream_t s) {
+  if (p.PW <= 24) {
+    if (mask) return launch_lc<MT, NS, true, 24, KCS>(k, p, s);
+    return launch_lc<MT, NS, false, 24, KCS>(k, p, s);
+  }
+  if (mask) return launch_lc<MT, NS, true, 34, KCS>(k, p, s);
+  return launch_lc<MT, NS, false, 34, KCS>(k, p, s);
+}
+
+int conv16_launch_lc(const Conv16KArgs& k, const ConvPlan& p, int ns, bool mask, hipStream_t s) {
+  CSD_REQUIRE(p.stride == 1 && p.up == 0 && p.C1 == 0 && p.KCS > 1, "conv16 lc: fp16-source stride-1 layers only");
+#define CSD_LC_CASE(MT_, NS_, KCS_) \
+  if (p.MT == MT_ && ns == NS_ && p.KCS == KCS_) return pick_lc<MT_, NS_, KCS_>(k, p, mask, s);
+  CSD_LC_CASE(4, 1, 3) CSD_LC_CASE(4, 1, 2) CSD_LC_CASE(2, 1, 3) CSD_LC_CASE(2, 1, 2)
+  CSD_LC_CASE(4, 2, 2) CSD_LC_CASE(2, 2, 2)
+#undef CSD_LC_CASE
+  set_error("conv16 lc: no kernel for MT=%d ns=%d KCS=%d", p.MT, ns, p.KCS);
+  return CSD_ERR_INVALID;
+}
+
+}  // namespace csd

@@ -1,0 +1,468 @@
+// conv_f16_q.hip - "quad" schedule of the fp16-source 3x3 stride-1 convolution for layers whose Cout is a
+// multiple of 96 (every ResnetBlockDDPM conv of the DDPM-family nets: 96 / 192 / 288 channels; reference
+// models/layers.py:ddpm_conv3x3 inside ResnetBlockDDPM, models/ddpm.py:149-213).
+//
+// Why: the 3-wave workgroups of conv_f16_kernel.h (one 32-cout tile per wave) put 6 MFMA waves on the 4
+// SIMDs of a CU as (2,2,1,1).  A workgroup synchronises every K stage, so it runs at the pace of its slowest
+// wave and two co-resident workgroups deliver barely more than one (tools/phase_timing*.py: a stage takes
+// 7.6k cycles alone, 19k next to a second workgroup; the ideal is 6.9k).  Here a workgroup is FOUR waves in a
+// 2 x 2 grid - M half (MQ 16-pixel tiles) x N half (48 couts = three 16-cout tiles) - on
+// v_mfma_f32_16x16x32_f16, so two workgroups give every SIMD exactly two waves that cover each other's
+// memory stalls.  Operands are swapped (A = weights, B = pixels): a lane's result is 4 consecutive couts of
+// one pixel, so the epilogue is 16-byte buffer loads/stores (12 per wave instead of 64 dword ones), all
+// reads issued before the first store (vmcnt retires in order and counts stores).
+//
+// LDS patch layout, staging bursts (KCS = 2: 32 channels per stage = one K step of the MFMA per tap) and
+// the arithmetic (NS = 2: hi/lo split operands, 3 MFMAs per product; NS = 1: plain fp16) are those of
+// conv_f16_kernel.h.  Weights: [Cout/96][N half][Cin/32][tap][16-cout tile 0..2][plane][lane][8 halves].
+#include <stdlib.h>
+
+#include "conv_f16_kernel.h"
+
+namespace csd {
+
+typedef float floatx4q __attribute__((ext_vector_type(4)));
+typedef unsigned int uint4q __attribute__((ext_vector_type(4)));
+
+#define C16Q_THREADS 256
+
+template <int MQ, int NS, bool MASK, int PWC>
+__global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void* __restrict__ g_hi,
+                                                                    const void* __restrict__ g_lo,
+                                                                    const char* __restrict__ g_wpack,
+                                                                    const Conv16KArgs k) {
+  constexpr int TAPS = 9, KS = 3, KCS = 2;
+  constexpr int LO = 32 * KCS;               // byte offset of the lo plane inside a staged pixel
+  constexpr int PSB = 32 * KCS * NS + 16;    // bytes per staged pixel
+  constexpr int NPIX = 2 * MQ * 16;          // pixels per workgroup tile
+  constexpr int SPP = 2 * NS * KCS;          // 16-byte slots per patch pixel per stage
+  constexpr int NU = (NS == 2) ? 7 : 4;      // staging slots per thread (host: patch * SPP <= NU * 256)
+  constexpr int rstride = PWC * PSB;
+  constexpr int WSTEP = 3 * NS * 1024;       // weight bytes per K step per wave
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mi = wave >> 1, ni = wave & 1;
+  const int l16 = lane & 15, kq = lane >> 4;
+
+  int w;
+  {
+    const int bid = blockIdx.x, nb = k.nblocks;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int ng = w % k.n_groups;
+  const int tile = w / k.n_groups;
+  const int tile_y = tile / k.tiles_x;
+  const int ov0 = tile_y * k.TH, ox0 = (tile - tile_y * k.tiles_x) * k.TW;
+  const int prow0 = ov0 - 1, pcol0 = ox0 - 1;
+  const int Cin = k.C0;
+  const int npatch = k.PH * k.PW;
+  const int patch_bytes = k.PH * PWC * PSB;
+  int* const otab = reinterpret_cast<int*>(smem16 + patch_bytes);   // [NPIX] output pixel (relative to the tile row) or -1
+  int* const btab = otab + NPIX;                                     // [NPIX] sample
+  int* const vtab = btab + NPIX;                                     // [NPIX] tap validity bits
+  int* const stab = vtab + NPIX;                                     // [npatch] source pixel or -1
+  int* const dtab = stab + npatch;                                   // [npatch] LDS byte offset
+
+  // ---- tables ----
+  for (int m = tid; m < NPIX; m += C16Q_THREADS) {
+    const int ty = m / k.TW, tx = m - ty * k.TW;
+    const int ov = ov0 + ty, ox = ox0 + tx;
+    const bool mv = (m < k.TH * k.TW) && (ov < k.B * k.OH) && (ox < k.OW);
+    const int b = ov / k.OH, oy = ov - b * k.OH;
+    unsigned vb = 0;
+#pragma unroll
+    for (int r = 0; r < KS; ++r) {
+      const int iy = oy + r - 1, ix = ox + r - 1;
+      vb |= ((mv && iy >= 0 && iy < k.IH) ? 1u : 0u) << r;
+      vb |= ((mv && ix >= 0 && ix < k.IW) ? 1u : 0u) << (3 + r);
+    }
+    otab[m] = mv ? (ov - ov0) * k.OW + ox : -1;
+    btab[m] = mv ? b : 0;
+    vtab[m] = (int)vb;
+  }
+  for (int pix = tid; pix < npatch; pix += C16Q_THREADS) {
+    const int pr = pix / k.PW, pc = pix - pr * k.PW;
+    const int vr = prow0 + pr, col = pcol0 + pc;
+    // (MASK == false: the tile lies inside ONE sample; halo rows of its neighbours are padding)
+    const int img_lo = MASK ? 0 : (ov0 / k.OH) * k.IH;
+    const int img_hi = MASK ? k.B * k.IH : img_lo + k.IH;
+    const bool in = vr >= img_lo && vr < img_hi && col >= 0 && col < k.IW;
+    stab[pix] = in ? vr * k.IW + col : -1;
+    dtab[pix] = (pr * PWC + pc) * PSB;
+  }
+  // per-lane pixels of this wave's M half: LDS offset of tap (0,0) + this lane's 8-channel K slice
+  int base[MQ];
+#pragma unroll
+  for (int j = 0; j < MQ; ++j) {
+    const int m = (mi * MQ + j) * 16 + l16;
+    const int ty = m / k.TW, tx = m - ty * k.TW;
+    base[j] = (m < k.TH * k.TW) ? ty * rstride + tx * PSB + kq * 16 : kq * 16;
+  }
+  __syncthreads();
+  unsigned vbits[MQ];
+  if (MASK) {
+#pragma unroll
+    for (int j = 0; j < MQ; ++j) vbits[j] = (unsigned)vtab[(mi * MQ + j) * 16 + l16];
+  }
+
+  // ---- staging: slot e = pixel * SPP + plane * 2*KCS + 16-byte piece ----
+  const int total4 = npatch * SPP;
+  auto slot_load = [&](int e, int cb) -> float4 {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < total4) {
+      const int pix = e / SPP, sub = e - pix * SPP;
+      const int sp = stab[pix];
+      if (sp >= 0) {
+        const int pl = sub / (2 * KCS), rest = sub - pl * (2 * KCS);
+        const _Float16* plane = static_cast<const _Float16*>((NS == 2 && pl) ? g_lo : g_hi);
+        v = gload4f(reinterpret_cast<const float*>(plane + (size_t)sp * Cin + cb + rest * 8));
+      }
+    }
+    return v;
+  };
+  auto slot_store = [&](int e, const float4& v) {
+    if (e >= total4) return;
+    const int pix = e / SPP, sub = e - pix * SPP;
+    const int pl = sub / (2 * KCS), rest = sub - pl * (2 * KCS);
+    *reinterpret_cast<float4*>(smem16 + dtab[pix] + pl * LO + rest * 16) = v;
+  };
+
+  // ---- weight stream of this wave: 3 fragments (x NS planes) per K step, ring of BR steps ----
+  constexpr int BR = 3;
+  const int nk32 = Cin / 32;
+  const char* wstep = g_wpack + ((size_t)(ng * 2 + ni) * nk32 * TAPS) * WSTEP + lane * 16;
+  half8 wreg[BR][3][NS];
+#pragma unroll
+  for (int q = 0; q < BR - 1; ++q)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int p = 0; p < NS; ++p) wreg[q][t][p] = gload_h8(wstep + (size_t)q * WSTEP + (t * NS + p) * 1024);
+  wstep += (size_t)(BR - 2) * WSTEP;
+
+  floatx4q acc[MQ][3];
+#pragma unroll
+  for (int j = 0; j < MQ; ++j)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) acc[j][t] = floatx4q{0.f, 0.f, 0.f, 0.f};
+
+  // first stage: one burst
+  {
+    float4 v0[NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) v0[j] = slot_load(j * C16Q_THREADS + tid, 0);
+#pragma unroll
+    for (int j = 0; j < NU; ++j) slot_store(j * C16Q_THREADS + tid, v0[j]);
+  }
+  __syncthreads();
+
+  const int nstage = nk32;                      // one 32-channel K step per tap per stage
+  for (int stg = 0; stg < nstage; ++stg) {
+    const bool more = stg + 1 < nstage;
+    float4 sv[NU];
+    if (more) {                                 // next stage's burst: in flight under this stage's MFMAs
+#pragma unroll
+      for (int j = 0; j < NU; ++j) sv[j] = slot_load(j * C16Q_THREADS + tid, (stg + 1) * 32);
+    }
+    constexpr int RING = 2;
+    half8 preg[RING][NS];
+    auto load_frag = [&](int q) {               // q = tap * MQ + j
+      const int tap_ = q / MQ, j_ = q % MQ;
+      const char* p = smem16 + base[j_] + (tap_ / KS) * rstride + (tap_ % KS) * PSB;
+#pragma unroll
+      for (int pl = 0; pl < NS; ++pl) preg[q % RING][pl] = *reinterpret_cast<const half8*>(p + pl * LO);
+    };
+    load_frag(0);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int bc = tap % BR, bn = (tap + BR - 1) % BR;
+      const int r = tap / KS, sx = tap % KS;
+      wstep += WSTEP;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) wreg[bn][t][p] = gload_h8(wstep + (t * NS + p) * 1024);
+#pragma unroll
+      for (int j = 0; j < MQ; ++j) {
+        const int q = tap * MQ + j;
+        if (q + 1 < TAPS * MQ) load_frag(q + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        half8 b[NS];
+        const bool v = !MASK || (((vbits[j] >> r) & 1u) && ((vbits[j] >> (3 + sx)) & 1u));
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl) {
+          b[pl] = preg[q % RING][pl];
+          if (MASK && !v) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[pl][e] = (_Float16)0.f;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          if (NS == 2) {
+            acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[bc][t][1], b[0], acc[j][t], 0, 0, 0);
+            acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[bc][t][0], b[1], acc[j][t], 0, 0, 0);
+          }
+          acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[bc][t][0], b[0], acc[j][t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    static_assert(TAPS % BR == 0, "weight ring phase");
+    if (more) {
+      __syncthreads();                          // everyone is done reading this stage's patch
+#pragma unroll
+      for (int j = 0; j < NU; ++j) slot_store(j * C16Q_THREADS + tid, sv[j]);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: lane = pixel l16 of each 16-pixel tile, 4 consecutive couts per 16-cout tile ----
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int RSRC_FLAGS = 0x00020000;
+  const float wunscale = 1.0f / C16_WSCALE;
+  const size_t o_base = (size_t)ov0 * k.OW;
+  const int b0 = ov0 / k.OH;
+  const bool has_res = k.a.res != nullptr, has_temb = k.a.temb != nullptr;
+  const __amdgpu_buffer_rsrc_t out_r =
+      __builtin_amdgcn_make_buffer_rsrc(k.a.out + o_base * k.a.out_stride + k.a.out_coff, 0, OOB, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(has_res ? k.a.res + o_base * k.Cout : k.a.out), 0, OOB, RSRC_FLAGS);
+  const int c_base = ng * 96 + ni * 48 + kq * 4;            // this lane's first cout of 16-cout tile 0
+  int oidx[MQ];
+#pragma unroll
+  for (int j = 0; j < MQ; ++j) oidx[j] = otab[(mi * MQ + j) * 16 + l16];
+  // every read before the first store
+  float4 bias4[3], tvu4[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int c0 = c_base + t * 16;
+    bias4[t] = k.a.bias ? gload4f(k.a.bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    tvu4[t] = (!MASK && has_temb) ? gload4f(k.a.temb + (size_t)b0 * k.a.temb_stride + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 addv[MQ][3];
+#pragma unroll
+  for (int j = 0; j < MQ; ++j)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      float4 a = tvu4[t];
+      if (has_res) {
+        const unsigned off = oidx[j] >= 0 ? (unsigned)(oidx[j] * k.Cout + c_base + t * 16) * 4u : OOB;
+        const uint4q rv = __builtin_amdgcn_raw_buffer_load_b128(res_r, off, 0, 0);
+        const float4 rr = make_float4(__uint_as_float(rv.x), __uint_as_float(rv.y), __uint_as_float(rv.z), __uint_as_float(rv.w));
+        // residual first, then the time-embedding column: the order of conv_f16_kernel.h
+        a = (MASK || !has_temb) ? rr : make_float4(rr.x + a.x, rr.y + a.y, rr.z + a.z, rr.w + a.w);
+      }
+      addv[j][t] = a;
+    }
+  if (MASK && has_temb) {
+#pragma unroll
+    for (int j = 0; j < MQ; ++j) {
+      const int b = btab[(mi * MQ + j) * 16 + l16];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const float4 tv = gload4f(k.a.temb + (size_t)b * k.a.temb_stride + c_base + t * 16);
+        addv[j][t] = make_float4(addv[j][t].x + tv.x, addv[j][t].y + tv.y, addv[j][t].z + tv.z, addv[j][t].w + tv.w);
+      }
+    }
+  }
+  double st_s[3][4], st_q[3][4];              // GroupNorm partials of this lane's 12 columns over its MQ pixels
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { st_s[t][i] = 0.0; st_q[t][i] = 0.0; }
+#pragma unroll
+  for (int j = 0; j < MQ; ++j)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const float b4[4] = {bias4[t].x, bias4[t].y, bias4[t].z, bias4[t].w};
+      const float a4[4] = {addv[j][t].x, addv[j][t].y, addv[j][t].z, addv[j][t].w};
+      float o4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // (acc*2^-8 + bias) + temb + residual: same association as the reference's h + Dense(temb), x + h
+        o4[i] = ((acc[j][t][i] * wunscale + b4[i]) + a4[i]) * k.a.out_scale;
+        const double dv = oidx[j] >= 0 ? (double)o4[i] : 0.0;
+        st_s[t][i] += dv;
+        st_q[t][i] = fma(dv, dv, st_q[t][i]);
+      }
+      uint4q ov;
+      ov.x = __float_as_uint(o4[0]); ov.y = __float_as_uint(o4[1]); ov.z = __float_as_uint(o4[2]); ov.w = __float_as_uint(o4[3]);
+      const unsigned off = oidx[j] >= 0 ? (unsigned)(oidx[j] * k.a.out_stride + c_base + t * 16) * 4u : OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(ov, out_r, off, 0, 0);
+    }
+  // GroupNorm statistics of the written tensor: one (sum, sumsq) pair per (tile, M half, cout); the host sets
+  // `stats` only when a tile lies inside one sample.  Fixed-shape butterfly over the 16 pixel lanes.
+  if (k.a.stats) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        double s = st_s[t][i], q = st_q[t][i];
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+          s += __shfl_xor(s, d);
+          q += __shfl_xor(q, d);
+        }
+        if (l16 == 0) {
+          double* dst = k.a.stats + (((size_t)tile * 2 + mi) * k.Cout + c_base + t * 16 + i) * 2;
+          dst[0] = s;
+          dst[1] = q;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+bool conv16q_supported(const ConvPlan& p, int ns) {
+  return (ns == 1 || ns == 2) && p.taps == 9 && p.stride == 1 && p.up == 0 && p.C1 == 0 && p.C0 % 32 == 0 && p.Cout % 96 == 0;
+}
+
+size_t conv16q_packed_bytes(const ConvPlan& p, int ns) {
+  return (size_t)(p.Cout / 96) * 2 * (p.C0 / 32) * 9 * 3 * ns * 1024 + (size_t)4 * 3 * ns * 1024;   // + prefetch slack
+}
+
+__global__ void conv16q_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ wpack, int layout, int cin_src,
+                                    int cout_src, int cout_off, int Cin, int Cout, int ns) {
+  // one thread per (cout in [cout_off, cout_off + cout_src), cin, tap)
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)cout_src * Cin * 9;
+  if (idx >= total) return;
+  const int tap = (int)(idx % 9);
+  const int cin = (int)((idx / 9) % Cin);
+  const int co = (int)(idx / ((size_t)9 * Cin));
+  const int cout = cout_off + co;
+  if (cin >= cin_src || cout >= Cout) return;          // padding stays zero
+  const float v = ((layout == 0) ? w[((size_t)co * cin_src + cin) * 9 + tap] : w[(size_t)cin * cout_src + co]) * C16_WSCALE;
+  const int ng = cout / 96, ni = (cout % 96) / 48, t = (cout % 48) / 16, r = cout % 16;
+  const int kb = cin / 32, kq = (cin % 32) / 8, q = cin % 8;
+  const int lane = kq * 16 + r;
+  const size_t step = ((size_t)(ng * 2 + ni) * (Cin / 32) + kb) * 9 + tap;
+  _Float16* dst = wpack + (step * 3 + t) * (size_t)ns * 512 + lane * 8 + q;
+  const _Float16 hi = (_Float16)v;
+  dst[0] = hi;
+  if (ns == 2) dst[512] = (_Float16)(v - (float)hi);
+}
+
+__global__ void conv16q_zero_kernel(uint32_t* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
+int conv16q_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int cin_src, int cout_src, int cout_off,
+                        void* wpack, hipStream_t s) {
+  if (cout_off == 0) {
+    const size_t n32 = conv16q_packed_bytes(p, ns) / 4;
+    hipLaunchKernelGGL(conv16q_zero_kernel, dim3((unsigned)cdiv64(n32, 256)), dim3(256), 0, s, (uint32_t*)wpack, n32);
+    CSD_LAUNCH_CHECK();
+  }
+  const size_t total = (size_t)cout_src * p.C0 * 9;
+  hipLaunchKernelGGL(conv16q_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w, (_Float16*)wpack, layout,
+                     cin_src, cout_src, cout_off, p.C0, p.Cout, ns);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+static int in_coord_q(int t) { return t + 2; }      // patch extent of a t-pixel tile edge (3x3, stride 1)
+
+int conv16q_plan_tiles(ConvPlan* p, int ns) {
+  CSD_REQUIRE(conv16q_supported(*p, ns), "conv16q: unsupported shape (Cin=%d Cout=%d)", p->C0, p->Cout);
+  p->KC = C16_KC;
+  p->CoutPad = p->Cout;
+  p->NT = 3;
+  p->n_groups = p->Cout / 96;
+  p->KCS = 2;
+  p->LC = 0;
+  const int psb = 32 * 2 * ns + 16;
+  const int spp = 2 * ns * 2;
+  const int nu = ns == 2 ? 7 : 4;
+  auto pitch = [&](int tw) { return in_coord_q(tw) <= 24 ? 24 : 34; };
+  int best_mq = 0, best_tw = 0, best_th = 0;
+  for (int mq = 4; mq >= 2; mq >>= 1) {        // 128- or 64-pixel tiles
+    const int npix = 2 * mq * 16;
+    int btw = 0, bth = 0, blds = 1 << 30;
+    double bcov = -1;
+    bool bunm = false;
+    for (int tw = 1; tw <= 32 && tw <= p->OW; ++tw) {
+      if (p->OW % tw != 0 && !(tw == 32 && p->OW > 32)) continue;
+      const int th = npix / tw;       // (th * tw may be < npix: the spare pixels are masked)
+      if (th < 1) continue;
+      const int patch = in_coord_q(th) * in_coord_q(tw);
+      const int lds = in_coord_q(th) * pitch(tw) * psb;
+      if (lds > 72 * 1024 || patch * spp > nu * C16Q_THREADS) continue;
+      const double cov = (double)th * tw * p->OW / ((double)cdiv(p->OW, tw) * tw);
+      const bool unm = (p->OH % th) == 0;
+      if (cov > bcov + 1e-9 || (cov > bcov - 1e-9 && ((unm && !bunm) || (unm == bunm && lds < blds)))) {
+        bcov = cov; blds = lds; btw = tw; bth = th; bunm = unm;
+      }
+    }
+    if (btw == 0) continue;
+    best_mq = mq; best_tw = btw; best_th = bth;
+    const long nwg = (long)cdiv(p->OW, btw) * cdiv(p->B * p->OH, bth) * p->n_groups;
+    if (nwg >= 512 || mq == 2) break;
+  }
+  CSD_REQUIRE(best_tw > 0, "conv16q: no feasible tile for OW=%d", p->OW);
+  p->TW = best_tw; p->TH = best_th;
+  p->PH = in_coord_q(p->TH); p->PW = in_coord_q(p->TW);
+  p->tiles_x = cdiv(p->OW, p->TW);
+  p->tiles_y = cdiv(p->B * p->OH, p->TH);
+  p->MT = best_mq;           // (field reused: 16-pixel tiles per wave)
+  p->lds_bytes = (size_t)p->PH * pitch(p->TW) * psb + (size_t)3 * 2 * best_mq * 16 * sizeof(int) +
+                 (size_t)2 * p->PH * p->PW * sizeof(int);
+  return CSD_OK;
+}
+
+template <int MQ, int NS, bool MASK, int PWC>
+static int launch_q(const Conv16KArgs& k, size_t lds, hipStream_t s) {
+  auto kern = conv_f16_q_kernel<MQ, NS, MASK, PWC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(k.nblocks), dim3(C16Q_THREADS), lds, s, static_cast<const void*>(k.a.src0),
+                     static_cast<const void*>(k.a.src1), reinterpret_cast<const char*>(k.a.wpack), k);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
+  CSD_REQUIRE(conv16q_supported(p, ns), "conv16q: unsupported layer");
+  CSD_REQUIRE(!a.out_nchw && a.nscale == nullptr && a.out_stride % 4 == 0 && a.out_coff % 4 == 0,
+              "conv16q: NHWC fp32 output with 16-byte aligned rows, pre-normalised fp16 source");
+  Conv16KArgs k;
+  k.a = a;
+  k.a.dbg = nullptr;
+  k.B = p.B; k.IH = p.IH; k.IW = p.IW; k.OH = p.OH; k.OW = p.OW;
+  k.C0 = p.C0; k.C1 = 0; k.Cout = p.Cout;
+  k.stride = 1; k.pad = 1; k.up = 0;
+  k.TH = p.TH; k.TW = p.TW; k.PH = p.PH; k.PW = p.PW;
+  k.tiles_x = p.tiles_x; k.n_groups = p.n_groups;
+  k.nblocks = p.tiles_x * p.tiles_y * p.n_groups;
+  k.nck = p.C0 / C16_KC;
+  k.nw = 4;
+  k.ntiles_n = p.Cout / 32;
+  const bool mask = (p.OH % p.TH) != 0;
+#define CSD_Q_CASE(MQ_, NS_)                                                  \
+  if (p.MT == MQ_ && ns == NS_) {                                             \
+    if (p.PW <= 24) {                                                         \
+      if (mask) return launch_q<MQ_, NS_, true, 24>(k, p.lds_bytes, s);       \
+      return launch_q<MQ_, NS_, false, 24>(k, p.lds_bytes, s);                \
+    }                                                                         \
+    if (mask) return launch_q<MQ_, NS_, true, 34>(k, p.lds_bytes, s);         \
+    return launch_q<MQ_, NS_, false, 34>(k, p.lds_bytes, s);                  \
+  }
+  CSD_Q_CASE(4, 2) CSD_Q_CASE(2, 2) CSD_Q_CASE(4, 1) CSD_Q_CASE(2, 1)
+#undef CSD_Q_CASE
+  set_error("conv16q: no kernel for MQ=%d ns=%d", p.MT, ns);
+  return CSD_ERR_INVALID;
+}
+
+}  // namespace csd

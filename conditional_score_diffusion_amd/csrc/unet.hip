@@ -85,6 +85,7 @@ struct PackedConv {
   size_t w_off = 0, b_off = 0;   // float offsets in the packed buffer
   int ns = 0;                    // 0: fp32 kernel layout; 1/2: fp16 kernel layout with ns planes
   bool pw = false;               // ns != 0 and the layer runs on the pointwise fp16 kernel (conv_pw16.hip)
+  bool q = false;                // ns != 0 and the layer runs on the quad-wave fp16 kernel (conv_f16_q.hip)
   struct Src { int param_w, param_b, layout, cout_src, cout_off, cin_src; };
   std::vector<Src> srcs;
 };
@@ -344,12 +345,21 @@ static int build_packed_layout(Net& n) {
     n.copy_off[pname] = cpy.off;
   };
   const int net_ns = precision_ns(n.cfg.precision);
+  // quad schedule: measured faster than the loader/consumer one in the split (3-MFMA) mode only
+  const bool use_q = net_ns == 2 && !getenv("CSD_NO_Q");
   auto add_conv = [&](const std::string& key, int c0, int c1, int cout, int taps,
-                      std::vector<PackedConv::Src> srcs, bool stride1 = true) -> int {
+                      std::vector<PackedConv::Src> srcs, bool stride1 = true, bool normed = false) -> int {
     PackedConv pc;
     int rc = proto_conv(&pc.proto, c0, c1, cout, taps);
     if (rc) return rc;
-    if (net_ns && stride1 && conv16_supported(pc.proto)) {
+    ConvPlan one = pc.proto;       // a GroupNorm-ed conv reads ONE fp16 tensor of c0 + c1 channels
+    one.C0 = c0 + c1; one.C1 = 0;
+    if (use_q && normed && stride1 && conv16q_supported(one, net_ns)) {
+      pc.ns = net_ns;
+      pc.q = true;
+      pc.proto.KC = 16;
+      pc.w_off = take(conv16q_packed_bytes(one, pc.ns) / sizeof(float) + 1);
+    } else if (net_ns && stride1 && conv16_supported(pc.proto)) {
       pc.ns = net_ns;
       if ((rc = conv16_plan_tiles(&pc.proto, pc.ns))) return rc;
       pc.w_off = take(conv16_packed_bytes(pc.proto, pc.ns) / sizeof(float) + 1);
@@ -397,12 +407,12 @@ static int build_packed_layout(Net& n) {
     add_copy(mname(m.idx, "GroupNorm_0.weight"));
     add_copy(mname(m.idx, "GroupNorm_0.bias"));
     int r = add_conv(k + ".Conv_0", c0, c1, m.cout, 9,
-                     {{n.P(mname(m.idx, "Conv_0.weight")), n.P(mname(m.idx, "Conv_0.bias")), 0, m.cout, 0}});
+                     {{n.P(mname(m.idx, "Conv_0.weight")), n.P(mname(m.idx, "Conv_0.bias")), 0, m.cout, 0}}, true, true);
     if (r) return r;
     add_copy(mname(m.idx, "GroupNorm_1.weight"));
     add_copy(mname(m.idx, "GroupNorm_1.bias"));
     r = add_conv(k + ".Conv_1", m.cout, 0, m.cout, 9,
-                 {{n.P(mname(m.idx, "Conv_1.weight")), n.P(mname(m.idx, "Conv_1.bias")), 0, m.cout, 0}});
+                 {{n.P(mname(m.idx, "Conv_1.weight")), n.P(mname(m.idx, "Conv_1.bias")), 0, m.cout, 0}}, true, true);
     if (r) return r;
     if (m.cin != m.cout) {
       r = add_conv(k + ".NIN_0", c0, c1, m.cout, 1,
@@ -558,11 +568,15 @@ struct Builder {
     o.cp.stride = stride; o.cp.pad = pad; o.cp.up = up;
     o.cp.OH = (ih << up) / stride; o.cp.OW = (iw << up) / stride;
     o.i4 = pc.ns;
-    o.i2 = pc.pw ? 1 : 0;
+    o.i2 = pc.pw ? 1 : (pc.q ? 2 : 0);
     const int kcs = (pc.ns && !pc.pw && norm) ? conv16_kcs(pc.ns, o.cp.C0 + o.cp.C1) : 1;    // fp16-source convs stage in bursts
-    if (pc.pw) {
+    if (pc.q) {
+      if (!norm || stride != 1 || up || external_nchw) { set_error("quad fp16 conv on an unsupported layer"); rc = CSD_ERR_INVALID; return NONE; }
+      o.cp.C0 = o.cp.C0 + o.cp.C1; o.cp.C1 = 0;
+      if (conv16q_plan_tiles(&o.cp, pc.ns)) { rc = CSD_ERR_INVALID; return NONE; }
+    } else if (pc.pw) {
       if (act != CSD_ACT_NONE || temb_col != NONE || external_nchw) { set_error("pointwise fp16 layer with act/temb/NCHW"); rc = CSD_ERR_INVALID; return NONE; }
-    } else if (pc.ns ? conv16_plan_tiles(&o.cp, pc.ns, kcs) : conv_plan_tiles(&o.cp)) { rc = CSD_ERR_INVALID; return NONE; }
+    } else if (pc.ns ? conv16_plan_tiles(&o.cp, pc.ns, kcs, kcs > 1 && !getenv("CSD_NO_LC")) : conv_plan_tiles(&o.cp)) { rc = CSD_ERR_INVALID; return NONE; }
     // the packed layout depends on KC only (not on NT / tile shape)
     if (o.cp.KC != pc.proto.KC) { set_error("conv plan/pack mismatch"); rc = CSD_ERR_INVALID; return NONE; }
     o.a = src0; o.b = src1; o.pk0 = pc.w_off; o.pk1 = pc.b_off;
@@ -575,7 +589,7 @@ struct Builder {
       const size_t nh = ((size_t)B * ih * iw * (o.cp.C0 + o.cp.C1) + 1) / 2;      // halves -> floats
       Op ap;
       ap.kind = OP_GN_APPLY16;
-      ap.a = src0; ap.b = src1; ap.i0 = o.cp.C0; ap.i1 = o.cp.C1; ap.i2 = ih * iw;
+      ap.a = src0; ap.b = src1; ap.i0 = pc.proto.C0; ap.i1 = pc.proto.C1; ap.i2 = ih * iw;
       ap.d = nscale; ap.e = nshift; ap.act = act;
       hi16 = alloc_(nh);
       if (pc.ns == 2) lo16 = alloc_(nh);
@@ -599,7 +613,7 @@ struct Builder {
     if (!pc.pw && !external_nchw && o.cp.taps == 9 && o.cp.OH % o.cp.TH == 0 && !getenv("CSD_NO_FUSED_STATS")) {
       // every tile lies inside one sample: the epilogue also leaves (sum, sumsq) per (tile, cout) for the next
       // GroupNorm (the fp32 kernel: per (tile, wave, cout))
-      const int tpi = (o.cp.OH / o.cp.TH) * o.cp.tiles_x * (pc.ns ? 1 : 4);
+      const int tpi = (o.cp.OH / o.cp.TH) * o.cp.tiles_x * (pc.q ? 2 : (pc.ns ? 1 : 4));
       o.stats = alloc_((size_t)B * tpi * o.cp.Cout * 2 * 2);      // doubles; never released (small)
       tile_stats[o.out] = TileStats{o.stats, tpi};
     }
@@ -886,7 +900,8 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         a.out_scale = 1.f;
         a.dbg = nullptr;
         a.stats = reinterpret_cast<double*>(W(o.stats));
-        rc = o.i2 ? pw16_launch(o.cp, o.i4, a, s) : (o.i4 ? conv16_launch(o.cp, o.i4, a, s, o.i3 != 0) : conv_launch(o.cp, a, s));
+        rc = o.i2 == 2 ? conv16q_launch(o.cp, o.i4, a, s)
+           : o.i2 ? pw16_launch(o.cp, o.i4, a, s) : (o.i4 ? conv16_launch(o.cp, o.i4, a, s, o.i3 != 0) : conv_launch(o.cp, a, s));
         break;
       }
       case OP_ATTN:
@@ -943,7 +958,11 @@ static int pack_all(Net& n, float* pk, hipStream_t s) {
     if ((rc = dev_fill(pk + pc.b_off, 0.f, (size_t)pc.proto.CoutPad, s))) return rc;
     for (auto& src : pc.srcs) {   // sources are listed with ascending cout_off, first one clears the tensor
       const int cin_src = src.cin_src > 0 ? src.cin_src : pc.proto.C0 + pc.proto.C1;
-      rc = pc.pw ? pw16_pack_weight(pc.proto, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
+      ConvPlan one = pc.proto;
+      one.C0 = pc.proto.C0 + pc.proto.C1; one.C1 = 0;
+      rc = pc.q ? conv16q_pack_weight(one, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
+                                      src.cout_off, pk + pc.w_off, s)
+         : pc.pw ? pw16_pack_weight(pc.proto, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
                                     src.cout_off, pk + pc.w_off, s)
          : pc.ns ? conv16_pack_weight(pc.proto, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
                                       src.cout_off, pk + pc.w_off, s)
