@@ -170,7 +170,7 @@ static int launch16(const Conv16KArgs& k, size_t lds, hipStream_t s) {
 }
 
 int conv16_launch_in16(const Conv16KArgs& k, const ConvPlan& p, int ns, bool mask, hipStream_t s);   // conv_f16_in16.hip
-int conv16_launch_lc(const Conv16KArgs& k, const ConvPlan& p, int ns, bool mask, hipStream_t s);     // conv_f16_lc.hip
+int conv16_launch_lc(const Conv16KArgs& k, const ConvPlan& p, int ns, bool mask, hipStream_t s, bool f32src);     // conv_f16_lc.hip
 
 long long* g_c16_dbg = nullptr;     // tuning builds only
 int g_c16_dbg_blocks = 0;
@@ -191,7 +191,7 @@ int conv16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s, b
   k.ntiles_n = p.CoutPad / 32;
   CSD_REQUIRE(p.taps == 9, "conv16: only 3x3 kernels");
   CSD_REQUIRE(!in16 || (p.C1 == 0 && a.nscale == nullptr), "conv16: fp16 sources are single-tensor and pre-normalised");
-  CSD_REQUIRE(in16 || p.KCS == 1, "conv16: multi-chunk stages need an fp16 source");
+  CSD_REQUIRE(in16 || p.KCS == 1 || p.LC, "conv16: multi-chunk stages need an fp16 source");
   // masks are needed iff a tile can straddle two images (or the x2-upsample parity map is in use)
   const bool mask = (p.OH % p.TH) != 0 || p.up != 0;
   if (g_c16_dbg && k.nblocks == g_c16_dbg_blocks && g_c16_dbg_n < g_c16_dbg_max) {   // (tuning builds)
@@ -201,7 +201,7 @@ int conv16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s, b
     if (hipMemcpyAsync(k.a.dbg + 4095 * 8, hdr, sizeof(hdr), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
     g_c16_dbg_n++;
   }
-  if (in16 && p.LC) return conv16_launch_lc(k, p, ns, mask, s);
+  if (p.LC) return conv16_launch_lc(k, p, ns, mask, s, !in16);
   if (in16) return conv16_launch_in16(k, p, ns, mask, s);
 #define CSD_C16_CASE(MT_, NS_)                                                   \
   if (p.MT == MT_ && ns == NS_) {                                                \

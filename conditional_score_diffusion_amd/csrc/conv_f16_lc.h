@@ -28,7 +28,10 @@ __device__ __forceinline__ void lds_barrier() {     // LDS visibility only: VMEM
 
 #define C16_LC_MAXPATCH 208     // patch pixels a loader wave can stage (host: conv16_plan_tiles)
 
-template <int MT, int NS, bool MASK, int PWC, int KCS>
+// F32: the source is the fp32 NHWC residual stream itself (two-source virtual concat allowed) and the LOADER
+// applies the GroupNorm affine + activation + fp16 (hi|lo) split while it writes the patch - the
+// gn_apply16 pass and its fp16 planes disappear.  Host: KCS == 2, tiles inside one sample (MASK == false).
+template <int MT, int NS, bool MASK, int PWC, int KCS, bool F32>
 __global__ __launch_bounds__(256, 2) void conv_f16_lc_kernel(const void* __restrict__ g_hi,
                                                             const void* __restrict__ g_lo,
                                                             const char* __restrict__ g_wpack,
@@ -37,7 +40,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16_lc_kernel(const void* __restr
   constexpr int LO = 32 * KCS;               // byte offset of the lo plane inside a staged pixel
   constexpr int PSB = 32 * KCS * NS + 16;    // bytes per staged pixel: [hi KCS*16 ch][lo KCS*16 ch] + pad
   constexpr int NPIX = MT * 32;
-  constexpr int SPP = 2 * NS * KCS;          // 16-byte slots per patch pixel per stage
+  static_assert(!F32 || (KCS == 2 && !MASK), "fused fp32 source: 32-channel stages, unmasked tiles");
+  constexpr int SPP = F32 ? 4 * KCS : 2 * NS * KCS;   // 16-byte slots per patch pixel per stage (fp32: 4 channels each)
   constexpr int NUL = (C16_LC_MAXPATCH * SPP + 63) / 64;     // slots per loader lane
   constexpr int rstride = PWC * PSB;
   constexpr int SSTEPS = KCS * TAPS;         // K steps per stage (sub-chunk major, tap minor = stream order)
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_lc_kernel(const void* __restr
     const int q = nitems >> 3, r = nitems & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   };
-  const int Cin = k.C0;       // fp16 source: one tensor
+  const int Cin = k.C0 + k.C1;       // (fp16 source: one tensor, C1 == 0)
 #ifdef CSD_LC_STAGGER
   if ((int)blockIdx.x >= G / 2 && my_items > 1) {      // experiment: start the second workgroup of a CU half an item late
     const long long t0 = clock64();
@@ -86,11 +90,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16_lc_kernel(const void* __restr
       s_prc[j] = (e < total4) ? ((pr << 16) | (pix - pr * k.PW)) : -1;
     }
     float4 sv[NUL];
+    int tile_b = 0;             // F32: sample of the current tile (row of the GroupNorm scale/shift table)
+    float4 n_sc = make_float4(0.f, 0.f, 0.f, 0.f), n_sh = n_sc;     // F32: scale/shift of this lane's 4 channels, per stage
     auto tile_setup = [&](int item, int tb) {      // addresses of the tile's patch + its epilogue/mask tables
       const int tile = item / k.n_groups;
       const int tile_y = tile / k.tiles_x;
       const int ov0 = tile_y * k.TH, ox0 = (tile - tile_y * k.tiles_x) * k.TW;
       const int prow0 = ov0 - 1, pcol0 = ox0 - 1;
+      tile_b = ov0 / k.OH;
       // (MASK == false: the tile lies inside ONE sample and halo rows of its neighbours are padding)
       const int img_lo = MASK ? 0 : (ov0 / k.OH) * k.IH;
       const int img_hi = MASK ? k.B * k.IH : img_lo + k.IH;
@@ -120,25 +127,65 @@ __global__ __launch_bounds__(256, 2) void conv_f16_lc_kernel(const void* __restr
     };
     auto issue = [&](int stage) {                  // the whole patch of one K stage, back to back
       const int cb = stage * KCS * C16_KC;
+      if constexpr (F32) {
+        // slot = (pixel, 4-channel group lane % 8): the channel group of a lane is the same for all its slots
+        const int gch = lane & 7;
+        const bool s1 = cb >= k.C0;
+        const float* src = static_cast<const float*>(s1 ? g_lo : g_hi);
+        const int Cs = s1 ? k.C1 : k.C0, c = (s1 ? cb - k.C0 : cb) + gch * 4;
 #pragma unroll
-      for (int j = 0; j < NUL; ++j) {
-        const int e = j * 64 + lane;
-        const int sub = e % SPP;
-        const int pl = sub / (2 * KCS), rest = sub - pl * (2 * KCS);
-        const _Float16* plane = static_cast<const _Float16*>((NS == 2 && pl) ? g_lo : g_hi);
-        const int sp = s_off[j] >= 0 ? s_off[j] : 0;        // (out-of-image slots read pixel 0 and are zeroed below)
-        sv[j] = gload4f(reinterpret_cast<const float*>(plane + (size_t)sp * Cin + cb + rest * 8));
-      }
-    };
-    auto write = [&](char* buf) {
+        for (int j = 0; j < NUL; ++j) {
+          const int sp = s_off[j] >= 0 ? s_off[j] : 0;
+          sv[j] = gload4f(src + (size_t)sp * Cs + c);
+        }
+        n_sc = gload4f(k.a.nscale + (size_t)tile_b * Cin + cb + gch * 4);
+        n_sh = gload4f(k.a.nshift + (size_t)tile_b * Cin + cb + gch * 4);
+      } else {
 #pragma unroll
-      for (int j = 0; j < NUL; ++j) {
-        if (s_prc[j] >= 0) {
+        for (int j = 0; j < NUL; ++j) {
           const int e = j * 64 + lane;
           const int sub = e % SPP;
           const int pl = sub / (2 * KCS), rest = sub - pl * (2 * KCS);
-          const float4 v = s_off[j] >= 0 ? sv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(buf + ((s_prc[j] >> 16) * PWC + (s_prc[j] & 0xffff)) * PSB + pl * LO + rest * 16) = v;
+          const _Float16* plane = static_cast<const _Float16*>((NS == 2 && pl) ? g_lo : g_hi);
+          const int sp = s_off[j] >= 0 ? s_off[j] : 0;        // (out-of-image slots read pixel 0 and are zeroed below)
+          sv[j] = gload4f(reinterpret_cast<const float*>(plane + (size_t)sp * Cin + cb + rest * 8));
+        }
+      }
+    };
+    auto write = [&](char* buf) {
+      if constexpr (F32) {
+        const int gch = lane & 7;
+        const float4 sc = n_sc, sh = n_sh;
+#pragma unroll
+        for (int j = 0; j < NUL; ++j) {
+          if (s_prc[j] >= 0) {
+            half4 hi, lo;
+            if (s_off[j] >= 0) {
+              // same arithmetic as gn_apply16_kernel: fma, fast SiLU, round-to-nearest fp16, lo = h - hi
+              const float h0 = act16(sv[j].x * sc.x + sh.x, k.a.act), h1 = act16(sv[j].y * sc.y + sh.y, k.a.act);
+              const float h2 = act16(sv[j].z * sc.z + sh.z, k.a.act), h3 = act16(sv[j].w * sc.w + sh.w, k.a.act);
+              hi[0] = (_Float16)h0; hi[1] = (_Float16)h1; hi[2] = (_Float16)h2; hi[3] = (_Float16)h3;
+              lo[0] = (_Float16)(h0 - (float)hi[0]); lo[1] = (_Float16)(h1 - (float)hi[1]);
+              lo[2] = (_Float16)(h2 - (float)hi[2]); lo[3] = (_Float16)(h3 - (float)hi[3]);
+            } else {          // zero padding is applied to the ACTIVATED tensor: out-of-image taps are exactly 0
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { hi[q] = (_Float16)0.f; lo[q] = (_Float16)0.f; }
+            }
+            char* dst = buf + ((s_prc[j] >> 16) * PWC + (s_prc[j] & 0xffff)) * PSB + gch * 8;
+            *reinterpret_cast<half4*>(dst) = hi;
+            if (NS == 2) *reinterpret_cast<half4*>(dst + LO) = lo;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NUL; ++j) {
+          if (s_prc[j] >= 0) {
+            const int e = j * 64 + lane;
+            const int sub = e % SPP;
+            const int pl = sub / (2 * KCS), rest = sub - pl * (2 * KCS);
+            const float4 v = s_off[j] >= 0 ? sv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(buf + ((s_prc[j] >> 16) * PWC + (s_prc[j] & 0xffff)) * PSB + pl * LO + rest * 16) = v;
+          }
         }
       }
     };

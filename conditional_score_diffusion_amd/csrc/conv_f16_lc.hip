@@ -10,9 +10,9 @@ size_t conv16_lc_lds_bytes(const ConvPlan& p, int ns, int pitch_px) {
   return (size_t)2 * p.PH * pitch_px * psb + (size_t)9 * p.MT * 32 * sizeof(int);
 }
 
-template <int MT, int NS, bool MASK, int PWC, int KCS>
+template <int MT, int NS, bool MASK, int PWC, int KCS, bool F32 = false>
 static int launch_lc(const Conv16KArgs& k, const ConvPlan& p, hipStream_t s) {
-  auto kern = conv_f16_lc_kernel<MT, NS, MASK, PWC, KCS>;
+  auto kern = conv_f16_lc_kernel<MT, NS, MASK, PWC, KCS, F32>;
   static bool attr_set = false;
   if (!attr_set) {
     CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -42,8 +42,23 @@ static int pick_lc(const Conv16KArgs& k, const ConvPlan& p, bool mask, hipStream
   return launch_lc<MT, NS, false, 34, KCS>(k, p, s);
 }
 
-int conv16_launch_lc(const Conv16KArgs& k, const ConvPlan& p, int ns, bool mask, hipStream_t s) {
-  CSD_REQUIRE(p.stride == 1 && p.up == 0 && p.C1 == 0 && p.KCS > 1, "conv16 lc: fp16-source stride-1 layers only");
+int conv16_launch_lc(const Conv16KArgs& k, const ConvPlan& p, int ns, bool mask, hipStream_t s, bool f32src) {
+  CSD_REQUIRE(p.stride == 1 && p.up == 0 && p.KCS > 1, "conv16 lc: stride-1 layers staged in bursts only");
+  if (f32src) {
+    // fp32 source with the GroupNorm affine + activation fused into the loader
+    CSD_REQUIRE(!mask && p.KCS == 2 && p.C0 % 32 == 0 && p.C1 % 32 == 0 && k.a.nscale && k.a.nshift,
+                "conv16 lc (fused norm): needs unmasked tiles, 32-channel stages and scale/shift tables");
+#define CSD_LCF_CASE(MT_, NS_)                                                              \
+  if (p.MT == MT_ && ns == NS_) {                                                           \
+    if (p.PW <= 24) return launch_lc<MT_, NS_, false, 24, 2, true>(k, p, s);               \
+    return launch_lc<MT_, NS_, false, 34, 2, true>(k, p, s);                               \
+  }
+    CSD_LCF_CASE(4, 1) CSD_LCF_CASE(2, 1) CSD_LCF_CASE(4, 2) CSD_LCF_CASE(2, 2)
+#undef CSD_LCF_CASE
+    set_error("conv16 lc (fused norm): no kernel for MT=%d ns=%d", p.MT, ns);
+    return CSD_ERR_INVALID;
+  }
+  CSD_REQUIRE(p.C1 == 0, "conv16 lc: fp16 sources are single-tensor");
 #define CSD_LC_CASE(MT_, NS_, KCS_) \
   if (p.MT == MT_ && ns == NS_ && p.KCS == KCS_) return pick_lc<MT_, NS_, KCS_>(k, p, mask, s);
   CSD_LC_CASE(4, 1, 3) CSD_LC_CASE(4, 1, 2) CSD_LC_CASE(2, 1, 3) CSD_LC_CASE(2, 1, 2)

@@ -347,6 +347,9 @@ static int build_packed_layout(Net& n) {
   const int net_ns = precision_ns(n.cfg.precision);
   // quad schedule: measured faster than the loader/consumer one in the split (3-MFMA) mode only
   const bool use_q = net_ns == 2 && !getenv("CSD_NO_Q");
+  int cur_res = n.cfg.image_size;    // resolution of the layer being laid out
+  // opt-in experiment (measured slower: one loader wave cannot convert a patch as fast as three waves consume it)
+  const bool fused_norm = getenv("CSD_FUSED_NORM") != nullptr;
   auto add_conv = [&](const std::string& key, int c0, int c1, int cout, int taps,
                       std::vector<PackedConv::Src> srcs, bool stride1 = true, bool normed = false) -> int {
     PackedConv pc;
@@ -354,7 +357,9 @@ static int build_packed_layout(Net& n) {
     if (rc) return rc;
     ConvPlan one = pc.proto;       // a GroupNorm-ed conv reads ONE fp16 tensor of c0 + c1 channels
     one.C0 = c0 + c1; one.C1 = 0;
-    if (use_q && normed && stride1 && conv16q_supported(one, net_ns)) {
+    // high-resolution GroupNorm-ed convs run the loader/consumer schedule with the norm fused into its loader
+    // (standard fragment layout); the quad schedule serves the lower levels, whose tiles straddle samples
+    if (use_q && normed && stride1 && !(fused_norm && cur_res >= 64) && conv16q_supported(one, net_ns)) {
       pc.ns = net_ns;
       pc.q = true;
       pc.proto.KC = 16;
@@ -450,6 +455,7 @@ static int build_packed_layout(Net& n) {
   };
   for (int l = 0; l < c.n_levels; ++l) {
     const int res = c.image_size >> l;
+    cur_res = res;
     for (int b = 0; b < c.num_res_blocks; ++b) {
       Module& m = next_mod();
       if ((rc = res_layout(m, in_ch, 0))) return rc;
@@ -464,6 +470,7 @@ static int build_packed_layout(Net& n) {
   if ((rc = res_layout(next_mod(), in_ch, 0))) return rc;
   for (int l = c.n_levels - 1; l >= 0; --l) {
     const int res = c.image_size >> l;
+    cur_res = res;
     for (int b = 0; b < c.num_res_blocks + 1; ++b) {
       Module& m = next_mod();
       const int skip = hs_c.back();
@@ -570,7 +577,17 @@ struct Builder {
     o.i4 = pc.ns;
     o.i2 = pc.pw ? 1 : (pc.q ? 2 : 0);
     const int kcs = (pc.ns && !pc.pw && norm) ? conv16_kcs(pc.ns, o.cp.C0 + o.cp.C1) : 1;    // fp16-source convs stage in bursts
-    if (pc.q) {
+    bool fused = false;     // GroupNorm affine + activation applied by the conv's loader wave (no gn_apply16 pass)
+    if (pc.ns && !pc.pw && !pc.q && norm && stride == 1 && !up && o.cp.C0 % 32 == 0 && o.cp.C1 % 32 == 0 &&
+        !getenv("CSD_NO_LC") && getenv("CSD_FUSED_NORM")) {
+      ConvPlan trial = o.cp;
+      if (conv16_plan_tiles(&trial, pc.ns, 2, true) == CSD_OK && trial.LC && trial.OH % trial.TH == 0) {
+        fused = true;
+        o.cp = trial;
+      }
+    }
+    if (fused) {
+    } else if (pc.q) {
       if (!norm || stride != 1 || up || external_nchw) { set_error("quad fp16 conv on an unsupported layer"); rc = CSD_ERR_INVALID; return NONE; }
       o.cp.C0 = o.cp.C0 + o.cp.C1; o.cp.C1 = 0;
       if (conv16q_plan_tiles(&o.cp, pc.ns)) { rc = CSD_ERR_INVALID; return NONE; }
@@ -584,7 +601,7 @@ struct Builder {
     o.d = norm ? nscale : NONE;
     o.e = norm ? nshift : NONE;
     size_t hi16 = NONE, lo16 = NONE;
-    if (pc.ns && !pc.pw && norm) {
+    if (pc.ns && !pc.pw && norm && !fused) {
       // fp16 kernel: normalise + activate + split ONCE per element into fp16 planes, conv copies them
       const size_t nh = ((size_t)B * ih * iw * (o.cp.C0 + o.cp.C1) + 1) / 2;      // halves -> floats
       Op ap;
