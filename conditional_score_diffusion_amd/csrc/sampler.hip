@@ -120,6 +120,21 @@ __global__ __launch_bounds__(256) void reverse_diffusion_update_kernel(float* __
   }
 }
 
+// general one-step update shared by the Euler-Maruyama / ancestral-sampling predictors and the annealed
+// Langevin corrector (sampling/predictors.py:52-76,105-179, correctors.py:111-142 of the reference): with
+// per-call scalars p, a, c     x_mean = p*x + a*score,   x = x_mean + c*z
+__global__ __launch_bounds__(256) void affine_noise_update_kernel(float* __restrict__ x, float* __restrict__ x_mean,
+                                                                  const float* __restrict__ score,
+                                                                  const float* __restrict__ z, float p, float a,
+                                                                  float c, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float xm = p * x[i] + a * score[i];
+    x_mean[i] = xm;
+    x[i] = xm + c * z[i];
+  }
+}
+
 // ---- Philox4x32-10 + Box-Muller ------------------------------------------------------------------
 __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3,
                                              uint32_t k0, uint32_t k1) {
@@ -201,6 +216,14 @@ int reverse_diffusion_update_launch(float* x, float* x_mean, const float* net, i
   return CSD_OK;
 }
 
+int affine_noise_update_launch(float* x, float* x_mean, const float* score, const float* z, float p, float a, float c,
+                               size_t total, hipStream_t s) {
+  hipLaunchKernelGGL(affine_noise_update_kernel, dim3(ew_grid(total)), dim3(256), 0, s, x, x_mean, score, z, p, a, c,
+                     total);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
 int randn_launch(float* out, int64_t n, uint64_t seed, uint64_t stream_id, hipStream_t s) {
   if (n <= 0) return CSD_OK;
   CSD_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "randn: output must be 16-byte aligned");
@@ -240,6 +263,12 @@ extern "C" int csd_reverse_diffusion_step(float* x, float* x_mean, const float* 
                                           float G, int B, int64_t per_sample, void* stream) {
   CSD_REQUIRE(B > 0 && per_sample > 0, "reverse_diffusion_step: bad arguments");
   return reverse_diffusion_update_launch(x, x_mean, net, per_sample, z, std, G, B, per_sample, (hipStream_t)stream);
+}
+
+extern "C" int csd_affine_noise_step(float* x, float* x_mean, const float* score, const float* z, float p, float a,
+                                     float c, int64_t n, void* stream) {
+  CSD_REQUIRE(x && x_mean && score && z && n > 0, "affine_noise_step: bad arguments");
+  return affine_noise_update_launch(x, x_mean, score, z, p, a, c, (size_t)n, (hipStream_t)stream);
 }
 
 extern "C" int csd_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {

@@ -131,6 +131,15 @@ def langevin_step(x, net, z, std, snr):
     return x, x_mean
 
 
+def affine_noise_step(x, score, z, p, a, c):
+    """In-place x_mean = p*x + a*score; x = x_mean + c*z (Euler-Maruyama / ancestral / annealed-Langevin updates)."""
+    x, score, z = _c(x, 'x'), _c(score, 'score'), _c(z, 'z')
+    x_mean = torch.empty_like(x)
+    check(lib().csd_affine_noise_step(ptr(x), ptr(x_mean), ptr(score), ptr(z), float(p), float(a), float(c),
+                                      x.numel(), current_stream(x.device)), 'affine_noise_step')
+    return x, x_mean
+
+
 def reverse_diffusion_step(x, net, z, std, G):
     """In-place reverse-diffusion predictor update (sampling/predictors.py:97-102)."""
     x, net, z = _c(x, 'x'), _c(net, 'net'), _c(z, 'z')

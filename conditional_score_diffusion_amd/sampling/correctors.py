@@ -2,8 +2,8 @@
 
 Mirrors sampling/correctors.py of the reference: ``register_corrector`` / ``get_corrector``
 (:5-27), ``Corrector`` (:29-49), ``langevin`` (:51-78), ``conditional_langevin`` (:81-108),
-``none`` / ``conditional_none`` (:145-163).  ``ald`` / ``conditional_ald`` (:111-142) are not
-provided yet and raise NotImplementedError.
+``none`` / ``conditional_none`` (:145-163) and ``ald`` (:111-142, plus a conditional variant) on the general
+affine update kernel.
 """
 import abc
 
@@ -96,17 +96,46 @@ class conditionalNoneCorrector(Corrector):
         return x, x
 
 
-def _not_yet(name):
-    class _Missing(Corrector):
-        def __init__(self, *a, **k):
-            raise NotImplementedError('corrector %r is not provided by the HIP path yet (SURVEY.md 8f)' % name)
+def _ald(sde, score_of, x, t, snr, n_steps):
+    """Annealed Langevin dynamics (sampling/correctors.py:111-142): step = (snr*std(t))^2 * 2*alpha,
+    x_mean = x + step*grad, x = x_mean + sqrt(2*step)*z; no batch coupling."""
+    t1 = t.detach().cpu().flatten()[:1].to(torch.float32)
+    if t.numel() > 1 and not bool(torch.all(t == t.flatten()[0])):
+        raise NotImplementedError('per-sample t within one update is not supported by the HIP step kernel')
+    if isinstance(sde, (sde_lib.VPSDE, sde_lib.cVPSDE, sde_lib.subVPSDE)):
+        alpha = float(sde.alphas.to(torch.float32)[int((t1 * (sde.N - 1) / sde.T).long()[0])])
+    else:
+        alpha = 1.0
+    std = float(sde.marginal_prob(torch.zeros(1, 1, 1, 1), t1)[1].flatten()[0])
+    step = (snr * std) ** 2 * 2 * alpha
+    x = x.clone()
+    x_mean = x
+    for _ in range(n_steps):
+        grad = score_of(x)
+        noise = torch.randn_like(x)
+        x, x_mean = ops.affine_noise_step(x, grad, noise, 1.0, step, (2 * step) ** 0.5)
+    return x, x_mean
 
-        def update_fn(self, x, t):  # pragma: no cover
-            raise NotImplementedError
 
-    _Missing.__name__ = 'Missing_' + name
-    return _Missing
+@register_corrector(name='ald')
+class AnnealedLangevinDynamics(Corrector):
+    def __init__(self, sde, score_fn, snr, n_steps):
+        super().__init__(sde, score_fn, snr, n_steps)
+        if not isinstance(sde, (sde_lib.VPSDE, sde_lib.VESDE, sde_lib.subVPSDE)):
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+
+    def update_fn(self, x, t):
+        return _ald(self.sde, lambda v: self.score_fn(v, t), x, t, self.snr, self.n_steps)
 
 
-for _n in ('ald', 'conditional_ald'):
-    register_corrector(_not_yet(_n), name=_n)
+@register_corrector(name='conditional_ald')
+class conditionalAnnealedLangevinDynamics(Corrector):
+    """Not registered by the reference (only the unconditional ``ald`` is); provided for the conditional loop."""
+
+    def __init__(self, sde, score_fn, snr, n_steps):
+        super().__init__(sde, score_fn, snr, n_steps)
+        if not isinstance(sde, (sde_lib.cVESDE, sde_lib.cVPSDE)):
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+
+    def update_fn(self, x, y, t):
+        return _ald(self.sde, lambda v: self.score_fn(v, y, t), x, t, self.snr, self.n_steps)

@@ -6,9 +6,8 @@ Mirrors sampling/predictors.py of the reference: ``register_predictor`` / ``get_
 ``conditional_none`` (:182-200).  ``update_fn`` keeps the reference signature
 ``(x, t) | (x, y, t) -> (x, x_mean)``; the pixel update runs in csrc/sampler.hip.
 
-Not yet provided: euler_maruyama, ancestral_sampling and their
-conditional variants - requesting them raises NotImplementedError instead of silently running
-somewhere else.
+``euler_maruyama`` (:52-76) and ``ancestral_sampling`` (:105-179) and their conditional variants run on the
+general affine update kernel (``csd_affine_noise_step``): their per-step coefficients are host scalars.
 """
 import abc
 
@@ -101,17 +100,80 @@ class conditionalNonePredictor(Predictor):
         return x, x
 
 
-def _not_yet(name):
-    class _Missing(Predictor):
-        def __init__(self, *a, **k):
-            raise NotImplementedError('predictor %r is not provided by the HIP path yet (SURVEY.md 8f)' % name)
-
-        def update_fn(self, x, t):  # pragma: no cover
-            raise NotImplementedError
-
-    _Missing.__name__ = 'Missing_' + name
-    return _Missing
+def _linear_sde_coeffs(sde, t):
+    """(phi, g) with forward drift f(x, t) = phi*x and diffusion g at the (uniform) time t: every SDE of
+    sde_lib has a drift that is linear in x, so one evaluation at x = 1 on the host gives phi."""
+    t1 = t.detach().cpu().flatten()[:1].to(torch.float32)
+    drift, diffusion = sde.sde(torch.ones(1, 1, 1, 1), t1)
+    return float(drift.flatten()[0]), float(diffusion.flatten()[0])
 
 
-for _n in ('euler_maruyama', 'conditional_euler_maruyama', 'ancestral_sampling', 'conditional_ancestral_sampling'):
-    register_predictor(_not_yet(_n), name=_n)
+def _euler_maruyama(sde, score, x, t, probability_flow):
+    """x_mean = x + (f - g^2*score*(1/2 if ode else 1))*dt, x = x_mean + g*sqrt(-dt)*z with dt = -1/N
+    (sampling/predictors.py:52-76; reverse drift sde_lib.py:123-133)."""
+    _uniform_scalar(t, 't')
+    phi, g = _linear_sde_coeffs(sde, t)
+    dt = -1.0 / sde.N
+    kappa = 0.5 if probability_flow else 1.0
+    z = torch.randn_like(x)
+    return ops.affine_noise_step(x.clone(), score, z, 1.0 + phi * dt, -kappa * g * g * dt,
+                                 0.0 if probability_flow else g * (-dt) ** 0.5)
+
+
+@register_predictor(name='euler_maruyama')
+class EulerMaruyamaPredictor(Predictor):
+    def update_fn(self, x, t):
+        return _euler_maruyama(self.sde, self.score_fn(x, t), x, t, self.probability_flow)
+
+
+@register_predictor(name='conditional_euler_maruyama')
+class conditionalEulerMaruyamaPredictor(Predictor):
+    def update_fn(self, x, y, t):
+        return _euler_maruyama(self.sde, self.score_fn(x, y, t), x, t, self.probability_flow)
+
+
+def _ancestral(sde, score, x, t):
+    """sampling/predictors.py:114-135: VE  x_mean = x + (s_i^2 - s_{i-1}^2)*score, std = sqrt(s_{i-1}^2 (s_i^2 - s_{i-1}^2)/s_i^2);
+    VP  x_mean = (x + beta_i*score)/sqrt(1 - beta_i), std = sqrt(beta_i)."""
+    _uniform_scalar(t, 't')
+    t1 = t.detach().cpu().flatten()[:1].to(torch.float32)
+    i = int((t1 * (sde.N - 1) / sde.T).long()[0])
+    z = torch.randn_like(x)
+    if isinstance(sde, (sde_lib.VESDE, sde_lib.cVESDE)):
+        sig = sde.discrete_sigmas.to(torch.float32)
+        s2 = float(sig[i]) ** 2
+        a2 = float(sig[i - 1]) ** 2 if i > 0 else 0.0
+        return ops.affine_noise_step(x.clone(), score, z, 1.0, s2 - a2, (a2 * (s2 - a2) / s2) ** 0.5)
+    beta = float(sde.discrete_betas.to(torch.float32)[i])
+    r = (1.0 - beta) ** 0.5
+    return ops.affine_noise_step(x.clone(), score, z, 1.0 / r, beta / r, beta ** 0.5)
+
+
+@register_predictor(name='ancestral_sampling')
+class AncestralSamplingPredictor(Predictor):
+    """Ancestral sampling; VE / VP SDEs only, as in the reference (sampling/predictors.py:105-143)."""
+
+    def __init__(self, sde, score_fn, probability_flow=False):
+        super().__init__(sde, score_fn, probability_flow)
+        if not isinstance(sde, (sde_lib.VPSDE, sde_lib.VESDE)):
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+        assert not probability_flow, "Probability flow not supported by ancestral sampling"
+
+    def update_fn(self, x, t):
+        return _ancestral(self.sde, self.score_fn(x, t), x, t)
+
+
+@register_predictor(name='conditional_ancestral_sampling')
+class conditionalAncestralSamplingPredictor(Predictor):
+    """The reference registers this class with a two-argument ``update_fn(self, x, t)`` that calls the
+    three-argument helpers (sampling/predictors.py:175-179), so it cannot run inside the conditional loop
+    there.  Here ``update_fn(x, y, t)`` has the signature the conditional sampler uses."""
+
+    def __init__(self, sde, score_fn, probability_flow=False):
+        super().__init__(sde, score_fn, probability_flow)
+        if not isinstance(sde, (sde_lib.cVESDE, sde_lib.cVPSDE)):
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+        assert not probability_flow, "Probability flow not supported by ancestral sampling"
+
+    def update_fn(self, x, y, t):
+        return _ancestral(self.sde, self.score_fn(x, y, t), x, t)

@@ -163,6 +163,11 @@ int csd_langevin_step(float* x, float* x_mean, const float* net, const float* z,
                       float snr, int B, int64_t per_sample, void* scratch, void* stream);
 int csd_reverse_diffusion_step(float* x, float* x_mean, const float* net, const float* z, float std,
                                float G, int B, int64_t per_sample, void* stream);
+/* General one-step update  x_mean = p*x + a*score,  x = x_mean + c*z  (n elements, scalars per call): the
+ * Euler-Maruyama and ancestral-sampling predictors (sampling/predictors.py:52-76,105-179) and the annealed
+ * Langevin corrector (sampling/correctors.py:111-142); `score` is the score itself (already divided by std). */
+int csd_affine_noise_step(float* x, float* x_mean, const float* score, const float* z, float p, float a,
+                          float c, int64_t n, void* stream);
 /* standard-normal fill (Philox4x32-10 + Box-Muller); counter-based: (seed, stream_id) */
 int csd_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
 /* out[b,:] = in[b,:] * scale[b]  or / scale[b] (divide_by_sigmas, models/utils.py:50-74) */

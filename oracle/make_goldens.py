@@ -178,12 +178,70 @@ def gen_sde_tables(ref):
     print('sde_tables', {k: v.shape for k, v in out.items()})
 
 
+def step_score(x, t, y=None):
+    """A closed-form stand-in for the score network (the update rules are what is being pinned): smooth in x,
+    depends on t (and y), same formula in tests/test_gpu_steps.py."""
+    tt = t.reshape(-1, 1, 1, 1)
+    s = -(x - 0.25) / (1.0 + tt) + 0.1 * torch.sin(3.0 * x)
+    if y is not None:
+        s = s + 0.05 * y
+    return s
+
+
+# (ald on subVPSDE is not pinned: the reference class has no `alphas` and raises AttributeError)
+# (probability-flow Euler-Maruyama is not pinned: the reference indexes a Python float there and raises TypeError)
+STEP_CASES = [
+    # name, sde class, sde kwargs, kind, registry name, probability_flow, conditional
+    ('ve_em', 'VESDE', dict(sigma_min=0.01, sigma_max=50., N=1000), 'predictor', 'euler_maruyama', False, False),
+    ('ve_anc', 'VESDE', dict(sigma_min=0.01, sigma_max=50., N=1000), 'predictor', 'ancestral_sampling', False, False),
+    ('vp_em', 'VPSDE', dict(beta_min=0.1, beta_max=20., N=1000), 'predictor', 'euler_maruyama', False, False),
+    ('vp_anc', 'VPSDE', dict(beta_min=0.1, beta_max=20., N=1000), 'predictor', 'ancestral_sampling', False, False),
+    ('subvp_em', 'subVPSDE', dict(beta_min=0.1, beta_max=20., N=1000), 'predictor', 'euler_maruyama', False, False),
+    ('cve_em', 'cVESDE', dict(sigma_min=0.01, sigma_max=50., N=1000), 'predictor', 'conditional_euler_maruyama', False, True),
+    ('ve_ald', 'VESDE', dict(sigma_min=0.01, sigma_max=50., N=1000), 'corrector', 'ald', False, False),
+    ('vp_ald', 'VPSDE', dict(beta_min=0.1, beta_max=20., N=1000), 'corrector', 'ald', False, False),
+]
+STEP_TIMES = [0.73, 0.31, 1e-4]     # (the last one is timestep 0: adjacent sigma = 0 in ancestral sampling)
+
+
+def gen_steps(ref):
+    """One update of every predictor / corrector the first round did not cover, run by the reference classes
+    themselves with a noise tape -> tests/golden/steps.npz (inputs by seed, reference outputs)."""
+    sl, pr, co = ref['sde_lib'], ref['sampling.predictors'], ref['sampling.correctors']
+    g = torch.Generator().manual_seed(77)
+    B, C, S = 3, 3, 8
+    x0 = torch.randn(B, C, S, S, generator=g) * 2.0
+    y0 = torch.rand(B, C, S, S, generator=g)
+    z0 = torch.randn(2, B, C, S, S, generator=g)
+    out = {'x0': x0.numpy(), 'y0': y0.numpy(), 'z0': z0.numpy(), 'times': np.array(STEP_TIMES, np.float32)}
+    for name, scls, skw, kind, reg, pf, cond in STEP_CASES:
+        sde = getattr(sl, scls)(**skw)
+        for ti, tv in enumerate(STEP_TIMES):
+            t = torch.full((B,), tv)
+            if cond:
+                score_fn = lambda x, y, t: step_score(x, t, y)
+            else:
+                score_fn = lambda x, t: step_score(x, t)
+            with ref_import.TapeRandn([z0[0], z0[1]]):
+                if kind == 'predictor':
+                    obj = pr.get_predictor(reg)(sde, score_fn, pf)
+                    x, xm = obj.update_fn(x0.clone(), y0, t) if cond else obj.update_fn(x0.clone(), t)
+                else:
+                    obj = co.get_corrector(reg)(sde, score_fn, 0.16, 2)
+                    x, xm = obj.update_fn(x0.clone(), t)
+            out['%s_t%d_x' % (name, ti)] = x.numpy()
+            out['%s_t%d_xmean' % (name, ti)] = xm.numpy()
+    np.savez_compressed(os.path.join(OUT, 'steps.npz'), **out)
+    print('steps.npz: %d arrays' % len(out))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = ref_import.modules()
     gen_sde_tables(ref)
     gen_modules(ref)
+    gen_steps(ref)
     for case in cases.CASES:
         gen_network_case(ref, case)
 

@@ -1,0 +1,109 @@
+"""The predictors / correctors beyond the fused PC pair (Euler-Maruyama, ancestral sampling, annealed Langevin
+dynamics: reference sampling/predictors.py:52-76,105-179, correctors.py:111-142) on the HIP affine update
+kernel, against outputs of the reference classes themselves (tests/golden/steps.npz, made by
+oracle/make_goldens.py:gen_steps with a noise tape and a closed-form score)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'steps.npz')
+
+
+def step_score(x, t, y=None):     # same closed form as oracle/make_goldens.py:step_score
+    tt = t.reshape(-1, 1, 1, 1)
+    s = -(x - 0.25) / (1.0 + tt) + 0.1 * torch.sin(3.0 * x)
+    if y is not None:
+        s = s + 0.05 * y
+    return s
+
+
+CASES = [
+    ('ve_em', 'VESDE', dict(sigma_min=0.01, sigma_max=50., N=1000), 'predictor', 'euler_maruyama', False),
+    ('ve_anc', 'VESDE', dict(sigma_min=0.01, sigma_max=50., N=1000), 'predictor', 'ancestral_sampling', False),
+    ('vp_em', 'VPSDE', dict(beta_min=0.1, beta_max=20., N=1000), 'predictor', 'euler_maruyama', False),
+    ('vp_anc', 'VPSDE', dict(beta_min=0.1, beta_max=20., N=1000), 'predictor', 'ancestral_sampling', False),
+    ('subvp_em', 'subVPSDE', dict(beta_min=0.1, beta_max=20., N=1000), 'predictor', 'euler_maruyama', False),
+    ('cve_em', 'cVESDE', dict(sigma_min=0.01, sigma_max=50., N=1000), 'predictor', 'conditional_euler_maruyama', True),
+    ('ve_ald', 'VESDE', dict(sigma_min=0.01, sigma_max=50., N=1000), 'corrector', 'ald', False),
+    ('vp_ald', 'VPSDE', dict(beta_min=0.1, beta_max=20., N=1000), 'corrector', 'ald', False),
+]
+
+
+class _Tape:
+    def __init__(self, zs):
+        self.zs, self.i = zs, 0
+
+    def __enter__(self):
+        self.orig = torch.randn_like
+
+        def nxt(x, **k):
+            z = self.zs[self.i].to(x.device)
+            self.i += 1
+            return z.clone()
+
+        torch.randn_like = nxt
+        return self
+
+    def __exit__(self, *a):
+        torch.randn_like = self.orig
+
+
+@pytest.mark.parametrize('name,scls,skw,kind,reg,cond', CASES)
+def test_step_vs_reference(name, scls, skw, kind, reg, cond):
+    from conditional_score_diffusion_amd import sde_lib
+    from conditional_score_diffusion_amd.sampling import correctors, predictors
+    g = np.load(GOLD)
+    dev = torch.device('cuda:0')
+    x0, y0 = torch.from_numpy(g['x0']).to(dev), torch.from_numpy(g['y0']).to(dev)
+    z0 = torch.from_numpy(g['z0'])
+    sde = getattr(sde_lib, scls)(**skw)
+    for ti, tv in enumerate(g['times']):
+        t = torch.full((x0.shape[0],), float(tv), device=dev)
+        score_fn = (lambda x, y, t: step_score(x, t, y)) if cond else (lambda x, t: step_score(x, t))
+        with _Tape([z0[0], z0[1]]):
+            if kind == 'predictor':
+                obj = predictors.get_predictor(reg)(sde, score_fn, False)
+                x, xm = obj.update_fn(x0.clone(), y0, t) if cond else obj.update_fn(x0.clone(), t)
+            else:
+                obj = correctors.get_corrector(reg)(sde, score_fn, 0.16, 2)
+                x, xm = obj.update_fn(x0.clone(), t)
+        for got, key in ((x, 'x'), (xm, 'xmean')):
+            ref = torch.from_numpy(g['%s_t%d_%s' % (name, ti, key)])
+            err = (got.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+            assert err < 5e-6, (name, ti, key, err)      # fp32 elementwise; coefficients rounded once on the host
+
+
+def test_probability_flow_euler_is_deterministic():
+    """The reference raises TypeError here (it indexes a Python float); the HIP path implements the ODE step:
+    x = x_mean = x - (f - g^2/2 * score) / N, no noise."""
+    from conditional_score_diffusion_amd import sde_lib
+    from conditional_score_diffusion_amd.sampling import predictors
+    dev = torch.device('cuda:0')
+    sde = sde_lib.VESDE(sigma_min=0.01, sigma_max=50., N=1000)
+    x0 = torch.randn(2, 3, 8, 8, device=dev)
+    t = torch.full((2,), 0.5, device=dev)
+    obj = predictors.get_predictor('euler_maruyama')(sde, lambda x, t: step_score(x, t), True)
+    x, xm = obj.update_fn(x0.clone(), t)
+    g = float(sde.sde(torch.ones(1, 1, 1, 1), torch.tensor([0.5]))[1][0])
+    ref = x0 + 0.5 * g * g / 1000.0 * step_score(x0, t)
+    assert torch.equal(x, xm)
+    assert (x - ref).abs().max().item() / ref.abs().max().item() < 5e-6
+
+
+def test_generic_loop_with_other_pair_runs():
+    """get_pc_sampler with a pair other than (reverse_diffusion, langevin) takes the per-step update_fn path."""
+    from conditional_score_diffusion_amd import sde_lib
+    from conditional_score_diffusion_amd.sampling import correctors, predictors
+    dev = torch.device('cuda:0')
+    sde = sde_lib.VESDE(sigma_min=0.01, sigma_max=5., N=20)
+    x = torch.randn(2, 3, 8, 8, device=dev) * 5
+    pred = predictors.get_predictor('ancestral_sampling')(sde, lambda x, t: step_score(x, t), False)
+    corr = correctors.get_corrector('ald')(sde, lambda x, t: step_score(x, t), 0.1, 1)
+    for tv in np.linspace(1.0, 1e-3, 20):
+        t = torch.full((2,), float(tv), device=dev)
+        x, xm = corr.update_fn(x, t)
+        x, xm = pred.update_fn(x, t)
+    assert torch.isfinite(xm).all()

@@ -80,8 +80,15 @@ def test_registries_behave_like_the_reference():
     assert correctors.get_corrector('conditional_langevin').__name__ == 'conditionalLangevinCorrector'
     with pytest.raises(ValueError):
         predictors.register_predictor(type('P', (), {}), name='reverse_diffusion')
-    with pytest.raises(NotImplementedError):
-        predictors.get_predictor('euler_maruyama')(None, None)
+    # every name the reference registers resolves (sampling/predictors.py, correctors.py)
+    for n in ('euler_maruyama', 'conditional_euler_maruyama', 'reverse_diffusion', 'conditional_reverse_diffusion',
+              'ancestral_sampling', 'conditional_ancestral_sampling', 'none', 'conditional_none'):
+        assert predictors.get_predictor(n) is not None
+    for n in ('langevin', 'conditional_langevin', 'ald', 'none', 'conditional_none'):
+        assert correctors.get_corrector(n) is not None
+    from conditional_score_diffusion_amd import sde_lib
+    with pytest.raises(NotImplementedError):       # same guard as the reference (predictors.py:110-111)
+        predictors.get_predictor('ancestral_sampling')(sde_lib.subVPSDE(0.1, 20., 10), lambda x, t: x)
 
 
 def test_sde_lib_matches_reference_tables(golden_dir):
