@@ -79,6 +79,10 @@ SIGNATURES = {
     'csd_langevin_step': (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i64, _vp, _vp]),
     'csd_reverse_diffusion_step': (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i64, _vp]),
     'csd_affine_noise_step': (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _i64, _vp]),
+    'csd_linear': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'csd_fourier_embedding': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'csd_axpby': (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
+    'csd_bias_add_nchw': (_i, [_vp, _vp, _vp, _i, _i, _i64, _i, _i, _vp]),
     'csd_randn': (_i, [_vp, _i64, _u64, _u64, _vp]),
     'csd_scale_rows': (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp]),
     'csd_groupnorm_scratch_bytes': (_sz, [_i, _i, _i, _i]),

@@ -1,6 +1,8 @@
 // elementwise.hip - the small HBM-/latency-bound kernels around the contraction kernels:
 // time embedding + dense layers, boundary layout changes (NCHW <-> NHWC), and the reference's
 // two native ops (upfirdn2d, fused_bias_act) re-written for gfx950.
+#include <algorithm>
+
 #include "common.h"
 
 namespace csd {
@@ -296,6 +298,62 @@ __global__ void fused_bias_act_kernel(const float* __restrict__ x, const float* 
     }
     out[i] = y;
   }
+}
+
+// ---- small per-op kernels for graphs orchestrated above the C ABI (NCSN++: models/ncsnpp.py of the reference) ----
+// Gaussian Fourier features (models/layerspp.py:32-41): out[b] = [sin(a_bk), cos(a_bk)], a = ((t*W)*2)*pi evaluated
+// in fp32 in that order (the argument reaches ~1e3, so its fp32 rounding is part of the result), sin/cos in fp64
+__global__ void fourier_embedding_kernel(const float* __restrict__ t, const float* __restrict__ W, float* __restrict__ out,
+                                         int B, int E) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * E) return;
+  const int b = i / E, k = i - b * E;
+  float a = t[b] * W[k];
+  a = a * 2.0f;
+  a = a * 3.14159265358979323846f;
+  out[(size_t)b * 2 * E + k] = (float)sin((double)a);
+  out[(size_t)b * 2 * E + E + k] = (float)cos((double)a);
+}
+int fourier_embedding_launch(const float* t, const float* W, float* out, int B, int E, hipStream_t s) {
+  hipLaunchKernelGGL(fourier_embedding_kernel, dim3(cdiv(B * E, 256)), dim3(256), 0, s, t, W, out, B, E);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+// out = (alpha*a + beta*b + gamma) * post   (b may be null): residual adds, (x + h)/sqrt(2), Combine 'sum', 2x - 1
+__global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, float alpha,
+                             float beta, float gamma, float post, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v = alpha * a[i];
+    if (b) v += beta * b[i];
+    out[i] = (v + gamma) * post;
+  }
+}
+int axpby_launch(const float* a, const float* b, float* out, float alpha, float beta, float gamma, float post, size_t n,
+                 hipStream_t s) {
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)std::min<size_t>(cdiv64(n, 256), 65536)), dim3(256), 0, s, a, b, out, alpha,
+                     beta, gamma, post, n);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+// out[b,c,:] = act(x[b,c,:] + bias[b*bias_stride + c])   (h += Dense_0(act(temb))[:, :, None, None])
+__global__ void bias_add_nchw_kernel(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ out,
+                                     int C, size_t inner, int bias_stride, int act, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t bc = i / inner;
+    const size_t b = bc / C;
+    const int c = (int)(bc - b * C);
+    out[i] = ew_act(x[i] + bias[b * bias_stride + c], act);
+  }
+}
+int bias_add_nchw_launch(const float* x, const float* bias, float* out, int B, int C, size_t inner, int bias_stride, int act,
+                         hipStream_t s) {
+  const size_t n = (size_t)B * C * inner;
+  hipLaunchKernelGGL(bias_add_nchw_kernel, dim3((unsigned)std::min<size_t>(cdiv64(n, 256), 65536)), dim3(256), 0, s, x, bias,
+                     out, C, inner, bias_stride, act, n);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
 }
 
 }  // namespace csd

@@ -147,3 +147,27 @@ extern "C" int csd_attention(const float* q, const float* k, const float* v, flo
   if ((rc = attention_launch(qkv, 3 * C, oh, B, L, C, s))) return rc;
   return nhwc_to_nchw_launch(oh, out, B, C, L, C, s);
 }
+
+// ---- small operators for graphs orchestrated above the C ABI (the NCSN++ adapter) ---------------------------
+extern "C" int csd_linear(const float* in, const float* weight, const float* bias, float* out, int B, int K, int N,
+                          int act_in, void* stream) {
+  CSD_REQUIRE(in && weight && out && B > 0 && K > 0 && N > 0, "linear: bad arguments");
+  return linear_launch(in, weight, bias, out, B, K, N, act_in, (hipStream_t)stream);
+}
+
+extern "C" int csd_fourier_embedding(const float* t, const float* W, float* out, int B, int E, void* stream) {
+  CSD_REQUIRE(t && W && out && B > 0 && E > 0, "fourier_embedding: bad arguments");
+  return fourier_embedding_launch(t, W, out, B, E, (hipStream_t)stream);
+}
+
+extern "C" int csd_axpby(const float* a, const float* b, float* out, float alpha, float beta, float gamma, float post,
+                         int64_t n, void* stream) {
+  CSD_REQUIRE(a && out && n > 0, "axpby: bad arguments");
+  return axpby_launch(a, b, out, alpha, beta, gamma, post, (size_t)n, (hipStream_t)stream);
+}
+
+extern "C" int csd_bias_add_nchw(const float* x, const float* bias, float* out, int B, int C, int64_t inner,
+                                 int bias_stride, int act, void* stream) {
+  CSD_REQUIRE(x && bias && out && B > 0 && C > 0 && inner > 0, "bias_add_nchw: bad arguments");
+  return bias_add_nchw_launch(x, bias, out, B, C, (size_t)inner, bias_stride, act, (hipStream_t)stream);
+}

@@ -103,6 +103,54 @@ def timestep_embedding(t, dim):
     return out
 
 
+def linear(x, weight, bias=None, act_in='none'):
+    """act_in(x) @ weight.T + bias on [B, K] (nn.Linear; the reference applies the activation to the INPUT of the
+    second temb layer and of every Dense_0: models/ncsnpp.py:257-263, layerspp.py:253-255)."""
+    x, weight = _c(x, 'x'), _c(weight, 'weight')
+    if bias is not None:
+        bias = _c(bias, 'bias')
+    B, K = x.shape
+    N = weight.shape[0]
+    out = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    check(lib().csd_linear(ptr(x), ptr(weight), ptr(bias), ptr(out), B, K, N, _lib.ACT_IDS[act_in],
+                           current_stream(x.device)), 'linear')
+    return out
+
+
+def fourier_embedding(t, W):
+    """GaussianFourierProjection (models/layerspp.py:32-41): [sin(2 pi W t), cos(2 pi W t)]."""
+    t, W = _c(t, 't'), _c(W, 'W')
+    out = torch.empty(t.shape[0], 2 * W.shape[0], dtype=torch.float32, device=t.device)
+    check(lib().csd_fourier_embedding(ptr(t), ptr(W), ptr(out), t.shape[0], W.shape[0], current_stream(t.device)),
+          'fourier_embedding')
+    return out
+
+
+def axpby(a, b=None, alpha=1.0, beta=1.0, gamma=0.0, post=1.0):
+    """(alpha*a + beta*b + gamma) * post, elementwise (b optional)."""
+    a = _c(a, 'a')
+    if b is not None:
+        b = _c(b, 'b')
+        if b.shape != a.shape:
+            raise RuntimeError('axpby: shapes %s and %s differ' % (tuple(a.shape), tuple(b.shape)))
+    out = torch.empty_like(a)
+    check(lib().csd_axpby(ptr(a), ptr(b), ptr(out), float(alpha), float(beta), float(gamma), float(post), a.numel(),
+                          current_stream(a.device)), 'axpby')
+    return out
+
+
+def bias_add_nchw(x, bias, act='none'):
+    """act(x + bias[:, :, None, None]) with bias [B, C] (or [C])."""
+    x, bias = _c(x, 'x'), _c(bias, 'bias')
+    B, C = x.shape[0], x.shape[1]
+    inner = x.numel() // (B * C)
+    stride = C if bias.dim() == 2 else 0
+    out = torch.empty_like(x)
+    check(lib().csd_bias_add_nchw(ptr(x), ptr(bias), ptr(out), B, C, inner, stride, _lib.ACT_IDS[act],
+                                  current_stream(x.device)), 'bias_add_nchw')
+    return out
+
+
 def randn(shape, seed, stream_id, device):
     """Counter-based standard normals (Philox4x32-10): same (seed, stream_id) -> same tensor."""
     out = torch.empty(*shape, dtype=torch.float32, device=device)

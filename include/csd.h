@@ -213,6 +213,23 @@ int csd_nearest_up2(const float* x, float* out, int N, int C, int H, int W, void
 /* sinusoidal timestep embedding (models/layers.py:524-538): out [B, dim] */
 int csd_timestep_embedding(const float* t, float* out, int B, int dim, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Small operators for graphs orchestrated above the C ABI (the NCSN++ adapter, models/ncsnpp.py:238-388):
+ * ---------------------------------------------------------------------------------------- */
+/* nn.Linear on the activated input: out[b] = act_in(in[b]) . weight^T + bias; weight [N, K] (temb MLP
+ * models/ncsnpp.py:96-102,257-263; Dense_0 models/layerspp.py:253-255) */
+int csd_linear(const float* in, const float* weight, const float* bias, float* out, int B, int K, int N,
+               int act_in, void* stream);
+/* GaussianFourierProjection (models/layerspp.py:32-41): out [B, 2E] = [sin(2 pi W t), cos(2 pi W t)] */
+int csd_fourier_embedding(const float* t, const float* W, float* out, int B, int E, void* stream);
+/* out = (alpha*a + beta*b + gamma) * post, b may be NULL: x + h, (x + h)/sqrt(2) (layerspp.py:271-274),
+ * Combine 'sum' (:56-57), 2x - 1 (ncsnpp.py:266-268), pyramid sums (:352) */
+int csd_axpby(const float* a, const float* b, float* out, float alpha, float beta, float gamma, float post,
+              int64_t n, void* stream);
+/* out[b,c,:] = act(x[b,c,:] + bias[b*bias_stride + c]): h += Dense_0(act(temb))[:, :, None, None] */
+int csd_bias_add_nchw(const float* x, const float* bias, float* out, int B, int C, int64_t inner,
+                      int bias_stride, int act, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,61 @@ CASES = {
 }
 
 
+def make_ncsnpp_config(name='ncsnpp', nf=16, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(8,), image_size=16,
+                       channels=3, embedding_type='fourier', progressive='output_skip', progressive_input='input_skip',
+                       skip_rescale=True, fir_kernel=(1, 3, 3, 1), init_scale=0., centered=False):
+    """A reference-style NCSN++ config with the keys models/ncsnpp.py:44-236 reads
+    (cf. configs/ve/ffhq_256_ncsnpp_continuous.py, configs/default_lsun_configs.py)."""
+    c = ConfigDict()
+    c.training = ConfigDict(continuous=True, sde='vesde', likelihood_weighting=False, reduce_mean=False)
+    c.sampling = ConfigDict(method='pc', predictor='reverse_diffusion', corrector='langevin', n_steps_each=1,
+                            noise_removal=True, probability_flow=False, snr=0.075)
+    c.data = ConfigDict(image_size=image_size, effective_image_size=image_size, centered=centered, num_channels=channels)
+    c.model = ConfigDict(name=name, nf=nf, ch_mult=tuple(ch_mult), num_res_blocks=num_res_blocks,
+                         attn_resolutions=tuple(attn_resolutions), dropout=0.1, resamp_with_conv=True, conditional=True,
+                         nonlinearity='swish', num_scales=1000, sigma_min=0.01, sigma_max=50., fir=True,
+                         fir_kernel=list(fir_kernel), skip_rescale=skip_rescale, resblock_type='biggan',
+                         progressive=progressive, progressive_input=progressive_input, progressive_combine='sum',
+                         attention_type='ddpm', init_scale=init_scale, embedding_type=embedding_type, fourier_scale=16,
+                         conv_size=3, scale_by_sigma=True)
+    return c
+
+
+NCSNPP_CASES = {
+    # name: (config kwargs, batch)
+    'ncsnpp_fourier_skip': (dict(), 2),
+    'ncsnpp_positional_plain': (dict(nf=32, ch_mult=(1, 1, 2), attn_resolutions=(4,), embedding_type='positional',
+                                     progressive='none', progressive_input='none', skip_rescale=False, centered=True), 2),
+    'ncsnpp_paired_skip': (dict(name='ncsnpp_paired', channels=6, nf=32, ch_mult=(1, 2), attn_resolutions=(16,),
+                                num_res_blocks=2), 2),
+}
+
+
+def ncsnpp_case(case):
+    kw, B = NCSNPP_CASES[case]
+    cfg = make_ncsnpp_config(**kw)
+    rs = np.random.RandomState(321)
+    S, C = cfg.data.image_size, cfg.data.num_channels
+    x = torch.from_numpy(rs.uniform(0, 1, size=(B, C, S, S)).astype(np.float32) * 3.0 - 1.0)
+    if cfg.model.embedding_type == 'fourier':
+        labels = torch.from_numpy(np.log(np.array([0.02, 7.5][:B], np.float32)))     # log sigma (models/utils.py:246-253)
+    else:
+        labels = torch.from_numpy(np.array([12.25, 871.0][:B], np.float32))          # t * (N - 1)
+    return cfg, B, x, labels
+
+
+def ncsnpp_params(shapes, seed, fourier_scale=16.0):
+    """score_oracle.synth_params, except that a Gaussian-Fourier ``W`` keeps its real scale (the sin/cos arguments then
+    reach several hundred, which is what the embedding kernel has to get right)."""
+    import score_oracle as so
+    p = so.synth_params(shapes, seed)
+    for k in shapes:
+        if k.endswith('.W') and len(shapes[k]) == 1:
+            rs = np.random.RandomState(seed + 99)
+            p[k] = torch.from_numpy((rs.standard_normal(shapes[k]) * fourier_scale).astype(np.float32))
+    return p
+
+
 def case_config(case):
     kw, B = CASES[case]
     return make_config(**kw), B

@@ -235,6 +235,29 @@ def gen_steps(ref):
     print('steps.npz: %d arrays' % len(out))
 
 
+def gen_ncsnpp(ref):
+    """Reference NCSN++ forward (models/ncsnpp.py) on the seeded cases of cases.NCSNPP_CASES -> tests/golden/ncsnpp.npz:
+    state_dict key order + shapes (as a string table) and the network output."""
+    out = {}
+    for case in cases.NCSNPP_CASES:
+        cfg, B, x, labels = cases.ncsnpp_case(case)
+        torch.manual_seed(0)
+        model = ref['models.utils'].create_model(cfg)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict(cases.ncsnpp_params(shapes, 5))
+        model.eval()
+        with torch.no_grad():
+            if cfg.model.name == 'ncsnpp_paired':
+                r = model({'x': x[:, :3], 'y': x[:, 3:]}, labels)
+                y = torch.cat([r['x'], r['y']], dim=1)
+            else:
+                y = model(x, labels)
+        out[case + '_out'] = y.numpy()
+        out[case + '_keys'] = np.array(['%s|%s' % (k, ','.join(map(str, shapes[k]))) for k in model.state_dict()])
+        print(case, tuple(y.shape), float(y.abs().max()), len(shapes), 'tensors')
+    np.savez_compressed(os.path.join(OUT, 'ncsnpp.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -242,6 +265,7 @@ def main():
     gen_sde_tables(ref)
     gen_modules(ref)
     gen_steps(ref)
+    gen_ncsnpp(ref)
     for case in cases.CASES:
         gen_network_case(ref, case)
 
