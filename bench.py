@@ -83,6 +83,7 @@ def main():
     ap.add_argument('--precision', default=os.environ.get('CSD_PRECISION', 'fp16x3'), choices=['fp32', 'fp16x3', 'fp16'],
                     help='arithmetic of the 3x3 contractions (all modes pass the 1e-3 parity tests)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-alt', action='store_true', help='skip the short side measurements of the other precision modes')
     ap.add_argument('--cpu-steps', type=int, default=4)
     args = ap.parse_args()
 
@@ -192,7 +193,17 @@ def main():
             roof = {'bound': 'hbm', 'achieved': dom_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dom_gbs / HBM_PEAK_GBS}
         else:
             roof = {'bound': 'mfma', 'achieved': dom_tf, 'peak': dom_peak, 'unit': 'TFLOP/s', 'frac': dom_tf / dom_peak}
-        roof.update({'kernel': dom_kernel, 'traffic': None, 'peak_note': dom_note,
+        # HBM traffic of the same kernel class from PMC counters (a separate rocprofv3 pass cannot run inside this
+        # process): the committed summary of tools/pmc_hbm.sh for this mode, bytes per launch like `achieved`
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_hbm_traffic_%s.json' % args.precision)
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic = tj['conv3x3_class']['hbm_bytes_per_launch']
+            traffic_src = 'profiles/' + os.path.basename(tpath) + ' (' + tj['source'] + ')'
+        roof.update({'kernel': dom_kernel, 'traffic': traffic, 'traffic_unit': 'bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)',
+                     'traffic_source': traffic_src,
+                     'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1), 'peak_note': dom_note,
                      'arithmetic_intensity_flop_per_byte': dom_ai, 'ridge_flop_per_byte': ridge,
                      'achieved_TFLOPs': dom_tf, 'achieved_GBs': dom_gbs,
                      'launches': dom['launches'], 'avg_launch_ms': dom['ms'] / max(dom['launches'], 1),
@@ -227,6 +238,23 @@ def main():
             res['cpu_baseline'] = cpu_baseline(cfg, steps=args.cpu_steps)
         else:
             res['cpu_baseline'] = None
+        if world == 1 and not args.no_alt:
+            # the other two arithmetic modes, measured the same way in short side runs (reported, not the headline)
+            import subprocess
+            alt = {}
+            for mode in ('fp32', 'fp16x3', 'fp16'):
+                if mode == args.precision:
+                    continue
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--precision', mode, '--steps', '10',
+                                        '--warmup', '2', '--no-cpu-baseline', '--no-alt', '--batch', str(B)],
+                                       capture_output=True, text=True, timeout=600)
+                    j = json.loads(r.stdout.strip().splitlines()[-1])
+                    alt[mode] = {'value': j['value'], 'unit': j['unit'], 'ms_per_step': j['ms_per_step'], 'dtype': j['dtype'],
+                                 'hbm_roofline_frac': j['hbm_roofline']['frac'], 'steps': 10}
+                except Exception as e:      # a side measurement must never break the bench line
+                    alt[mode] = {'error': str(e)[:200]}
+            res['other_precision_modes'] = alt
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()
