@@ -83,6 +83,7 @@ def main():
     ap.add_argument('--precision', default=os.environ.get('CSD_PRECISION', 'fp16x3'), choices=['fp32', 'fp16x3', 'fp16'],
                     help='arithmetic of the 3x3 contractions (all modes pass the 1e-3 parity tests)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true', help='tuning aid: time the loop without the in-library event profiler')
     ap.add_argument('--no-alt', action='store_true', help='skip the short side measurements of the other precision modes')
     ap.add_argument('--cpu-steps', type=int, default=4)
     args = ap.parse_args()
@@ -153,7 +154,13 @@ def main():
     if W > 0:
         run_steps(0, W, 1000 + rank)
     barrier()
-    _lib.profile_start()
+    if not args.no_profile:
+        # events around the dominant kernel class only, on every 8th step of the timed region: bracketing all ~1000
+        # launches of every step costs ~5 ms of stream time per step (measured: the event records serialise launches),
+        # which would be charged to `value`; the full per-class breakdown comes from a second, untimed region below
+        PROF_STRIDE = 8
+        _lib.profile_select(['conv3x3'], PROF_STRIDE)
+        _lib.profile_start()
     t0 = time.perf_counter()
     run_steps(W, K, 2000 + rank)
     if world > 1:   # the one collective of the sampling path: gather the finished samples
@@ -162,6 +169,20 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof = _lib.profile_stop()
+    # untimed second region with every launch class bracketed: the per-class milliseconds (they include the event overhead)
+    prof_all, prof_all_ms = prof, None
+    if not args.no_profile:
+        n2 = max(1, min(K, 5))
+        _lib.profile_select(None, 1)
+        barrier()
+        _lib.profile_start()
+        t1 = time.perf_counter()
+        run_steps(W + K, n2, 3000 + rank)
+        barrier()
+        prof_all_ms = (time.perf_counter() - t1) / n2 * 1e3
+        prof_all = _lib.profile_stop()
+        prof_all = {k: dict(v, ms=v['ms'] * K / n2, launches=v['launches'] * K // n2, flops=v['flops'] * K / n2,
+                            bytes=v['bytes'] * K / n2) for k, v in prof_all.items()}
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -175,7 +196,7 @@ def main():
         value = total_images / (1000.0 * dt / K)
         dom = prof['conv3x3']
         dom_tf = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 else 0.0
-        kernel_ms = sum(v['ms'] for v in prof.values())
+        kernel_ms = sum(v['ms'] for v in prof_all.values())
         if args.precision == 'fp32':
             dom_kernel, dom_peak = 'conv_f32_kernel (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)', F32_MFMA_PEAK_TF
             dom_note = 'fp32 MFMA dense peak'
@@ -207,7 +228,8 @@ def main():
                      'arithmetic_intensity_flop_per_byte': dom_ai, 'ridge_flop_per_byte': ridge,
                      'achieved_TFLOPs': dom_tf, 'achieved_GBs': dom_gbs,
                      'launches': dom['launches'], 'avg_launch_ms': dom['ms'] / max(dom['launches'], 1),
-                     'share_of_kernel_time': dom['ms'] / max(kernel_ms, 1e-9)})
+                     'sampling': 'events on every 8th PC step of the timed region (dominant class only)' if not args.no_profile else 'off',
+                     'share_of_kernel_time': prof_all['conv3x3']['ms'] / max(kernel_ms, 1e-9)})
         # north_star yardstick: HBM roofline of the whole sampling run
         bytes_per_img = 2000 * (ALG_BYTES_PER_IMG_NFE + ALG_WEIGHT_BYTES_PER_NFE / B)
         hbm_roof = HBM_PEAK_GBS * 1e9 / bytes_per_img                      # images/s/GPU
@@ -228,8 +250,10 @@ def main():
                              'achieved_GBs': value / world * bytes_per_img / 1e9, 'peak_GBs': HBM_PEAK_GBS},
             'flop_roofline_f32': {'images_per_sec_per_gpu': flop_roof, 'frac': value / world / flop_roof,
                                   'achieved_TFLOPs': value / world * 2000 * ALG_FLOP_PER_IMG_NFE / 1e12},
-            'kernel_classes_ms_per_step': {k: v['ms'] / K for k, v in prof.items()},
-            'kernel_time_fraction_of_wall': kernel_ms / (dt * 1e3),
+            'kernel_classes_ms_per_step': {k: v['ms'] / K for k, v in prof_all.items()},
+            'kernel_classes_note': 'second, untimed region of %d steps with every launch bracketed by events (%s ms per step '
+                                   'there; the event records themselves cost ~5 ms per step)' % (max(1, min(K, 5)), ('%.2f' % prof_all_ms) if prof_all_ms else 'n/a'),
+            'kernel_time_fraction_of_wall': kernel_ms / ((prof_all_ms or (dt / K * 1e3)) * K),
         }
         if not args.no_cpu_baseline and world == 1:
             # oneDNN conv scaling collapses past ~16-32 threads on this host (measured: 16 thr 0.12 s, 64 thr

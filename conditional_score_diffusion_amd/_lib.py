@@ -59,6 +59,7 @@ SIGNATURES = {
     'csd_version': (ctypes.c_char_p, []),
     'csd_last_error': (ctypes.c_char_p, []),
     'csd_profile_start': (_i, []),
+    'csd_profile_select': (_i, [ctypes.c_uint, _i]),
     'csd_profile_stop': (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),
                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     'csd_unet_create': (_i, [ctypes.POINTER(UNetConfig), ctypes.POINTER(_vp)]),
@@ -120,6 +121,12 @@ PROF_CLASSES = ['conv3x3', 'conv3x3_resample', 'conv1x1', 'gn_stats', 'gn_finali
 
 def profile_start():
     check(lib().csd_profile_start(), 'profile_start')
+
+
+def profile_select(classes=None, step_stride=1):
+    """Limit the profiler's events to the named launch classes (None = all) on every step_stride-th PC step."""
+    mask = 0xFFFFFFFF if classes is None else sum(1 << PROF_CLASSES.index(c) for c in classes)
+    check(lib().csd_profile_select(mask, int(step_stride)), 'profile_select')
 
 
 def profile_stop():

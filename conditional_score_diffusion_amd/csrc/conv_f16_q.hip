@@ -169,7 +169,11 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
 #pragma unroll
       for (int j = 0; j < NU; ++j) sv[j] = slot_load(j * C16Q_THREADS + tid, (stg + 1) * 32);
     }
+#ifdef CSD_Q_RING
+    constexpr int RING = CSD_Q_RING;
+#else
     constexpr int RING = 2;
+#endif
     half8 preg[RING][NS];
     auto load_frag = [&](int q) {               // q = tap * MQ + j
       const int tap_ = q / MQ, j_ = q % MQ;
@@ -177,7 +181,8 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
 #pragma unroll
       for (int pl = 0; pl < NS; ++pl) preg[q % RING][pl] = *reinterpret_cast<const half8*>(p + pl * LO);
     };
-    load_frag(0);
+#pragma unroll
+    for (int q = 0; q < RING - 1; ++q) load_frag(q);
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int bc = tap % BR, bn = (tap + BR - 1) % BR;
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
 #pragma unroll
       for (int j = 0; j < MQ; ++j) {
         const int q = tap * MQ + j;
-        if (q + 1 < TAPS * MQ) load_frag(q + 1);
+        if (q + RING - 1 < TAPS * MQ) load_frag(q + RING - 1);
         __builtin_amdgcn_sched_barrier(0);
         half8 b[NS];
         const bool v = !MASK || (((vbits[j] >> r) & 1u) && ((vbits[j] >> (3 + sx)) & 1u));

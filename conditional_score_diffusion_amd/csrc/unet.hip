@@ -35,6 +35,9 @@ const char* get_error() { return g_err; }
 struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
 struct Profiler {
   bool on = false;
+  unsigned mask = ~0u;        // launch classes that get events (bit = CSD_PROF_* id)
+  int step_stride = 1;        // csd_pc_sample: only every step_stride-th PC step is bracketed
+  bool step_on = true;
   std::vector<ProfRec> recs;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
   size_t used = 0;
@@ -45,7 +48,7 @@ struct ProfScope {
   hipStream_t s;
   hipEvent_t b = nullptr;
   ProfScope(int cls, double flops, double bytes, hipStream_t s_) : s(s_) {
-    if (!g_prof.on) return;
+    if (!g_prof.on || !g_prof.step_on || !((g_prof.mask >> cls) & 1u)) return;
     if (g_prof.used == g_prof.pool.size()) {
       hipEvent_t e0, e1;
       if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
@@ -1015,6 +1018,13 @@ struct csd_unet {
   Net net;
 };
 
+extern "C" int csd_profile_select(unsigned class_mask, int step_stride) {
+  g_prof.mask = class_mask;
+  g_prof.step_stride = step_stride > 0 ? step_stride : 1;
+  g_prof.step_on = true;
+  return CSD_OK;
+}
+
 extern "C" int csd_profile_start(void) {
   g_prof.on = true;
   g_prof.recs.clear();
@@ -1197,6 +1207,7 @@ extern "C" int csd_pc_sample(csd_unet* net, const void* packed, void* workspace,
   const float* pk = static_cast<const float*>(packed);
   float* ws = static_cast<float*>(workspace);
   for (int i = 0; i < p->n_steps; ++i) {
+    g_prof.step_on = (i % g_prof.step_stride) == 0;
     hipLaunchKernelGGL(fill_labels_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, labels, p->labels[i], B);
     CSD_LAUNCH_CHECK();
     for (int phase = 0; phase < 2; ++phase) {   // corrector, then predictor (sampling/conditional.py:208-211)
@@ -1219,6 +1230,7 @@ extern "C" int csd_pc_sample(csd_unet* net, const void* packed, void* workspace,
       CSD_CHECK_HIP(hipMemcpyAsync(p->record + (size_t)i * nx, x, nx * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
   }
+  g_prof.step_on = true;
   if (p->denoise) CSD_CHECK_HIP(hipMemcpyAsync(x, x_mean, nx * sizeof(float), hipMemcpyDeviceToDevice, s));
   return CSD_OK;
 }

@@ -64,6 +64,11 @@ enum {
   CSD_PROF_GN_APPLY = 8,          /* GroupNorm+activation+fp16 split pass (fp16 conv modes)   */
   CSD_PROF_NUM_CLASSES = 9
 };
+/* Restrict the events to the launch classes whose bit (1u << CSD_PROF_*) is set and, inside csd_pc_sample, to every
+ * step_stride-th PC step (defaults: all classes, every step).  An event pair costs ~5-15 us of stream time (the records
+ * serialise back-to-back launches): ~5 ms per PC step with everything on - a timed region that only needs the dominant
+ * kernel selects that class on a sample of the steps. */
+int csd_profile_select(unsigned class_mask, int step_stride);
 int csd_profile_start(void);
 int csd_profile_stop(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes);
 
