@@ -201,10 +201,12 @@ def main():
             dom_kernel, dom_peak = 'conv_f32_kernel (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)', F32_MFMA_PEAK_TF
             dom_note = 'fp32 MFMA dense peak'
         elif args.precision == 'fp16x3':
-            dom_kernel, dom_peak = 'conv_f16_kernel<NS=2> (3x3 stride-1 implicit GEMM, 3x v_mfma_f32_32x32x16_f16 per product)', F16_MFMA_PEAK_TF / 3
+            dom_kernel, dom_peak = ('3x3 stride-1 convolution class: conv_f16_q_kernel<NS=2> (quad-wave implicit GEMM, 3x '
+                                    'v_mfma_f32_16x16x32_f16 per product) + conv_f16_lc_kernel / conv_f16_kernel<NS=2>'), F16_MFMA_PEAK_TF / 3
             dom_note = 'fp16 MFMA dense peak (2500 TF) / 3 MFMAs per algorithmic product; achieved counts algorithmic flops'
         else:
-            dom_kernel, dom_peak = 'conv_f16_kernel<NS=1> (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x16_f16)', F16_MFMA_PEAK_TF
+            dom_kernel, dom_peak = ('3x3 stride-1 convolution class: conv_f16_lc_kernel<NS=1> (loader/consumer persistent implicit '
+                                    'GEMM, v_mfma_f32_32x32x16_f16) + conv_f16_kernel<NS=1>'), F16_MFMA_PEAK_TF
             dom_note = 'fp16 MFMA dense peak'
         # which roof bounds the dominant kernel: arithmetic intensity of its launches vs the ridge of its MFMA peak
         dom_gbs = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9 if dom['ms'] > 0 else 0.0
