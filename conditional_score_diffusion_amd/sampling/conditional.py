@@ -8,7 +8,7 @@ Fast path: for the (conditional_reverse_diffusion, conditional_langevin, VE) pai
 BASELINE config selects - the whole loop runs on the device through csd_pc_sample
 (sampling/fused.py).  Any other registered predictor/corrector pair runs the reference's
 per-step protocol (corrector then predictor, sampling/conditional.py:208-211) by calling the
-objects' ``update_fn``.  Extra keyword arguments (not in the reference): ``noise_tape`` (list of
+objects' ``update_fn``; ``use_path=True`` runs the bridge sampler of :124-178.  Extra keyword arguments (not in the reference): ``noise_tape`` (list of
 standard-normal tensors in the reference's draw order, SURVEY.md 3.1 - parity mode) and ``seed``
 (on-device Philox - throughput mode).
 """
@@ -62,10 +62,9 @@ def conditional_shared_corrector_update_fn(x, y, t, sde, model, corrector, conti
 
 def get_pc_conditional_sampler(sde, shape, predictor, corrector, snr, p_steps, c_steps=1, probability_flow=False,
                                continuous=False, denoise=True, use_path=False, eps=1e-5):
-    if use_path:
-        raise NotImplementedError('use_path sampling (sampling/conditional.py:124-178) is not provided yet '
-                                  '(SURVEY.md 8f rank 2)')
     two_sde = isinstance(sde, dict) and len(sde) == 2
+    if use_path and not two_sde:
+        raise NotImplementedError('use_path needs the two-SDE (CMDE / VS-CMDE) setting: sde = {"x": ..., "y": ...}')
     c_sde = sde['x'] if isinstance(sde, dict) else sde
     pred_fn = functools.partial(conditional_shared_predictor_update_fn, sde=sde, predictor=predictor,
                                 probability_flow=probability_flow, continuous=continuous)
@@ -84,6 +83,45 @@ def get_pc_conditional_sampler(sde, shape, predictor, corrector, snr, p_steps, c
                 y_in = y
             x, x_mean = update_fn(x=x, y=y_in, t=vec_t, model=model)
         return x, x_mean, y_in
+
+    def path_sampler(model, y, show_evolution=False):
+        """``use_path`` (sampling/conditional.py:85-100,124-178): y_t follows the bridge p(y_t | y_0, y_{t+tau})
+        (sde_lib.py:323-339) instead of being redrawn from the marginal; predictor first, then the corrector on the
+        same y_t.  The bridge coefficients are host scalars, the pixel work runs on csd_axpby."""
+        from .. import ops
+        sy = sde['y']
+
+        def scalars(fn):          # evaluate a [B]-valued sde function at one time on the host, in fp32 like the reference
+            return [float(v.flatten()[0]) for v in fn()]
+
+        with torch.no_grad():
+            x = c_sde.prior_sampling(shape).to(model.device)
+            timesteps = torch.linspace(c_sde.T, eps, p_steps)
+            tau, T0 = timesteps[0] - timesteps[1], timesteps[0]
+            std0, = scalars(lambda: (sy.marginal_prob(torch.zeros(1, 1, 1, 1), (T0 + tau).reshape(1))[1],))
+            y_tpt = ops.axpby(y, torch.randn_like(y), 1.0, std0)
+            evolution = {'x': [], 'y': []}
+            x_mean = x
+            one, zero = torch.ones(1, 1, 1, 1), torch.zeros(1, 1, 1, 1)
+            for i in range(p_steps):
+                t1 = timesteps[i].reshape(1)
+                w0, std = scalars(lambda: sy.compute_backward_kernel(one, zero, t1, tau.reshape(1)))
+                w1, = scalars(lambda: (sy.compute_backward_kernel(zero, one, t1, tau.reshape(1))[0],))
+                vec_t = torch.ones(x.shape[0], device=model.device) * float(timesteps[i])
+                y_t = ops.axpby(ops.axpby(y, y_tpt, w0, w1), torch.randn_like(y), 1.0, std)
+                x, x_mean = pred_fn(x=x, y=y_t, t=vec_t, model=model)
+                y_tpt = y_t
+                x, x_mean = corr_fn(x=x, y=y_tpt, t=vec_t, model=model)
+                if show_evolution:
+                    evolution['x'].append(x.cpu())
+                    evolution['y'].append(y_tpt.cpu())
+            out = x_mean if denoise else x
+            if show_evolution:
+                return out, {'evolution': {'x': torch.stack(evolution['x']), 'y': torch.stack(evolution['y'])}}
+            return out, {}
+
+    if use_path:
+        return path_sampler
 
     def pc_conditional_sampler(model, y, show_evolution=False, noise_tape=None, seed=0):
         if fused.fusable(model, sde, predictor, corrector, c_steps, probability_flow, continuous):

@@ -235,6 +235,30 @@ def gen_steps(ref):
     print('steps.npz: %d arrays' % len(out))
 
 
+def gen_use_path(ref):
+    """use_path conditional PC sampling (sampling/conditional.py:124-178) of the reference on the CMDE tiny case, 4 steps,
+    noise tape -> tests/golden/use_path.npz."""
+    case = 'cmde_tiny'
+    cfg, B = cases.case_config(case)
+    model, _ = build_ref_model(ref, cfg)
+    sde = sdes_for(ref, cfg)
+    y = cases.case_y(case)
+    xs, ys = (B,) + tuple(cfg.data.shape_x), (B,) + tuple(cfg.data.shape_y)
+    P = 4
+    shapes = [xs, ys] + [ys, xs, xs] * P              # prior, y_{T+tau}; per step: bridge y, predictor z, corrector z
+    tp = cases.tape(shapes, seed=7)
+    sc = ref['sampling.conditional']
+    fn = sc.get_pc_conditional_sampler(sde, xs, ref['sampling.predictors'].get_predictor('conditional_reverse_diffusion'),
+                                       ref['sampling.correctors'].get_corrector('conditional_langevin'), snr=cfg.sampling.snr,
+                                       p_steps=P, c_steps=1, continuous=True, denoise=True, use_path=True, eps=1e-5)
+    with ref_import.TapeRandn(tp) as tr:
+        out, info = fn(model, y, show_evolution=True)
+        assert tr.i == len(tp), (tr.i, len(tp))
+    np.savez_compressed(os.path.join(OUT, 'use_path.npz'), out=out.numpy(), evo_x=info['evolution']['x'].numpy(),
+                        evo_y=info['evolution']['y'].numpy())
+    print('use_path', tuple(out.shape), float(out.abs().max()))
+
+
 def gen_ncsnpp(ref):
     """Reference NCSN++ forward (models/ncsnpp.py) on the seeded cases of cases.NCSNPP_CASES -> tests/golden/ncsnpp.npz:
     state_dict key order + shapes (as a string table) and the network output."""
@@ -266,6 +290,7 @@ def main():
     gen_modules(ref)
     gen_steps(ref)
     gen_ncsnpp(ref)
+    gen_use_path(ref)
     for case in cases.CASES:
         gen_network_case(ref, case)
 

@@ -227,3 +227,33 @@ def test_errors_are_loud():
               torch.zeros(2, device=dev()))
     with pytest.raises(ValueError):
         mutils.register_model(type(model), name='ddpm')
+
+
+def test_use_path_sampler_vs_golden(golden_dir):
+    """use_path conditional sampling (reference sampling/conditional.py:85-100,124-178: y_t follows the backward
+    bridge, predictor before corrector) against the reference's own 4-step run with a noise tape
+    (tests/golden/use_path.npz, oracle/make_goldens.py:gen_use_path)."""
+    from conditional_score_diffusion_amd.sampling import conditional, correctors, predictors
+    g = np.load(os.path.join(golden_dir, 'use_path.npz'))
+    cfg, nc, p, model = build('cmde_tiny')
+    sde = sdes_for(cfg)
+    y = cases.case_y('cmde_tiny').to(dev())
+    B = y.shape[0]
+    xs, ys = (B,) + tuple(cfg.data.shape_x), (B,) + tuple(cfg.data.shape_y)
+    P = 4
+    tp = cases.tape([xs, ys] + [ys, xs, xs] * P, seed=7)
+    fn = conditional.get_pc_conditional_sampler(sde, xs, predictors.get_predictor('conditional_reverse_diffusion'),
+                                                correctors.get_corrector('conditional_langevin'), snr=cfg.sampling.snr,
+                                                p_steps=P, c_steps=1, continuous=True, denoise=True, use_path=True, eps=1e-5)
+    it = iter(tp)
+    o_randn, o_like = torch.randn, torch.randn_like
+    torch.randn = lambda *s, **k: next(it)
+    torch.randn_like = lambda t, **k: next(it).to(t.device)
+    try:
+        out, info = fn(model, y, show_evolution=True)
+    finally:
+        torch.randn, torch.randn_like = o_randn, o_like
+    smax = float(sde['x'].sigma_max)
+    assert rel(info['evolution']['y'].numpy(), g['evo_y']) < 1e-5
+    assert np.abs(info['evolution']['x'].numpy() - g['evo_x']).max() / smax < 2e-4
+    assert np.abs(out.cpu().numpy() - g['out']).max() / smax < 2e-4
