@@ -192,3 +192,22 @@ def test_config_dict_loads_reference_style_config(tmp_path):
     assert isinstance(c, ConfigDict) and c.model.nf == 96 and c.model.ch_mult == (1, 1, 2) and c.seed == 42
     with pytest.raises(AttributeError):
         c.model.missing
+
+
+def test_lightning_checkpoint_reader(tmp_path):
+    """A reference-style Lightning checkpoint (score_model.* keys + VS-CMDE buffers) loads into the adapter."""
+    from conditional_score_diffusion_amd import checkpoint
+    from conditional_score_diffusion_amd.models import utils as mutils
+    cfg, _ = cases.case_config('cmde_tiny')
+    src = mutils.create_model(cfg)
+    sd = {'score_model.' + k: v.clone() + 0.01 for k, v in src.state_dict().items()}
+    sd['sigma_max_y'] = torch.tensor(0.37)
+    path = os.path.join(tmp_path, 'epoch=1.ckpt')
+    torch.save({'state_dict': sd, 'hyper_parameters': {'config': None}, 'epoch': 1}, path)
+    dst = mutils.create_model(cfg)
+    rest = checkpoint.load_lightning_checkpoint(dst, path)
+    assert float(rest['sigma_max_y']) == pytest.approx(0.37)
+    for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert torch.equal(a + 0.01, b), k
+    with pytest.raises(KeyError):
+        checkpoint.split_lightning_state_dict({'state_dict': {'other.weight': torch.zeros(1)}})
