@@ -79,6 +79,7 @@ SIGNATURES = {
     'csd_update_scratch_bytes': (_sz, [_i]),
     'csd_langevin_step': (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i64, _vp, _vp]),
     'csd_reverse_diffusion_step': (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i64, _vp]),
+    'csd_row_norms': (_i, [_vp, _vp, _i, _i64, _vp]),
     'csd_affine_noise_step': (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _i64, _vp]),
     'csd_linear': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'csd_fourier_embedding': (_i, [_vp, _vp, _vp, _i, _i, _vp]),

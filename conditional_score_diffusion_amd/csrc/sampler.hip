@@ -120,6 +120,20 @@ __global__ __launch_bounds__(256) void reverse_diffusion_update_kernel(float* __
   }
 }
 
+// out[b] = ||a_b||_2 (fp64 sum of squares, one workgroup per sample): the per-sample norms of the Langevin step size
+// (sampling/correctors.py:102-103) for callers that combine them across ranks before the update
+__global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict__ a, float* __restrict__ out, int64_t per) {
+  __shared__ double red[4];
+  const float* p = a + (size_t)blockIdx.x * per;
+  double s = 0;
+  for (int64_t i = threadIdx.x; i < per; i += 256) { const float v = p[i]; s += (double)v * v; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+}
+
 // general one-step update shared by the Euler-Maruyama / ancestral-sampling predictors and the annealed
 // Langevin corrector (sampling/predictors.py:52-76,105-179, correctors.py:111-142 of the reference): with
 // per-call scalars p, a, c     x_mean = p*x + a*score,   x = x_mean + c*z
@@ -263,6 +277,13 @@ extern "C" int csd_reverse_diffusion_step(float* x, float* x_mean, const float* 
                                           float G, int B, int64_t per_sample, void* stream) {
   CSD_REQUIRE(B > 0 && per_sample > 0, "reverse_diffusion_step: bad arguments");
   return reverse_diffusion_update_launch(x, x_mean, net, per_sample, z, std, G, B, per_sample, (hipStream_t)stream);
+}
+
+extern "C" int csd_row_norms(const float* a, float* out, int B, int64_t per_sample, void* stream) {
+  CSD_REQUIRE(a && out && B > 0 && per_sample > 0, "row_norms: bad arguments");
+  hipLaunchKernelGGL(row_norms_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, out, per_sample);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
 }
 
 extern "C" int csd_affine_noise_step(float* x, float* x_mean, const float* score, const float* z, float p, float a,

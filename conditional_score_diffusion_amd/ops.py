@@ -179,6 +179,15 @@ def langevin_step(x, net, z, std, snr):
     return x, x_mean
 
 
+def row_norms(x):
+    """||x_b||_2 per sample -> [B] (fp64 accumulation on the device)."""
+    x = _c(x, 'x')
+    B = x.shape[0]
+    out = torch.empty(B, dtype=torch.float32, device=x.device)
+    check(lib().csd_row_norms(ptr(x), ptr(out), B, x.numel() // B, current_stream(x.device)), 'row_norms')
+    return out
+
+
 def affine_noise_step(x, score, z, p, a, c):
     """In-place x_mean = p*x + a*score; x = x_mean + c*z (Euler-Maruyama / ancestral / annealed-Langevin updates)."""
     x, score, z = _c(x, 'x'), _c(score, 'score'), _c(z, 'z')

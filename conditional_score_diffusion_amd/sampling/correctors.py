@@ -96,6 +96,52 @@ class conditionalNoneCorrector(Corrector):
         return x, x
 
 
+def _langevin_global(sde, score_of, x, snr, n_steps, group=None):
+    """Langevin corrector whose batch-mean norms run over the GLOBAL batch of a sharded run ("global-norm"
+    exactness mode): per-sample norms on the device, ONE all-reduce of two fp32 sums per corrector step, then the
+    same update as sampling/correctors.py:100-106.  Without an initialised process group it equals ``langevin``."""
+    import torch.distributed as dist
+    if isinstance(sde, (sde_lib.VPSDE, sde_lib.cVPSDE, sde_lib.subVPSDE)):
+        raise NotImplementedError('the HIP Langevin step covers the VE SDEs (alpha = 1); got %s' % sde.__class__.__name__)
+    x = x.clone()
+    x_mean = x
+    for _ in range(n_steps):
+        grad = score_of(x)
+        noise = torch.randn_like(x)
+        sums = torch.stack([ops.row_norms(grad).sum(), ops.row_norms(noise).sum(),
+                            torch.tensor(float(x.shape[0]), device=x.device)])
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(sums, group=group)
+        g_sum, n_sum, b_tot = (float(v) for v in sums.tolist())
+        step = (snr * (n_sum / b_tot) / (g_sum / b_tot)) ** 2 * 2
+        x, x_mean = ops.affine_noise_step(x, grad, noise, 1.0, step, (2 * step) ** 0.5)
+    return x, x_mean
+
+
+@register_corrector(name='langevin_global')
+class LangevinCorrectorGlobal(Corrector):
+    """``langevin`` with global-batch norms across ranks (not in the reference: replaces running it in ONE process)."""
+
+    def __init__(self, sde, score_fn, snr, n_steps):
+        super().__init__(sde, score_fn, snr, n_steps)
+        if not isinstance(sde, (sde_lib.VPSDE, sde_lib.VESDE, sde_lib.subVPSDE)):
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+
+    def update_fn(self, x, t):
+        return _langevin_global(self.sde, lambda v: self.score_fn(v, t), x, self.snr, self.n_steps)
+
+
+@register_corrector(name='conditional_langevin_global')
+class conditionalLangevinCorrectorGlobal(Corrector):
+    def __init__(self, sde, score_fn, snr, n_steps):
+        super().__init__(sde, score_fn, snr, n_steps)
+        if not isinstance(sde, (sde_lib.cVESDE, sde_lib.cVPSDE)):
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+
+    def update_fn(self, x, y, t):
+        return _langevin_global(self.sde, lambda v: self.score_fn(v, y, t), x, self.snr, self.n_steps)
+
+
 def _ald(sde, score_of, x, t, snr, n_steps):
     """Annealed Langevin dynamics (sampling/correctors.py:111-142): step = (snr*std(t))^2 * 2*alpha,
     x_mean = x + step*grad, x = x_mean + sqrt(2*step)*z; no batch coupling."""

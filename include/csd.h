@@ -173,6 +173,9 @@ int csd_reverse_diffusion_step(float* x, float* x_mean, const float* net, const 
  * Langevin corrector (sampling/correctors.py:111-142); `score` is the score itself (already divided by std). */
 int csd_affine_noise_step(float* x, float* x_mean, const float* score, const float* z, float p, float a,
                           float c, int64_t n, void* stream);
+/* out[b] = ||a_b||_2 over per_sample elements (fp64 accumulation): the per-sample norms behind the Langevin step size
+ * (sampling/correctors.py:102-103), for the global-batch exactness mode that all-reduces them across ranks */
+int csd_row_norms(const float* a, float* out, int B, int64_t per_sample, void* stream);
 /* standard-normal fill (Philox4x32-10 + Box-Muller); counter-based: (seed, stream_id) */
 int csd_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
 /* out[b,:] = in[b,:] * scale[b]  or / scale[b] (divide_by_sigmas, models/utils.py:50-74) */

@@ -68,3 +68,75 @@ def test_single_process_is_passthrough():
     y = torch.ones(4, 3, 2, 2)
     out, info = D.sample_sharded(_fake_sampler, None, y_global=y, seed=1)
     assert out.shape == y.shape and info['n'] == 4
+
+
+# ---- global-norm exactness mode: the Langevin step size uses batch means over the GLOBAL batch ----
+def _install_cpu_standins():
+    """Test doubles for the two HIP ops the corrector calls (the kernels themselves are covered by -m gpu tests);
+    what is under test here is the cross-rank reduction and the step-size algebra."""
+    from conditional_score_diffusion_amd import ops
+
+    def row_norms(x):
+        return torch.norm(x.reshape(x.shape[0], -1), dim=-1)
+
+    def affine_noise_step(x, score, z, p, a, c):
+        xm = p * x + a * score
+        return xm + c * z, xm
+
+    ops.row_norms, ops.affine_noise_step = row_norms, affine_noise_step
+
+
+def _score(x, t):
+    return -(x - 0.3) * (1.0 + t.reshape(-1, 1, 1, 1))
+
+
+def _global_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _install_cpu_standins()
+    from conditional_score_diffusion_amd import sde_lib
+    from conditional_score_diffusion_amd.sampling import correctors
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(6, 3, 4, 4, generator=g)
+    z = torch.randn(2, 6, 3, 4, 4, generator=g)
+    lo, hi = rank * 3, rank * 3 + 3
+    it = iter([z[0, lo:hi], z[1, lo:hi]])
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **k: next(it)
+    try:
+        corr = correctors.get_corrector('langevin_global')(sde_lib.VESDE(0.01, 50., 100), _score, 0.16, 2)
+        out, out_mean = corr.update_fn(x[lo:hi], torch.full((3,), 0.5))
+    finally:
+        torch.randn_like = orig
+    q.put((rank, out, out_mean))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_norm_langevin_equals_single_process_gloo():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_global_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got, got_mean = torch.cat([r[1] for r in res]), torch.cat([r[2] for r in res])
+    # the reference's Langevin corrector (sampling/correctors.py:88-108, alpha = 1) on the whole batch in ONE process
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(6, 3, 4, 4, generator=g)
+    z = torch.randn(2, 6, 3, 4, 4, generator=g)
+    t = torch.full((6,), 0.5)
+    for i in range(2):
+        grad = _score(x, t)
+        gn = torch.norm(grad.reshape(6, -1), dim=-1).mean()
+        nn_ = torch.norm(z[i].reshape(6, -1), dim=-1).mean()
+        step = (0.16 * nn_ / gn) ** 2 * 2
+        x_mean = x + step * grad
+        x = x_mean + torch.sqrt(step * 2) * z[i]
+    assert torch.allclose(got, x, rtol=1e-5, atol=1e-6) and torch.allclose(got_mean, x_mean, rtol=1e-5, atol=1e-6)

@@ -107,3 +107,25 @@ def test_generic_loop_with_other_pair_runs():
         x, xm = corr.update_fn(x, t)
         x, xm = pred.update_fn(x, t)
     assert torch.isfinite(xm).all()
+
+
+def test_global_norm_langevin_is_langevin_in_one_process():
+    """Without a process group 'langevin_global' (per-sample norms on the device + host step size) must reproduce the
+    fused Langevin step kernel."""
+    from conditional_score_diffusion_amd import sde_lib
+    from conditional_score_diffusion_amd.sampling import correctors
+    dev = torch.device('cuda:0')
+    sde = sde_lib.VESDE(sigma_min=0.01, sigma_max=50., N=1000)
+    g = torch.Generator().manual_seed(11)
+    x0 = (torch.randn(4, 3, 16, 16, generator=g) * 3).to(dev)
+    z = torch.randn(2, 4, 3, 16, 16, generator=g)
+    t = torch.full((4,), 0.4, device=dev)
+    outs = []
+    for name in ('langevin', 'langevin_global'):
+        with _Tape([z[0], z[1]]):
+            outs.append(correctors.get_corrector(name)(sde, lambda x, t: step_score(x, t), 0.16, 2).update_fn(x0.clone(), t))
+    for a, b in zip(outs[0], outs[1]):
+        assert (a - b).abs().max().item() <= 2e-6 * a.abs().max().item()
+    n = torch.randn(5, 7, 9, device=dev)
+    from conditional_score_diffusion_amd import ops
+    assert torch.allclose(ops.row_norms(n), torch.norm(n.reshape(5, -1), dim=-1), rtol=1e-6)
