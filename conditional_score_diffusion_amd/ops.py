@@ -62,17 +62,67 @@ def attention(q, k, v):
     return out
 
 
-def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
-    """Same call signature as the reference's op.upfirdn2d (op/upfirdn2d.py:147-158)."""
+def _upfirdn2d_raw(x, kernel, up, down, pad4):
+    """csd_upfirdn2d with per-axis factors and four pads (x0, x1, y0, y1); negative pads crop."""
     x, kernel = _c(x, 'x'), _c(kernel, 'kernel')
     N, C, H, W = x.shape
     kh, kw = kernel.shape
-    OH = (H * up + pad[0] + pad[1] - kh) // down + 1
-    OW = (W * up + pad[0] + pad[1] - kw) // down + 1
+    (ux, uy), (dx, dy), (px0, px1, py0, py1) = up, down, pad4
+    OH = (H * uy + py0 + py1 - kh) // dy + 1
+    OW = (W * ux + px0 + px1 - kw) // dx + 1
     out = torch.empty(N, C, OH, OW, dtype=torch.float32, device=x.device)
-    check(lib().csd_upfirdn2d(ptr(x), ptr(kernel), ptr(out), N, C, H, W, kh, kw, up, up, down, down,
-                              pad[0], pad[1], pad[0], pad[1], current_stream(x.device)), 'upfirdn2d')
+    check(lib().csd_upfirdn2d(ptr(x), ptr(kernel), ptr(out), N, C, H, W, kh, kw, ux, uy, dx, dy, px0, px1, py0, py1,
+                              current_stream(x.device)), 'upfirdn2d')
     return out
+
+
+class _UpFirDn2dBackward(torch.autograd.Function):
+    """grad_input = upfirdn2d(grad_output, flip(kernel), up=down, down=up, pad=g_pad) (op/upfirdn2d.py:20-85)."""
+
+    @staticmethod
+    def forward(ctx, grad_output, kernel, grad_kernel, up, down, pad, g_pad, in_size, out_size):
+        ctx.save_for_backward(kernel)
+        ctx.up, ctx.down, ctx.pad, ctx.in_size, ctx.out_size = up, down, pad, in_size, out_size
+        g = _upfirdn2d_raw(grad_output.reshape(in_size[0], in_size[1], out_size[0], out_size[1]), grad_kernel, down, up, g_pad)
+        return g.view(in_size)
+
+    @staticmethod
+    def backward(ctx, gradgrad_input):
+        kernel, = ctx.saved_tensors
+        gg = _upfirdn2d_raw(gradgrad_input.contiguous(), kernel, ctx.up, ctx.down, ctx.pad)
+        return gg, None, None, None, None, None, None, None, None
+
+
+class _UpFirDn2d(torch.autograd.Function):
+    """Differentiable upfirdn2d, same autograd structure as the reference's UpFirDn2d (op/upfirdn2d.py:88-145)."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, up, down, pad):
+        ux, uy = up
+        dx, dy = down
+        px0, px1, py0, py1 = pad
+        kh, kw = kernel.shape
+        _, _, in_h, in_w = x.shape
+        out = _upfirdn2d_raw(x, kernel, up, down, pad)
+        out_h, out_w = out.shape[2], out.shape[3]
+        ctx.save_for_backward(kernel, torch.flip(kernel, [0, 1]))
+        ctx.in_size, ctx.out_size, ctx.up, ctx.down, ctx.pad = tuple(x.shape), (out_h, out_w), up, down, pad
+        ctx.g_pad = (kw - px0 - 1, in_w * ux - out_w * dx + px0 - ux + 1,
+                     kh - py0 - 1, in_h * uy - out_h * dy + py0 - uy + 1)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        kernel, grad_kernel = ctx.saved_tensors
+        g = _UpFirDn2dBackward.apply(grad_output.contiguous(), kernel, grad_kernel, ctx.up, ctx.down, ctx.pad, ctx.g_pad,
+                                     ctx.in_size, ctx.out_size)
+        return g, None, None, None, None
+
+
+def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
+    """Same call signature as the reference's op.upfirdn2d (op/upfirdn2d.py:147-158); differentiable w.r.t. ``x`` with
+    the reference's backward (the same FIR kernel flipped, up/down swapped, pads g_pad)."""
+    return _UpFirDn2d.apply(x, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
 
 
 def fused_leaky_relu(x, bias, negative_slope=0.2, scale=2 ** 0.5):

@@ -176,3 +176,45 @@ def test_update_kernels():
     assert rel(xo, xr) < 1e-6 and rel(xmo, xmr) < 1e-6
     sc = torch.tensor([2.0, 0.5, 277.0])
     assert rel(ops.scale_rows(x.to(dev()), sc.to(dev()), divide=True), x / sc.view(-1, 1, 1, 1)) < 1e-7
+
+
+def _upfirdn2d_native(x, kernel, up, down, pad):
+    """CPU restatement of op/upfirdn2d.py:161-202 (zero-stuff, pad / crop, correlate with the flipped taps, decimate)."""
+    n, c, h, w = x.shape
+    kh, kw = kernel.shape
+    out = x.reshape(-1, h, 1, w, 1, 1)
+    out = F.pad(out, [0, 0, 0, up - 1, 0, 0, 0, up - 1]).reshape(-1, h * up, w * up, 1)
+    p0, p1 = pad
+    out = F.pad(out, [0, 0, max(p0, 0), max(p1, 0), max(p0, 0), max(p1, 0)])
+    out = out[:, max(-p0, 0):out.shape[1] - max(-p1, 0), max(-p0, 0):out.shape[2] - max(-p1, 0), :]
+    out = out.permute(0, 3, 1, 2).reshape(-1, 1, h * up + p0 + p1, w * up + p0 + p1)
+    out = F.conv2d(out, torch.flip(kernel, [0, 1]).view(1, 1, kh, kw))
+    out = out[:, :, ::down, ::down]
+    return out.reshape(n, c, out.shape[2], out.shape[3])
+
+
+@pytest.mark.parametrize('up,down,pad,hw', [(2, 1, (2, 1), 9), (1, 2, (1, 1), 12), (1, 1, (1, 2), 7), (2, 1, (0, 0), 6),
+                                            (1, 2, (2, 2), 11), (2, 2, (1, 1), 8)])
+def test_upfirdn2d_backward_matches_autograd_of_native(up, down, pad, hw):
+    """a12: backward of upfirdn2d = the same op with the flipped kernel, swapped factors and g_pad
+    (op/upfirdn2d.py:20-85,108-116); checked against torch autograd through the native CPU formulation,
+    and the double backward against the forward formula."""
+    from conditional_score_diffusion_amd import ops
+    k1 = torch.tensor([1., 3., 3., 1.])
+    kern = torch.outer(k1, k1)
+    kern = kern / kern.sum() * (up ** 2)
+    x = rnd(2, 3, hw, hw + 1, seed=5)
+    xc = x.clone().requires_grad_(True)
+    ref = _upfirdn2d_native(xc, kern, up, down, pad)
+    go = rnd(*ref.shape, seed=6)
+    ref.backward(go)
+    xg = x.to(dev()).requires_grad_(True)
+    out = ops.upfirdn2d(xg, kern.to(dev()), up=up, down=down, pad=pad)
+    assert rel(out.detach(), ref.detach()) < 1e-6
+    go_d = go.to(dev()).requires_grad_(True)
+    gi, = torch.autograd.grad(out, xg, go_d, create_graph=True)
+    assert rel(gi.detach(), xc.grad) < 1e-6
+    # double backward (op/upfirdn2d.py:62-85): d<gi, v>/d(go) = upfirdn2d(v) with the forward parameters
+    v = rnd(*x.shape, seed=7)
+    gg, = torch.autograd.grad(gi, go_d, v.to(dev()))
+    assert rel(gg, _upfirdn2d_native(v, kern, up, down, pad)) < 1e-6
