@@ -1,7 +1,7 @@
 """ORACLE (test infrastructure - NOT product code).
 
 CPU restatement, in plain functional PyTorch fp32, of the reference's score network
-(DDPM-family U-Net) and of its predictor-corrector sampling loop.  Only ``tests/``,
+(DDPM-family U-Net and NCSN++) and of its predictor-corrector sampling loop.  Only ``tests/``,
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this file; the
 product path (conditional_score_diffusion_amd/) never does.
 
@@ -320,6 +320,149 @@ def upfirdn2d_ref(x, kernel, up=1, down=1, pad=(0, 0)):
     out = F.conv2d(out, w)
     out = out[:, :, ::down, ::down]
     return out.reshape(N, C, out.shape[2], out.shape[3])
+
+
+# ------------------------------------------------------------------------------------------
+# NCSN++ (models/ncsnpp.py; blocks models/layerspp.py; FIR resampling models/up_or_down_sampling.py)
+# ------------------------------------------------------------------------------------------
+def _ncsnpp_groups(c):
+    return min(c // 4, 32)                     # layerspp.py:67,219,231
+
+
+def fir_kernel_2d(k, gain=1.0):
+    """up_or_down_sampling.py:181-189 ``_setup_kernel`` (separable taps -> normalised 2-D kernel) times a gain."""
+    k = np.asarray(k, dtype=np.float32)
+    k = np.outer(k, k)
+    k /= np.sum(k)
+    return torch.tensor(k * gain)
+
+
+def upsample_2d(x, k, factor=2):
+    """up_or_down_sampling.py:196-226."""
+    kern = fir_kernel_2d(k, float(factor ** 2))
+    p = kern.shape[0] - factor
+    return upfirdn2d_ref(x, kern, up=factor, pad=((p + 1) // 2 + factor - 1, p // 2))
+
+
+def downsample_2d(x, k, factor=2):
+    """up_or_down_sampling.py:229-257."""
+    kern = fir_kernel_2d(k, 1.0)
+    p = kern.shape[0] - factor
+    return upfirdn2d_ref(x, kern, down=factor, pad=((p + 1) // 2, p // 2))
+
+
+def biggan_block(p, pre, x, temb, act, cin, cout, up, down, fir_k, skip_rescale):
+    """ResnetBlockBigGANpp.forward in eval mode (layerspp.py:242-274)."""
+    h = act(F.group_norm(x, _ncsnpp_groups(cin), p[pre + 'GroupNorm_0.weight'], p[pre + 'GroupNorm_0.bias'], eps=1e-6))
+    if up:
+        h, x = upsample_2d(h, fir_k), upsample_2d(x, fir_k)
+    elif down:
+        h, x = downsample_2d(h, fir_k), downsample_2d(x, fir_k)
+    h = F.conv2d(h, p[pre + 'Conv_0.weight'], p[pre + 'Conv_0.bias'], padding=1)
+    if temb is not None:
+        h = h + F.linear(act(temb), p[pre + 'Dense_0.weight'], p[pre + 'Dense_0.bias'])[:, :, None, None]
+    h = act(F.group_norm(h, _ncsnpp_groups(cout), p[pre + 'GroupNorm_1.weight'], p[pre + 'GroupNorm_1.bias'], eps=1e-6))
+    h = F.conv2d(h, p[pre + 'Conv_1.weight'], p[pre + 'Conv_1.bias'], padding=1)
+    if cin != cout or up or down:
+        x = F.conv2d(x, p[pre + 'Conv_2.weight'], p[pre + 'Conv_2.bias'])
+    return (x + h) / np.sqrt(2.) if skip_rescale else x + h
+
+
+def attn_block_pp(p, pre, x, skip_rescale):
+    """AttnBlockpp.forward (layerspp.py:75-91): AttnBlock with GroupNorm(min(C/4, 32)) and the optional rescale."""
+    C = x.shape[1]
+    out = attn_block(p, pre, x, groups=_ncsnpp_groups(C))          # = x + h
+    return out / np.sqrt(2.) if skip_rescale else out
+
+
+def ncsnpp_forward(p, config, x, time_cond):
+    """NCSNpp.forward (models/ncsnpp.py:238-388) for the option set the HIP adapter covers: biggan blocks, FIR
+    resampling, progressive in {none, output_skip}, progressive_input in {none, input_skip}, combine 'sum'."""
+    m, d = config.model, config.data
+    act = _act(m.nonlinearity.lower())
+    nf, ch_mult = m.nf, tuple(m.ch_mult)
+    L = len(ch_mult)
+    res = [d.effective_image_size // (2 ** i) for i in range(L)]
+    fir_k, skip = tuple(m.fir_kernel), bool(m.skip_rescale)
+    prog, prog_in = m.progressive.lower(), m.progressive_input.lower()
+    i = 0
+
+    def pre():
+        return 'all_modules.%d.' % i
+
+    if m.embedding_type.lower() == 'fourier':
+        xp = time_cond[:, None] * p[pre() + 'W'][None, :] * 2 * np.pi          # layerspp.py:39-41
+        temb = torch.cat([torch.sin(xp), torch.cos(xp)], dim=-1)
+        i += 1
+    else:
+        temb = timestep_embedding(time_cond, nf)
+    if m.conditional:
+        temb = F.linear(temb, p[pre() + 'weight'], p[pre() + 'bias'])
+        i += 1
+        temb = F.linear(act(temb), p[pre() + 'weight'], p[pre() + 'bias'])
+        i += 1
+    else:
+        temb = None
+    if not d.centered:
+        x = 2 * x - 1.
+    input_pyramid = x if prog_in != 'none' else None
+    hs = [F.conv2d(x, p[pre() + 'weight'], p[pre() + 'bias'], padding=1)]
+    i += 1
+    in_ch = nf
+    hs_c = [nf]
+    for lv in range(L):
+        for _ in range(m.num_res_blocks):
+            out_ch = nf * ch_mult[lv]
+            h = biggan_block(p, pre(), hs[-1], temb, act, in_ch, out_ch, False, False, fir_k, skip)
+            i += 1
+            in_ch = out_ch
+            if h.shape[-1] in m.attn_resolutions:
+                h = attn_block_pp(p, pre(), h, skip)
+                i += 1
+            hs.append(h)
+            hs_c.append(in_ch)
+        if lv != L - 1:
+            h = biggan_block(p, pre(), hs[-1], temb, act, in_ch, in_ch, False, True, fir_k, skip)
+            i += 1
+            if prog_in == 'input_skip':
+                input_pyramid = downsample_2d(input_pyramid, fir_k)
+                h = F.conv2d(input_pyramid, p[pre() + 'Conv_0.weight'], p[pre() + 'Conv_0.bias']) + h   # Combine 'sum'
+                i += 1
+            hs.append(h)
+            hs_c.append(in_ch)
+    h = hs[-1]
+    h = biggan_block(p, pre(), h, temb, act, in_ch, in_ch, False, False, fir_k, skip)
+    i += 1
+    h = attn_block_pp(p, pre(), h, skip)
+    i += 1
+    h = biggan_block(p, pre(), h, temb, act, in_ch, in_ch, False, False, fir_k, skip)
+    i += 1
+    pyramid = None
+    for lv in reversed(range(L)):
+        for _ in range(m.num_res_blocks + 1):
+            out_ch = nf * ch_mult[lv]
+            h = biggan_block(p, pre(), torch.cat([h, hs.pop()], dim=1), temb, act, in_ch + hs_c.pop(), out_ch, False, False,
+                             fir_k, skip)
+            i += 1
+            in_ch = out_ch
+        if h.shape[-1] in m.attn_resolutions:
+            h = attn_block_pp(p, pre(), h, skip)
+            i += 1
+        if prog == 'output_skip':
+            ph = act(F.group_norm(h, _ncsnpp_groups(in_ch), p[pre() + 'weight'], p[pre() + 'bias'], eps=1e-6))
+            i += 1
+            ph = F.conv2d(ph, p[pre() + 'weight'], p[pre() + 'bias'], padding=1)
+            i += 1
+            pyramid = ph if pyramid is None else upsample_2d(pyramid, fir_k) + ph
+        if lv != 0:
+            h = biggan_block(p, pre(), h, temb, act, in_ch, in_ch, True, False, fir_k, skip)
+            i += 1
+    assert not hs
+    if prog == 'output_skip':
+        return pyramid
+    h = act(F.group_norm(h, _ncsnpp_groups(in_ch), p[pre() + 'weight'], p[pre() + 'bias'], eps=1e-6))
+    i += 1
+    return F.conv2d(h, p[pre() + 'weight'], p[pre() + 'bias'], padding=1)
 
 
 # ------------------------------------------------------------------------------------------

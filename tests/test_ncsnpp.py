@@ -104,3 +104,28 @@ def test_pc_sampler_runs_on_ncsnpp():
         torch.manual_seed(0)
         out, info = fn(model)
         assert out.shape == (2, 3, 16, 16) and torch.isfinite(out).all() and info['steps'] == 8
+
+
+@pytest.mark.gpu
+def test_larger_config_vs_oracle():
+    """A configuration without a fixture (nf=64, 32x32, three levels, attention at 16, 6 -> 6 channels paired): HIP path
+    vs the CPU oracle (oracle/score_oracle.py:ncsnpp_forward, itself pinned to the reference by test_oracle_golden)."""
+    import score_oracle as so
+    from conditional_score_diffusion_amd.models import utils as mutils
+    cfg = cases.make_ncsnpp_config(name='ncsnpp_paired', channels=6, nf=64, ch_mult=(1, 2, 2), attn_resolutions=(16,),
+                                   num_res_blocks=2, image_size=32, embedding_type='positional')
+    cfg.model.csd_precision = 'fp16x3'
+    dev = torch.device('cuda:0')
+    model = mutils.create_model(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    p = cases.ncsnpp_params(shapes, 9)
+    model.load_state_dict(p)
+    model = model.to(dev).eval()
+    rs = np.random.RandomState(4)
+    x = torch.from_numpy(rs.uniform(-1, 2, size=(2, 6, 32, 32)).astype(np.float32))
+    labels = torch.tensor([3.5, 640.0])
+    with torch.no_grad():
+        r = model({'x': x[:, :3].to(dev), 'y': x[:, 3:].to(dev)}, labels.to(dev))
+        got = torch.cat([r['x'], r['y']], dim=1).cpu()
+        ref = so.ncsnpp_forward(p, cfg, x, labels)
+    assert (got - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()

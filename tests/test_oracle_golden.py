@@ -126,3 +126,19 @@ def test_ve_scalars(golden_dir):
         assert np.array_equal((ts * 999).numpy(), g['labels%d' % n])
         assert np.array_equal(ve.G(ts).numpy(), g['G%d' % n])
         assert np.array_equal(ve.std(ts).numpy(), g['std%d' % n])
+
+
+@pytest.mark.parametrize('case', list(cases.NCSNPP_CASES))
+def test_ncsnpp_oracle_vs_reference(golden_dir, case):
+    """oracle.ncsnpp_forward == the reference NCSNpp.forward on the seeded cases (fixtures: oracle/make_goldens.py)."""
+    g = np.load(os.path.join(golden_dir, 'ncsnpp.npz'))
+    cfg, B, x, labels = cases.ncsnpp_case(case)
+    shapes = {}
+    for s in g[case + '_keys']:
+        k, shp = str(s).split('|')
+        shapes[k] = tuple(int(v) for v in shp.split(',')) if shp else ()
+    p = cases.ncsnpp_params(shapes, 5)
+    with torch.no_grad():
+        y = so.ncsnpp_forward(p, cfg, x, labels)
+    ref = torch.from_numpy(g[case + '_out'])
+    assert (y - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
