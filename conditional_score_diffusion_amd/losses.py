@@ -1,0 +1,117 @@
+"""Score-matching losses with the reference's factories (losses.py:55-232) - **evaluation (forward) value only**.
+
+``get_sde_loss_fn`` / ``get_general_sde_loss_fn`` return ``loss_fn(model, batch) -> scalar tensor`` with the reference's
+argument meaning: per-sample ``t ~ U(eps, T)``, perturbation ``x_t = mean + std * z``, score evaluation, and the
+(likelihood-)weighted denoising score-matching residual, reduced per sample (mean or 0.5*sum) and averaged over the
+batch.  Every pixel-sized operation runs on the HIP kernels (perturbation: csd_scale_rows + csd_axpby; residual:
+csd_scale_rows + csd_axpby; per-sample squared norms: csd_row_norms); the remaining arithmetic is on B scalars.
+
+The value carries NO autograd graph: the backward of the network (dX/dW of every layer and the
+gradient all-reduce) is not built yet, so ``train=True`` raises NotImplementedError instead of returning a loss that
+silently cannot be differentiated.
+"""
+import torch
+
+from . import ops, sde_lib
+from .models import utils as mutils
+
+
+def _bstd(sde, ref, t):
+    """(mean-scale, std) of p_t(x|x0) as [B] fp32 host tensors: every SDE of sde_lib has mean = m(t)*x0."""
+    t = t.detach().cpu().float()
+    mean, std = sde.marginal_prob(torch.ones(t.shape[0], 1, 1, 1), t)
+    return mean.flatten(), std.flatten().float()
+
+
+def _perturb(x, z, m, std):
+    """x_t = m_b * x + std_b * z on the device."""
+    dev = x.device
+    xm = x if bool(torch.all(m == 1)) else ops.scale_rows(x, m.to(dev))
+    return ops.axpby(xm, ops.scale_rows(z, std.to(dev)))
+
+
+def _residual_sumsq(score, z, std, weighting):
+    """per-sample sum of squares of (score*std + z) [weighting False] or (score + z/std) [True] -> [B] host tensor."""
+    dev = score.device
+    if weighting:
+        d = ops.axpby(score, ops.scale_rows(z, std.to(dev), divide=True))
+    else:
+        d = ops.axpby(ops.scale_rows(score, std.to(dev)), z)
+    n = ops.row_norms(d).cpu().double()
+    return n * n
+
+
+def _reduce(sumsq, numel, reduce_mean):
+    return sumsq / numel if reduce_mean else 0.5 * sumsq
+
+
+def _g2(sde, t):
+    t = t.detach().cpu().float()
+    return (sde.sde(torch.zeros(t.shape[0], 1, 1, 1), t)[1].flatten().double()) ** 2
+
+
+def _check_eval(train):
+    if train:
+        raise NotImplementedError('training loss needs the network backward (SURVEY.md 8 a19/a20), which the HIP path does '
+                                  'not provide yet; use train=False for the evaluation loss value')
+
+
+def get_sde_loss_fn(sde, train, reduce_mean=True, continuous=True, likelihood_weighting=True, eps=1e-5):
+    """losses.py:55-97 (unconditional)."""
+    _check_eval(train)
+
+    def loss_fn(model, batch):
+        score_fn = mutils.get_score_fn(sde, model, train=False, continuous=continuous)
+        t = torch.rand(batch.shape[0]) * (sde.T - eps) + eps
+        z = torch.randn_like(batch)
+        m, std = _bstd(sde, batch, t)
+        score = score_fn(_perturb(batch, z, m, std), t.to(batch.device))
+        per = batch[0].numel()
+        losses = _reduce(_residual_sumsq(score, z, std, likelihood_weighting), per, reduce_mean)
+        if likelihood_weighting:
+            losses = losses * _g2(sde, t)
+        return losses.mean().float()
+
+    return loss_fn
+
+
+def get_general_sde_loss_fn(sde, train, conditional=False, reduce_mean=True, continuous=True, likelihood_weighting=True,
+                            eps=1e-5):
+    """losses.py:99-232: unconditional, SR3 (one conditional SDE, clean y) and the two-SDE CMDE / VS-CMDE branch."""
+    _check_eval(train)
+    if not conditional:
+        return get_sde_loss_fn(sde, train, reduce_mean, continuous, likelihood_weighting, eps)
+    if isinstance(sde, dict):
+        if len(sde) != 2:
+            raise NotImplementedError('multi-speed losses with >= 3 SDEs (losses.py:148-183) are not provided')
+        assert likelihood_weighting, 'For the variance reduction technique in inverse problems, we only support likelihood weighting for the time being.'
+
+        def loss_fn(model, batch):
+            y, x = batch
+            score_fn = mutils.get_score_fn(sde, model, conditional=True, train=False, continuous=continuous)
+            t = torch.rand(x.shape[0]) * (sde['x'].T - eps) + eps
+            z_y = torch.randn_like(y)
+            m_y, std_y = _bstd(sde['y'], y, t)
+            z_x = torch.randn_like(x)
+            m_x, std_x = _bstd(sde['x'], x, t)
+            score = score_fn({'x': _perturb(x, z_x, m_x, std_x), 'y': _perturb(y, z_y, m_y, std_y)}, t.to(x.device))
+            sx = _residual_sumsq(score['x'].contiguous(), z_x, std_x, True) * _g2(sde['x'], t)
+            sy = _residual_sumsq(score['y'].contiguous(), z_y, std_y, True) * _g2(sde['y'], t)
+            numel = x[0].numel() + y[0].numel()          # the reference concatenates both residuals before reducing
+            return _reduce(sx + sy, numel, reduce_mean).mean().float()
+
+        return loss_fn
+
+    def loss_fn(model, batch):          # SR3 estimator (losses.py:185-205)
+        y, x = batch
+        score_fn = mutils.get_score_fn(sde, model, conditional=True, train=False, continuous=continuous)
+        t = torch.rand(x.shape[0]) * (sde.T - eps) + eps
+        z = torch.randn_like(x)
+        m, std = _bstd(sde, x, t)
+        score = score_fn({'x': _perturb(x, z, m, std), 'y': y}, t.to(x.device))
+        losses = _reduce(_residual_sumsq(score, z, std, likelihood_weighting), x[0].numel(), reduce_mean)
+        if likelihood_weighting:
+            losses = losses * _g2(sde, t)
+        return losses.mean().float()
+
+    return loss_fn

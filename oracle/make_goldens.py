@@ -259,6 +259,42 @@ def gen_use_path(ref):
     print('use_path', tuple(out.shape), float(out.abs().max()))
 
 
+def gen_losses(ref):
+    """Evaluation-loss values (losses.py:99-232) of the reference on the tiny cases with fixed t and noise -> tests/golden/losses.npz."""
+    L = ref['losses']
+    out = {}
+    for case in cases.CASES:
+        cfg, B = cases.case_config(case)
+        model, _ = build_ref_model(ref, cfg)
+        sde = sdes_for(ref, cfg)
+        rs = np.random.RandomState(11)
+        xs, ys = (B,) + tuple(cfg.data.shape_x), (B,) + tuple(cfg.data.shape_y)
+        x = torch.from_numpy(rs.uniform(0, 1, size=xs).astype(np.float32))
+        y = cases.case_y(case)
+        tvals = torch.tensor([0.83, 0.21][:B])
+        for lw in (True, False):
+            if isinstance(sde, dict) and not lw:
+                continue
+            for rm in (True, False):
+                if cfg.model.name == 'ddpm':
+                    model.embedding_type = 'positional'      # (attribute the reference's score_fn reads; see gen_network_case)
+                    fn, batch, tape = L.get_general_sde_loss_fn(sde, False, False, rm, True, lw), x, cases.tape([xs], 3)
+                elif isinstance(sde, dict):
+                    fn, batch, tape = L.get_general_sde_loss_fn(sde, False, True, rm, True, lw), (y, x), cases.tape([ys, xs], 3)
+                else:
+                    fn, batch, tape = L.get_general_sde_loss_fn(sde, False, True, rm, True, lw), (y, x), cases.tape([xs], 3)
+                orig = torch.rand
+                torch.rand = lambda *a, **k: tvals.clone()
+                try:
+                    with ref_import.TapeRandn(tape), torch.no_grad():
+                        v = fn(model, batch)
+                finally:
+                    torch.rand = orig
+                out['%s_lw%d_rm%d' % (case, lw, rm)] = np.float64(v.item())
+                print(case, lw, rm, float(v))
+    np.savez_compressed(os.path.join(OUT, 'losses.npz'), **out)
+
+
 def gen_ncsnpp(ref):
     """Reference NCSN++ forward (models/ncsnpp.py) on the seeded cases of cases.NCSNPP_CASES -> tests/golden/ncsnpp.npz:
     state_dict key order + shapes (as a string table) and the network output."""
@@ -291,6 +327,7 @@ def main():
     gen_steps(ref)
     gen_ncsnpp(ref)
     gen_use_path(ref)
+    gen_losses(ref)
     for case in cases.CASES:
         gen_network_case(ref, case)
 
