@@ -248,6 +248,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16_lc_kernel(const void* __restr
   };
   if (total > 0) item_begin(0, ng, tile, ov0);
   zero_acc();
+#ifdef CSD_C16_TIMING
+  if (k.a.dbg && tid == 0 && blockIdx.x == 0) { k.a.dbg[4094 * 8 + 0] = clock64(); k.a.dbg[4094 * 8 + 1] = wall_clock64(); }
+#endif
 
 #ifdef CSD_C16_TIMING
   int ts_n = 0;
@@ -423,6 +426,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16_lc_kernel(const void* __restr
     ng = ng_n; tile = tile_n; ov0 = ov0_n;
     zero_acc();
   }
+#ifdef CSD_C16_TIMING
+  if (k.a.dbg && tid == 0 && blockIdx.x == 0) { k.a.dbg[4094 * 8 + 2] = clock64(); k.a.dbg[4094 * 8 + 3] = wall_clock64(); }
+#endif
 }
 
 }  // namespace csd

@@ -29,4 +29,7 @@ for l in range(L):
     if len(t) == 0: continue
     nz = int((t[0] != 0).sum())
     d = np.diff(t[:, :nz], axis=1).mean(0)
+    ck = allt[l, 4094, :4]
+    if ck[3] > ck[1]:
+        print('     shader clock during this launch: %.0f MHz (clock64 / wall_clock64 x 100 MHz, workgroup 0 lifetime %.0f us)' % (100.0 * (ck[2] - ck[0]) / (ck[3] - ck[1]), (ck[3] - ck[1]) / 100.0))
     print('#%2d Cin %3d Cout %3d res %d temb %d item total %7.0f | ' % (l, hdr[0], hdr[1], hdr[3] & 1, (hdr[3] >> 1) & 1, (t[:, nz - 1] - t[:, 0]).mean()) + ' '.join('%6.0f' % v for v in d))
