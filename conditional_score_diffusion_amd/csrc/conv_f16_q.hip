@@ -26,6 +26,24 @@ typedef unsigned int uint4q __attribute__((ext_vector_type(4)));
 
 #define C16Q_THREADS 256
 
+// sum of a double over the 16 lanes of a DPP row, result in every lane: quad_perm xor 1, xor 2, then row rotations by 4
+// and 8 - VALU-rate data movement (a ds_bpermute butterfly of 24 doubles cost 8.6k cycles per workgroup, 15 % of the
+// kernel: tools/phase_timing_q.py)
+__device__ __forceinline__ double dpp_row16_sum(double v) {
+#define CSD_DPP_STEP(CTRL)                                                                                   \
+  {                                                                                                          \
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);                        \
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);                        \
+    v += __hiloint2double(hi, lo);                                                                           \
+  }
+  CSD_DPP_STEP(0xB1)      // quad_perm [1,0,3,2]
+  CSD_DPP_STEP(0x4E)      // quad_perm [2,3,0,1]
+  CSD_DPP_STEP(0x124)     // row_ror:4
+  CSD_DPP_STEP(0x128)     // row_ror:8
+#undef CSD_DPP_STEP
+  return v;
+}
+
 template <int MQ, int NS, bool MASK, int PWC>
 __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void* __restrict__ g_hi,
                                                                     const void* __restrict__ g_lo,
@@ -42,6 +60,13 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
   extern __shared__ __attribute__((aligned(16))) char smem16[];
 
   const int tid = threadIdx.x;
+#ifdef CSD_C16_TIMING
+  int ts_n = 0;
+#define Q_TSTAMP() do { if (k.a.dbg && tid == 0 && blockIdx.x < 4095 && ts_n < 8) k.a.dbg[blockIdx.x * 8 + ts_n++] = clock64(); } while (0)
+#else
+#define Q_TSTAMP() do { } while (0)
+#endif
+  Q_TSTAMP();
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mi = wave >> 1, ni = wave & 1;
@@ -104,6 +129,7 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
     base[j] = (m < k.TH * k.TW) ? ty * rstride + tx * PSB + kq * 16 : kq * 16;
   }
   __syncthreads();
+  Q_TSTAMP();
   unsigned vbits[MQ];
   if (MASK) {
 #pragma unroll
@@ -160,6 +186,7 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
     for (int j = 0; j < NU; ++j) slot_store(j * C16Q_THREADS + tid, v0[j]);
   }
   __syncthreads();
+  Q_TSTAMP();
 
   const int nstage = nk32;                      // one 32-channel K step per tap per stage
   for (int stg = 0; stg < nstage; ++stg) {
@@ -219,6 +246,7 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
       }
     }
     static_assert(TAPS % BR == 0, "weight ring phase");
+    Q_TSTAMP();
     if (more) {
       __syncthreads();                          // everyone is done reading this stage's patch
 #pragma unroll
@@ -302,18 +330,13 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
       __builtin_amdgcn_raw_buffer_store_b128(ov, out_r, off, 0, 0);
     }
   // GroupNorm statistics of the written tensor: one (sum, sumsq) pair per (tile, M half, cout); the host sets
-  // `stats` only when a tile lies inside one sample.  Fixed-shape butterfly over the 16 pixel lanes.
+  // `stats` only when a tile lies inside one sample.  Fixed-order DPP reduction over the 16 pixel lanes.
   if (k.a.stats) {
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        double s = st_s[t][i], q = st_q[t][i];
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-          s += __shfl_xor(s, d);
-          q += __shfl_xor(q, d);
-        }
+        const double s = dpp_row16_sum(st_s[t][i]), q = dpp_row16_sum(st_q[t][i]);
         if (l16 == 0) {
           double* dst = k.a.stats + (((size_t)tile * 2 + mi) * k.Cout + c_base + t * 16 + i) * 2;
           dst[0] = s;
@@ -321,6 +344,7 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
         }
       }
   }
+  Q_TSTAMP();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -445,6 +469,19 @@ int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) 
   Conv16KArgs k;
   k.a = a;
   k.a.dbg = nullptr;
+#ifdef CSD_C16_TIMING
+  {
+    extern long long* g_c16_dbg; extern int g_c16_dbg_blocks, g_c16_dbg_max, g_c16_dbg_n;
+    const int nb = cdiv(p.OW, p.TW) * cdiv(p.B * p.OH, p.TH) * p.n_groups;
+    if (g_c16_dbg && nb == g_c16_dbg_blocks && g_c16_dbg_n < g_c16_dbg_max) {
+      k.a.dbg = g_c16_dbg + (size_t)g_c16_dbg_n * 4096 * 8;
+      if (hipMemsetAsync(k.a.dbg, 0, 4096 * 8 * 8, s) != hipSuccess) return -1;
+      long long hdr[4] = {p.C0, p.Cout, 1, (a.res ? 1 : 0) | (a.temb ? 2 : 0)};
+      if (hipMemcpyAsync(k.a.dbg + 4095 * 8, hdr, sizeof(hdr), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+      g_c16_dbg_n++;
+    }
+  }
+#endif
   k.B = p.B; k.IH = p.IH; k.IW = p.IW; k.OH = p.OH; k.OW = p.OW;
   k.C0 = p.C0; k.C1 = 0; k.Cout = p.Cout;
   k.stride = 1; k.pad = 1; k.up = 0;

@@ -1,0 +1,32 @@
+"""Tuning aid (needs a -DCSD_C16_TIMING library via CSD_LIB_PATH): per-workgroup stamps of the quad conv kernel:
+[start, tables, first stage in LDS, end of MFMAs of each stage ..., end]."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+import numpy as np, torch
+import bench, score_oracle as so
+from conditional_score_diffusion_amd import _lib
+from conditional_score_diffusion_amd.models import utils as mutils
+dev = torch.device('cuda:0')
+cfg = bench.sr3_160_config(); cfg.model.csd_precision = sys.argv[1] if len(sys.argv) > 1 else 'fp16x3'
+B = 64
+m = mutils.create_model(cfg); m.load_state_dict(so.synth_params(so.ddpm_param_shapes(so.NetCfg.from_config(cfg)), 0)); m = m.to(dev).eval()
+x = torch.randn(B, 3, 160, 160, device=dev) * 50; y = bench.synth_y(B).to(dev); lab = torch.full((B,), 500., device=dev)
+L = 12
+buf = torch.zeros(L * 4096 * 8, dtype=torch.int64, device=dev)
+nblocks = int(sys.argv[2]) if len(sys.argv) > 2 else 12800
+_lib.lib().csd_debug_timing.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+with torch.no_grad():
+    m({'x': x, 'y': y}, lab)
+    _lib.lib().csd_debug_timing(ctypes.c_void_p(buf.data_ptr()), nblocks, L)
+    m({'x': x, 'y': y}, lab)
+torch.cuda.synchronize()
+allt = buf.cpu().numpy().reshape(L, 4096, 8)
+for l in range(L):
+    hdr = allt[l, 4095, :4]
+    t = allt[l, :4095]
+    t = t[t[:, 0] != 0]
+    if len(t) == 0: continue
+    nz = int((t[0] != 0).sum())
+    d = np.diff(t[:, :nz], axis=1).mean(0)
+    print('#%2d Cin %3d Cout %3d res %d temb %d wg total %7.0f | ' % (l, hdr[0], hdr[1], hdr[3] & 1, (hdr[3] >> 1) & 1, (t[:, nz - 1] - t[:, 0]).mean()) + ' '.join('%6.0f' % v for v in d))
