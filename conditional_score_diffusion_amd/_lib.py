@@ -28,7 +28,9 @@ class UNetConfig(ctypes.Structure):
                 ('image_size', ctypes.c_int32), ('x_channels', ctypes.c_int32),
                 ('y_channels', ctypes.c_int32), ('out_channels', ctypes.c_int32),
                 ('resamp_with_conv', ctypes.c_int32), ('conditional', ctypes.c_int32),
-                ('centered', ctypes.c_int32), ('act', ctypes.c_int32), ('precision', ctypes.c_int32)]
+                ('centered', ctypes.c_int32), ('act', ctypes.c_int32), ('precision', ctypes.c_int32),
+                ('skip_rescale', ctypes.c_int32), ('progressive', ctypes.c_int32), ('progressive_input', ctypes.c_int32),
+                ('embedding_type', ctypes.c_int32), ('n_fir', ctypes.c_int32), ('fir_kernel', ctypes.c_float * 8)]
 
 
 class PCParams(ctypes.Structure):

@@ -164,6 +164,7 @@ int linear_launch(const float* in, const float* W, const float* bias, float* out
 int assemble_input_launch(const float* x, const float* y, const float* y_noise, float y_sigma,
                           float* out, int B, int Cx, int Cy, int HW, int Cpad, int centered,
                           hipStream_t s);
+int fir_resample_nhwc_launch(const float* in, float* out, int B, int H, int W, int C, const float* taps4, int up, hipStream_t s);
 int fourier_embedding_launch(const float* t, const float* W, float* out, int B, int E, hipStream_t s);
 int axpby_launch(const float* a, const float* b, float* out, float alpha, float beta, float gamma, float post, size_t n,
                  hipStream_t s);

@@ -300,6 +300,55 @@ __global__ void fused_bias_act_kernel(const float* __restrict__ x, const float* 
   }
 }
 
+// ---- FIR resampling of an NHWC tensor by 2 with a separable 4-tap kernel: upsample_2d / downsample_2d of
+// models/up_or_down_sampling.py:196-257 (= upfirdn2d with up = 2, pad (2, 1) / down = 2, pad (1, 1)); used inside the
+// NCSN++ graph executor, where activations never leave the NHWC layout ----
+struct Fir16 { float k[16]; };      // the 2-D kernel as upfirdn2d receives it (gain applied), row-major
+__global__ void fir_resample_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C, int up,
+                                         Fir16 f, size_t total) {
+  const int OH = up ? H * 2 : H / 2, OW = up ? W * 2 : W / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t r = i / C;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const size_t b = r / OH;
+    const float* src = in + b * (size_t)H * W * C + c;
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      // coordinate in the zero-stuffed (up) or plain (down) image; upfirdn2d correlates with the FLIPPED kernel
+      const int my = up ? oy + ky - 2 : oy * 2 + ky - 1;
+      if (my < 0 || (up && (my & 1))) continue;
+      const int iy = up ? my >> 1 : my;
+      if (iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const int mx = up ? ox + kx - 2 : ox * 2 + kx - 1;
+        if (mx < 0 || (up && (mx & 1))) continue;
+        const int ix = up ? mx >> 1 : mx;
+        if (ix >= W) continue;
+        acc += src[((size_t)iy * W + ix) * C] * f.k[(3 - ky) * 4 + (3 - kx)];
+      }
+    }
+    out[i] = acc;
+  }
+}
+int fir_resample_nhwc_launch(const float* in, float* out, int B, int H, int W, int C, const float* taps4, int up, hipStream_t s) {
+  // _setup_kernel (up_or_down_sampling.py:181-189): outer product, normalised, times the gain (factor^2 when upsampling)
+  Fir16 f;
+  float sum = 0.f;
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b) { f.k[a * 4 + b] = taps4[a] * taps4[b]; sum += f.k[a * 4 + b]; }
+  for (int a = 0; a < 16; ++a) f.k[a] = f.k[a] / sum * (up ? 4.f : 1.f);
+  const size_t total = (size_t)B * (up ? H * 2 : H / 2) * (up ? W * 2 : W / 2) * C;
+  hipLaunchKernelGGL(fir_resample_nhwc_kernel, dim3((unsigned)std::min<size_t>(cdiv64(total, 256), 65536)), dim3(256), 0, s, in,
+                     out, H, W, C, up, f, total);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
 // ---- small per-op kernels for graphs orchestrated above the C ABI (NCSN++: models/ncsnpp.py of the reference) ----
 // Gaussian Fourier features (models/layerspp.py:32-41): out[b] = [sin(a_bk), cos(a_bk)], a = ((t*W)*2)*pi evaluated
 // in fp32 in that order (the argument reaches ~1e3, so its fp32 rounding is part of the result), sin/cos in fp64

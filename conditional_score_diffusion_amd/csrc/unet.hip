@@ -75,11 +75,12 @@ struct Param {
   const float* ptr = nullptr;
 };
 
-enum ModKind { M_LINEAR, M_CONV3, M_RES, M_ATTN, M_DOWN, M_UP, M_GN };
+enum ModKind { M_LINEAR, M_CONV3, M_RES, M_ATTN, M_DOWN, M_UP, M_GN, M_FOURIER, M_COMBINE };
 struct Module {
   ModKind kind;
   int idx;
   int cin = 0, cout = 0;   // res / conv3 / linear ; attn/down/up/gn use cin as "channels"
+  int up = 0, down = 0;    // NCSN++ ResnetBlockBigGANpp: FIR resampling of h and x inside the block
 };
 
 // one packed convolution weight (+bias): where it lives inside the packed buffer
@@ -98,7 +99,7 @@ struct Net;
 // ---------------------------------------------------------------------------------------------
 // execution plan for one batch size
 // ---------------------------------------------------------------------------------------------
-enum OpKind { OP_ASSEMBLE, OP_TEMB, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_GN_FINAL_TILES, OP_GN_APPLY16, OP_CONV, OP_ATTN, OP_AVGPOOL,
+enum OpKind { OP_ASSEMBLE, OP_TEMB, OP_FOURIER, OP_FIR, OP_GN_APPLY32, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_GN_FINAL_TILES, OP_GN_APPLY16, OP_CONV, OP_ATTN, OP_AVGPOOL,
               OP_UPNEAR, OP_TO_NCHW };
 
 static const size_t NONE = (size_t)-1;
@@ -115,6 +116,7 @@ struct Op {
   GNPlan gp;
   int act = 0;
   int out_external = 0;               // conv writes to the caller's NCHW output
+  float fscale = 1.f;                 // conv: epilogue out_scale
   size_t temb_col = NONE;             // column offset inside dense_all
   int temb_stride = 0;
   int cls = CSD_PROF_OTHER;           // profiling class
@@ -220,9 +222,12 @@ static std::string mname(int idx, const char* sub) {
 }
 
 // ---- module list: mirrors DDPM.__init__ (models/ddpm.py:96-147) -------------------------------
+static int build_modules_ncsnpp(Net& n);
+
 static int build_modules(Net& n) {
   const csd_unet_config& c = n.cfg;
-  CSD_REQUIRE(c.arch == 0, "unet: arch %d not supported (0 = DDPM family)", c.arch);
+  CSD_REQUIRE(c.arch == 0 || c.arch == 1, "unet: arch %d not supported (0 = DDPM family, 1 = NCSN++)", c.arch);
+  if (c.arch == 1) return build_modules_ncsnpp(n);
   CSD_REQUIRE(c.n_levels >= 1 && c.n_levels <= CSD_MAX_LEVELS, "unet: bad n_levels %d", c.n_levels);
   CSD_REQUIRE(c.nf % 32 == 0, "unet: nf=%d must be a multiple of 32 (GroupNorm(32) + 32-wide MFMA tiles)", c.nf);
   CSD_REQUIRE(c.image_size % (1 << (c.n_levels - 1)) == 0, "unet: image_size %d not divisible by 2^%d",
@@ -329,6 +334,130 @@ static int build_modules(Net& n) {
   return CSD_OK;
 }
 
+// ---- NCSN++ module list: mirrors NCSNpp.__init__ (models/ncsnpp.py:44-236) for resblock_type 'biggan', fir = True,
+// progressive in {none, output_skip}, progressive_input in {none, input_skip}, progressive_combine 'sum' ----
+static int ncsnpp_groups(int c) { return std::min(c / 4, 32); }     // layerspp.py:67,219,231; ncsnpp.py:200-233
+
+static int build_modules_ncsnpp(Net& n) {
+  const csd_unet_config& c = n.cfg;
+  CSD_REQUIRE(c.n_levels >= 1 && c.n_levels <= CSD_MAX_LEVELS, "ncsnpp: bad n_levels %d", c.n_levels);
+  CSD_REQUIRE(c.nf % 8 == 0, "ncsnpp: nf=%d must be a multiple of 8", c.nf);
+  CSD_REQUIRE(c.image_size % (1 << (c.n_levels - 1)) == 0, "ncsnpp: image_size %d not divisible by 2^%d", c.image_size,
+              c.n_levels - 1);
+  CSD_REQUIRE(c.x_channels >= 1 && c.x_channels + c.y_channels <= 8, "ncsnpp: x+y channels must be <= 8");
+  CSD_REQUIRE(c.out_channels == c.x_channels + c.y_channels, "ncsnpp: the network maps its %d input channels to as many outputs",
+              c.x_channels + c.y_channels);
+  CSD_REQUIRE(c.act >= CSD_ACT_SWISH && c.act <= CSD_ACT_ELU, "ncsnpp: bad activation id %d", c.act);
+  CSD_REQUIRE(c.precision >= CSD_PREC_F32 && c.precision <= CSD_PREC_F16, "ncsnpp: bad precision id %d", c.precision);
+  CSD_REQUIRE(c.conditional, "ncsnpp: only time-conditional networks are supported");
+  CSD_REQUIRE(c.progressive >= 0 && c.progressive <= 1 && c.progressive_input >= 0 && c.progressive_input <= 1,
+              "ncsnpp: 'residual' progressive growing is not supported");
+  CSD_REQUIRE(c.n_fir == 4, "ncsnpp: a 4-tap FIR kernel is required (got %d taps)", c.n_fir);
+  auto add = [&](ModKind k, int cin, int cout, int up = 0, int down = 0) {
+    Module m;
+    m.kind = k; m.idx = (int)n.mods.size(); m.cin = cin; m.cout = cout; m.up = up; m.down = down;
+    n.mods.push_back(m);
+  };
+  auto is_attn = [&](int res) {
+    for (int i = 0; i < c.n_attn; ++i) if (c.attn_resolutions[i] == res) return true;
+    return false;
+  };
+  const int nf = c.nf, channels = c.x_channels + c.y_channels;
+  int embed_dim = nf;
+  if (c.embedding_type == 1) { add(M_FOURIER, nf, 2 * nf); embed_dim = 2 * nf; }
+  add(M_LINEAR, embed_dim, 4 * nf);
+  add(M_LINEAR, 4 * nf, 4 * nf);
+  add(M_CONV3, channels, nf);
+  std::vector<int> hs_c{nf};
+  int in_ch = nf;
+  for (int l = 0; l < c.n_levels; ++l) {
+    const int res = c.image_size >> l;
+    for (int b = 0; b < c.num_res_blocks; ++b) {
+      const int out_ch = nf * c.ch_mult[l];
+      add(M_RES, in_ch, out_ch);
+      in_ch = out_ch;
+      if (is_attn(res)) add(M_ATTN, in_ch, in_ch);
+      hs_c.push_back(in_ch);
+    }
+    if (l != c.n_levels - 1) {
+      add(M_RES, in_ch, in_ch, 0, 1);
+      if (c.progressive_input == 1) add(M_COMBINE, channels, in_ch);
+      hs_c.push_back(in_ch);
+    }
+  }
+  add(M_RES, in_ch, in_ch);
+  add(M_ATTN, in_ch, in_ch);
+  add(M_RES, in_ch, in_ch);
+  for (int l = c.n_levels - 1; l >= 0; --l) {
+    const int res = c.image_size >> l;
+    for (int b = 0; b < c.num_res_blocks + 1; ++b) {
+      const int out_ch = nf * c.ch_mult[l];
+      add(M_RES, in_ch + hs_c.back(), out_ch);
+      hs_c.pop_back();
+      in_ch = out_ch;
+    }
+    if (is_attn(res)) add(M_ATTN, in_ch, in_ch);
+    if (c.progressive == 1) { add(M_GN, in_ch, in_ch); add(M_CONV3, in_ch, channels); }
+    if (l != 0) add(M_RES, in_ch, in_ch, 1, 0);
+  }
+  if (c.progressive != 1) { add(M_GN, in_ch, in_ch); add(M_CONV3, in_ch, channels); }
+
+  const int temb = 4 * nf;
+  for (auto& m : n.mods) {
+    switch (m.kind) {
+      case M_FOURIER:
+        n.add_param(mname(m.idx, "W"), {m.cin});
+        break;
+      case M_LINEAR:
+        n.add_param(mname(m.idx, "weight"), {m.cout, m.cin});
+        n.add_param(mname(m.idx, "bias"), {m.cout});
+        break;
+      case M_CONV3:
+        n.add_param(mname(m.idx, "weight"), {m.cout, m.cin, 3, 3});
+        n.add_param(mname(m.idx, "bias"), {m.cout});
+        break;
+      case M_GN:
+        n.add_param(mname(m.idx, "weight"), {m.cin});
+        n.add_param(mname(m.idx, "bias"), {m.cin});
+        break;
+      case M_COMBINE:
+        n.add_param(mname(m.idx, "Conv_0.weight"), {m.cout, m.cin, 1, 1});
+        n.add_param(mname(m.idx, "Conv_0.bias"), {m.cout});
+        break;
+      case M_ATTN:
+        n.add_param(mname(m.idx, "GroupNorm_0.weight"), {m.cin});
+        n.add_param(mname(m.idx, "GroupNorm_0.bias"), {m.cin});
+        for (int j = 0; j < 4; ++j) {
+          char w[32], b[32];
+          snprintf(w, sizeof(w), "NIN_%d.W", j);
+          snprintf(b, sizeof(b), "NIN_%d.b", j);
+          n.add_param(mname(m.idx, w), {m.cin, m.cin});
+          n.add_param(mname(m.idx, b), {m.cin});
+        }
+        break;
+      case M_RES:
+        n.add_param(mname(m.idx, "GroupNorm_0.weight"), {m.cin});
+        n.add_param(mname(m.idx, "GroupNorm_0.bias"), {m.cin});
+        n.add_param(mname(m.idx, "Conv_0.weight"), {m.cout, m.cin, 3, 3});
+        n.add_param(mname(m.idx, "Conv_0.bias"), {m.cout});
+        n.add_param(mname(m.idx, "Dense_0.weight"), {m.cout, temb});
+        n.add_param(mname(m.idx, "Dense_0.bias"), {m.cout});
+        n.add_param(mname(m.idx, "GroupNorm_1.weight"), {m.cout});
+        n.add_param(mname(m.idx, "GroupNorm_1.bias"), {m.cout});
+        n.add_param(mname(m.idx, "Conv_1.weight"), {m.cout, m.cout, 3, 3});
+        n.add_param(mname(m.idx, "Conv_1.bias"), {m.cout});
+        if (m.cin != m.cout || m.up || m.down) {
+          n.add_param(mname(m.idx, "Conv_2.weight"), {m.cout, m.cin, 1, 1});
+          n.add_param(mname(m.idx, "Conv_2.bias"), {m.cout});
+        }
+        break;
+      default:
+        break;
+    }
+  }
+  return CSD_OK;
+}
+
 // ---- packed layout ------------------------------------------------------------------------------
 static int proto_conv(ConvPlan* p, int c0, int c1, int cout, int taps) {
   memset(p, 0, sizeof(*p));
@@ -396,7 +525,7 @@ static int build_packed_layout(Net& n) {
   int in_ch = c.nf;
   size_t mi = 0;
   auto next_mod = [&]() -> Module& { return n.mods[mi++]; };
-  if (c.conditional) {
+  if (c.arch == 0 && c.conditional) {
     for (int j = 0; j < 2; ++j) {
       Module& m = next_mod();
       add_copy(mname(m.idx, "weight"));
@@ -404,7 +533,7 @@ static int build_packed_layout(Net& n) {
     }
   }
   int rc;
-  {
+  if (c.arch == 0) {
     Module& m = next_mod();   // stem: Cin padded to 8 (zero weights for the padding channels)
     rc = add_conv(std::to_string(m.idx), n.in_cpad, 0, m.cout, 9,
                   {{n.P(mname(m.idx, "weight")), n.P(mname(m.idx, "bias")), 0, m.cout, 0, m.cin}});
@@ -456,6 +585,106 @@ static int build_packed_layout(Net& n) {
     for (int i = 0; i < c.n_attn; ++i) if (c.attn_resolutions[i] == res) return true;
     return false;
   };
+  if (c.arch == 1) {
+    // ---- NCSN++ (module list of build_modules_ncsnpp): same packed-conv machinery, BigGAN blocks ----
+    auto res_layout_pp = [&](Module& m, int c0, int c1) -> int {
+      const std::string k = std::to_string(m.idx);
+      const bool plain = !m.up && !m.down;
+      add_copy(mname(m.idx, "GroupNorm_0.weight"));
+      add_copy(mname(m.idx, "GroupNorm_0.bias"));
+      // Conv_0 reads the GroupNorm-ed input directly only in plain blocks; up/down blocks feed it the FIR-resampled
+      // activation (an fp32 tensor without a norm)
+      int r = add_conv(k + ".Conv_0", c0, c1, m.cout, 9,
+                       {{n.P(mname(m.idx, "Conv_0.weight")), n.P(mname(m.idx, "Conv_0.bias")), 0, m.cout, 0}}, true, plain);
+      if (r) return r;
+      add_copy(mname(m.idx, "GroupNorm_1.weight"));
+      add_copy(mname(m.idx, "GroupNorm_1.bias"));
+      r = add_conv(k + ".Conv_1", m.cout, 0, m.cout, 9,
+                   {{n.P(mname(m.idx, "Conv_1.weight")), n.P(mname(m.idx, "Conv_1.bias")), 0, m.cout, 0}}, true, true);
+      if (r) return r;
+      if (m.cin != m.cout || m.up || m.down) {
+        r = add_conv(k + ".Conv_2", c0, c1, m.cout, 1,
+                     {{n.P(mname(m.idx, "Conv_2.weight")), n.P(mname(m.idx, "Conv_2.bias")), 0, m.cout, 0}});
+        if (r) return r;
+      }
+      n.dense_col[m.idx] = n.dense_total;
+      n.dense_total += m.cout;
+      return CSD_OK;
+    };
+    auto conv3_layout = [&](Module& m, int cin_pad, bool normed) -> int {
+      return add_conv(std::to_string(m.idx), cin_pad, 0, m.cout, 9,
+                      {{n.P(mname(m.idx, "weight")), n.P(mname(m.idx, "bias")), 0, m.cout, 0, m.cin}}, true, normed);
+    };
+    auto gn_layout = [&](Module& m) {
+      add_copy(mname(m.idx, "weight"));
+      add_copy(mname(m.idx, "bias"));
+    };
+    size_t mj = 0;
+    auto nextm = [&]() -> Module& { return n.mods[mj++]; };
+    if (c.embedding_type == 1) add_copy(mname(nextm().idx, "W"));
+    for (int j = 0; j < 2; ++j) {
+      Module& m = nextm();
+      add_copy(mname(m.idx, "weight"));
+      add_copy(mname(m.idx, "bias"));
+    }
+    if ((rc = conv3_layout(nextm(), n.in_cpad, false))) return rc;      // stem: Cin padded to 8
+    std::vector<int> hc{c.nf};
+    int ich = c.nf;
+    for (int l = 0; l < c.n_levels; ++l) {
+      const int res = c.image_size >> l;
+      cur_res = res;
+      for (int b = 0; b < c.num_res_blocks; ++b) {
+        Module& m = nextm();
+        if ((rc = res_layout_pp(m, ich, 0))) return rc;
+        ich = m.cout;
+        if (is_attn(res)) { if ((rc = attn_layout(nextm()))) return rc; }
+        hc.push_back(ich);
+      }
+      if (l != c.n_levels - 1) {
+        cur_res = res >> 1;
+        if ((rc = res_layout_pp(nextm(), ich, 0))) return rc;
+        if (c.progressive_input == 1) {
+          Module& m = nextm();      // Combine: 1x1 conv of the (8-channel padded) input pyramid
+          rc = add_conv(std::to_string(m.idx) + ".Conv_0", n.in_cpad, 0, m.cout, 1,
+                        {{n.P(mname(m.idx, "Conv_0.weight")), n.P(mname(m.idx, "Conv_0.bias")), 0, m.cout, 0, m.cin}});
+          if (rc) return rc;
+        }
+        hc.push_back(ich);
+      }
+    }
+    if ((rc = res_layout_pp(nextm(), ich, 0))) return rc;
+    if ((rc = attn_layout(nextm()))) return rc;
+    if ((rc = res_layout_pp(nextm(), ich, 0))) return rc;
+    for (int l = c.n_levels - 1; l >= 0; --l) {
+      const int res = c.image_size >> l;
+      cur_res = res;
+      for (int b = 0; b < c.num_res_blocks + 1; ++b) {
+        Module& m = nextm();
+        const int skip = hc.back();
+        hc.pop_back();
+        if ((rc = res_layout_pp(m, ich, skip))) return rc;
+        ich = m.cout;
+      }
+      if (is_attn(res)) { if ((rc = attn_layout(nextm()))) return rc; }
+      if (c.progressive == 1) {
+        gn_layout(nextm());
+        if ((rc = conv3_layout(nextm(), ich, true))) return rc;
+      }
+      if (l != 0) {
+        cur_res = res << 1;
+        if ((rc = res_layout_pp(nextm(), ich, 0))) return rc;
+      }
+    }
+    if (c.progressive != 1) {
+      gn_layout(nextm());
+      if ((rc = conv3_layout(nextm(), ich, true))) return rc;
+    }
+    CSD_REQUIRE(mj == n.mods.size(), "ncsnpp: internal module walk mismatch");
+    n.dense_all_off = take((size_t)n.dense_total * 4 * c.nf);
+    n.dense_all_bias_off = take((size_t)n.dense_total);
+    n.packed_floats = off;
+    return CSD_OK;
+  }
   for (int l = 0; l < c.n_levels; ++l) {
     const int res = c.image_size >> l;
     cur_res = res;
@@ -512,6 +741,7 @@ struct Builder {
   int B;
   size_t gn_partial = NONE, nscale = NONE, nshift = NONE;   // shared scratch
   size_t dense_all = NONE;
+  float pending_scale = 1.f;          // out_scale of the NEXT conv() (NCSN++ skip_rescale: (x + h)/sqrt(2))
   int rc = CSD_OK;
   // tensors whose producing conv left per-tile GroupNorm partials behind: workspace offset -> (partials, tiles per sample)
   struct TileStats { size_t off; int tpi; };
@@ -533,6 +763,7 @@ struct Builder {
 
   // GroupNorm statistics of (src0|src1) -> nscale/nshift
   void gn(size_t src0, size_t src1, int c0, int c1, int hw, const std::string& gname, const std::string& bname) {
+    const int G = n.cfg.arch == 1 ? ncsnpp_groups(c0 + c1) : 32;
     const auto t0 = tile_stats.find(src0);
     const auto t1 = src1 == NONE ? tile_stats.end() : tile_stats.find(src1);
     if (t0 != tile_stats.end() && (src1 == NONE || t1 != tile_stats.end())) {
@@ -542,6 +773,7 @@ struct Builder {
       f.a = t0->second.off; f.i0 = t0->second.tpi; f.i1 = c0;
       f.b = src1 == NONE ? NONE : t1->second.off; f.i2 = src1 == NONE ? 0 : t1->second.tpi; f.i3 = c1;
       f.i4 = hw;
+      f.gp.G = G;
       f.pk0 = n.copy_off.at(gname); f.pk1 = n.copy_off.at(bname);
       f.out = nscale; f.c = nshift;
       f.cls = CSD_PROF_GN_FINAL;
@@ -552,7 +784,7 @@ struct Builder {
     }
     Op s;
     s.kind = OP_GN_STATS;
-    if (gn_plan(&s.gp, B, hw, c0, c1, 32)) { rc = CSD_ERR_INVALID; return; }
+    if (gn_plan(&s.gp, B, hw, c0, c1, G)) { rc = CSD_ERR_INVALID; return; }
     s.a = src0; s.b = src1; s.out = gn_partial;
     s.cls = CSD_PROF_GN_STATS; s.bytes = (double)B * hw * (c0 + c1) * 4;
     pl.ops.push_back(s);
@@ -624,6 +856,8 @@ struct Builder {
       o.i3 = 1;                                   // in16
     }
     o.temb_base = dense_all;
+    o.fscale = pending_scale;
+    pending_scale = 1.f;
     o.act = act;
     o.temb_col = temb_col;
     o.temb_stride = n.dense_total;
@@ -659,15 +893,68 @@ struct Builder {
     gn(h1, NONE, m.cout, 0, hw, mname(m.idx, "GroupNorm_1.weight"), mname(m.idx, "GroupNorm_1.bias"));
     size_t shortcut = x0, sc_buf = NONE;
     if (m.cin != m.cout) {
-      sc_buf = conv(k + ".NIN_0", x0, x1, hw_side, hw_side, 1, 0, 0, false, 0, NONE, NONE, false);
+      sc_buf = conv(k + (n.cfg.arch == 1 ? ".Conv_2" : ".NIN_0"), x0, x1, hw_side, hw_side, 1, 0, 0, false, 0, NONE, NONE, false);
       shortcut = sc_buf;
     } else if (x1 != NONE) {
       set_error("res block %d: identity shortcut on a concatenated input is not supported", m.idx);
       rc = CSD_ERR_INVALID;
     }
+    pending_scale = skip_scale();
     const size_t out = conv(k + ".Conv_1", h1, NONE, hw_side, hw_side, 1, 1, 0, true, n.cfg.act, shortcut, NONE, false);
     ar.release(h1);
     ar.release(sc_buf);
+    return out;
+  }
+
+  float skip_scale() const { return (n.cfg.arch == 1 && n.cfg.skip_rescale) ? 0.70710678118654752440f : 1.f; }
+
+  // ---- NCSN++ pieces (models/layerspp.py, models/up_or_down_sampling.py) ----
+  // FIR resampling of an fp32 NHWC tensor: upsample_2d / downsample_2d with the config's 4-tap kernel
+  size_t fir(size_t src, int side, int C, bool up) {
+    Op o;
+    o.kind = OP_FIR;
+    o.a = src; o.i0 = side; o.i1 = C; o.i2 = up ? 1 : 0;
+    const int os = up ? side * 2 : side / 2;
+    o.out = alloc_((size_t)B * os * os * C);
+    o.cls = CSD_PROF_OTHER;
+    pl.ops.push_back(o);
+    pl.launches += 1;
+    return o.out;
+  }
+
+  // act(GroupNorm(x)) materialised in fp32 (the up/down blocks resample it before Conv_0)
+  size_t gn_apply32(size_t src, int C, int hw, int act) {
+    Op o;
+    o.kind = OP_GN_APPLY32;
+    o.a = src; o.d = nscale; o.e = nshift; o.i0 = C; o.i1 = hw; o.act = act;
+    o.out = alloc_((size_t)B * hw * C);
+    o.cls = CSD_PROF_GN_APPLY;
+    o.bytes = (double)B * hw * C * 8;
+    pl.ops.push_back(o);
+    pl.launches += 1;
+    return o.out;
+  }
+
+  // ResnetBlockBigGANpp with up / down (layerspp.py:242-274): GN0+act -> FIR(h), FIR(x) -> Conv_0 (+temb) -> GN1+act
+  // -> Conv_1 + Conv_2(x') ; (x + h)/sqrt(2)
+  size_t res_block_updown(const Module& m, size_t x, int side) {
+    const std::string k = std::to_string(m.idx);
+    const int hw = side * side, os = m.up ? side * 2 : side / 2;
+    gn(x, NONE, m.cin, 0, hw, mname(m.idx, "GroupNorm_0.weight"), mname(m.idx, "GroupNorm_0.bias"));
+    const size_t ha = gn_apply32(x, m.cin, hw, n.cfg.act);
+    const size_t hr = fir(ha, side, m.cin, m.up != 0);
+    ar.release(ha);
+    const size_t xr = fir(x, side, m.cin, m.up != 0);
+    const size_t tcol = (size_t)n.dense_col.at(m.idx);
+    const size_t h1 = conv(k + ".Conv_0", hr, NONE, os, os, 1, 1, 0, false, 0, NONE, tcol, false);
+    ar.release(hr);
+    gn(h1, NONE, m.cout, 0, os * os, mname(m.idx, "GroupNorm_1.weight"), mname(m.idx, "GroupNorm_1.bias"));
+    const size_t sc = conv(k + ".Conv_2", xr, NONE, os, os, 1, 0, 0, false, 0, NONE, NONE, false);
+    ar.release(xr);
+    pending_scale = skip_scale();
+    const size_t out = conv(k + ".Conv_1", h1, NONE, os, os, 1, 1, 0, true, n.cfg.act, sc, NONE, false);
+    ar.release(h1);
+    ar.release(sc);
     return out;
   }
 
@@ -683,6 +970,7 @@ struct Builder {
     a.cls = CSD_PROF_ATTENTION;
     pl.ops.push_back(a);
     count(4.0 * B * (double)L * L * C, 0);
+    pending_scale = skip_scale();
     const size_t o = conv(k + ".NIN_3", a.out, NONE, hw_side, hw_side, 1, 0, 0, false, 0, x, NONE, false);
     ar.release(qkv);
     ar.release(a.out);
@@ -717,6 +1005,179 @@ static int build_plan(Net& n, int B, Plan** out) {
   }
   size_t mi = 0;
   auto next_mod = [&]() -> const Module& { return n.mods[mi++]; };
+
+  if (c.arch == 1) {
+    // ================= NCSN++: NCSNpp.forward (models/ncsnpp.py:238-388) =================
+    const int channels = c.x_channels + c.y_channels;
+    auto is_attn1 = [&](int res) {
+      for (int i = 0; i < c.n_attn; ++i) if (c.attn_resolutions[i] == res) return true;
+      return false;
+    };
+    Op as;
+    as.kind = OP_ASSEMBLE;
+    as.out = bd.alloc_((size_t)B * S * S * n.in_cpad);
+    pl.ops.push_back(as);
+    pl.launches += 1;
+    // time embedding: Fourier features of the label (or the sinusoidal embedding), two Linear layers, all Dense_0
+    size_t emb;
+    int emb_dim = nf;
+    if (c.embedding_type == 1) {
+      const Module& fm = next_mod();
+      Op e;
+      e.kind = OP_FOURIER;
+      e.pk0 = n.copy_off.at(mname(fm.idx, "W"));
+      e.i0 = nf;
+      e.out = bd.alloc_((size_t)B * 2 * nf);
+      pl.ops.push_back(e);
+      emb = e.out;
+      emb_dim = 2 * nf;
+    } else {
+      Op e;
+      e.kind = OP_TEMB;
+      e.out = bd.alloc_((size_t)B * nf);
+      e.i0 = nf;
+      pl.ops.push_back(e);
+      emb = e.out;
+    }
+    {
+      const Module& l0 = next_mod();
+      const Module& l1 = next_mod();
+      Op a;
+      a.kind = OP_LINEAR;
+      a.a = emb; a.out = bd.alloc_((size_t)B * 4 * nf);
+      a.pk0 = n.copy_off.at(mname(l0.idx, "weight")); a.pk1 = n.copy_off.at(mname(l0.idx, "bias"));
+      a.i0 = emb_dim; a.i1 = 4 * nf; a.act = CSD_ACT_NONE;
+      pl.ops.push_back(a);
+      Op b2;
+      b2.kind = OP_LINEAR;
+      b2.a = a.out; b2.out = bd.alloc_((size_t)B * 4 * nf);
+      b2.pk0 = n.copy_off.at(mname(l1.idx, "weight")); b2.pk1 = n.copy_off.at(mname(l1.idx, "bias"));
+      b2.i0 = 4 * nf; b2.i1 = 4 * nf; b2.act = c.act;
+      pl.ops.push_back(b2);
+      Op d;
+      d.kind = OP_LINEAR;   // every block's Dense_0(act(temb)) in one launch
+      d.a = b2.out; d.out = bd.alloc_((size_t)B * n.dense_total);
+      d.pk0 = n.dense_all_off; d.pk1 = n.dense_all_bias_off;
+      d.i0 = 4 * nf; d.i1 = n.dense_total; d.act = c.act;
+      pl.ops.push_back(d);
+      bd.dense_all = d.out;
+      pl.launches += 4;
+      pl.flops += 2.0 * B * ((double)emb_dim * 4 * nf + 16.0 * nf * nf + 4.0 * nf * n.dense_total);
+    }
+    struct Skip { size_t off; int ch; };
+    std::vector<Skip> hs;
+    size_t pyr_in = c.progressive_input == 1 ? as.out : NONE;     // input pyramid (8-channel padded NHWC)
+    int pyr_side = S;
+    {
+      const Module& m = next_mod();
+      const size_t h0 = bd.conv(std::to_string(m.idx), as.out, NONE, S, S, 1, 1, 0, false, 0, NONE, NONE, false, channels);
+      hs.push_back({h0, m.cout});
+    }
+    int in_ch = nf;
+    for (int l = 0; l < c.n_levels; ++l) {
+      const int side = S >> l;
+      for (int b = 0; b < c.num_res_blocks; ++b) {
+        const Module& m = next_mod();
+        size_t h = bd.res_block(m, hs.back().off, NONE, in_ch, 0, side);
+        in_ch = m.cout;
+        if (is_attn1(side)) {
+          const Module& am = next_mod();
+          const size_t h2 = bd.attn_block(am, h, side);
+          bd.ar.release(h);
+          h = h2;
+        }
+        hs.push_back({h, in_ch});
+      }
+      if (l != c.n_levels - 1) {
+        const Module& m = next_mod();
+        size_t h = bd.res_block_updown(m, hs.back().off, side);
+        if (c.progressive_input == 1) {
+          const Module& cm = next_mod();
+          const size_t pn = bd.fir(pyr_in, pyr_side, n.in_cpad, false);      // pyramid_downsample (FIR, no conv)
+          if (pyr_in != as.out) bd.ar.release(pyr_in);
+          pyr_in = pn;
+          pyr_side /= 2;
+          // Combine 'sum' (layerspp.py:53-57): Conv_0(input_pyramid) + h
+          const size_t hc2 = bd.conv(std::to_string(cm.idx) + ".Conv_0", pyr_in, NONE, side / 2, side / 2, 1, 0, 0, false, 0, h,
+                                     NONE, false, channels);
+          bd.ar.release(h);
+          h = hc2;
+        }
+        hs.push_back({h, in_ch});
+      }
+    }
+    if (pyr_in != NONE && pyr_in != as.out) bd.ar.release(pyr_in);
+    bd.ar.release(as.out);
+    size_t h = hs.back().off;
+    {
+      const int side = S >> (c.n_levels - 1);
+      const Module& r0 = next_mod();
+      size_t t0 = bd.res_block(r0, h, NONE, in_ch, 0, side);
+      const Module& am = next_mod();
+      size_t t1 = bd.attn_block(am, t0, side);
+      bd.ar.release(t0);
+      const Module& r1 = next_mod();
+      size_t t2 = bd.res_block(r1, t1, NONE, in_ch, 0, side);
+      bd.ar.release(t1);
+      h = t2;
+    }
+    size_t pyr = NONE;      // output pyramid [B, side, side, channels]
+    for (int l = c.n_levels - 1; l >= 0; --l) {
+      const int side = S >> l;
+      for (int b = 0; b < c.num_res_blocks + 1; ++b) {
+        const Module& m = next_mod();
+        const Skip sk = hs.back();
+        hs.pop_back();
+        const size_t o = bd.res_block(m, h, sk.off, in_ch, sk.ch, side);
+        bd.ar.release(h);
+        bd.ar.release(sk.off);
+        h = o;
+        in_ch = m.cout;
+      }
+      if (is_attn1(side)) {
+        const Module& am = next_mod();
+        const size_t o = bd.attn_block(am, h, side);
+        bd.ar.release(h);
+        h = o;
+      }
+      if (c.progressive == 1) {
+        const Module& g = next_mod();
+        const Module& cm = next_mod();
+        size_t res = NONE;
+        if (pyr != NONE) {
+          res = bd.fir(pyr, side / 2, channels, true);                       // pyramid_upsample
+          bd.ar.release(pyr);
+        }
+        bd.gn(h, NONE, in_ch, 0, side * side, mname(g.idx, "weight"), mname(g.idx, "bias"));
+        const bool last = (l == 0);
+        const size_t po = bd.conv(std::to_string(cm.idx), h, NONE, side, side, 1, 1, 0, true, c.act, res, NONE, last);
+        bd.ar.release(res);
+        pyr = po;        // (NONE when written straight to the caller's NCHW output)
+      }
+      if (l != 0) {
+        const Module& m = next_mod();
+        const size_t o = bd.res_block_updown(m, h, side);
+        bd.ar.release(h);
+        h = o;
+      }
+    }
+    if (c.progressive != 1) {
+      const Module& g = next_mod();
+      bd.gn(h, NONE, in_ch, 0, S * S, mname(g.idx, "weight"), mname(g.idx, "bias"));
+      const Module& m = next_mod();
+      bd.conv(std::to_string(m.idx), h, NONE, S, S, 1, 1, 0, true, c.act, NONE, NONE, true);
+    }
+    bd.ar.release(h);
+    if (bd.rc) return bd.rc;
+    CSD_REQUIRE(mi == n.mods.size() && hs.empty(), "ncsnpp: plan walk mismatch");
+    double pbytes1 = 0;
+    for (auto& p : n.params) pbytes1 += 4.0 * p.numel;
+    pl.bytes += pbytes1;
+    pl.ws_floats = bd.ar.peak();
+    *out = plp.get();
+    n.plans[B] = std::move(plp);
+    return CSD_OK;
+  }
 
   // ---- input + time embedding ----
   Op as;
@@ -886,6 +1347,15 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
       case OP_TEMB:
         rc = timestep_embedding_launch(labels, W(o.out), B, o.i0, s);
         break;
+      case OP_FOURIER:
+        rc = fourier_embedding_launch(labels, pk + o.pk0, W(o.out), B, o.i0, s);
+        break;
+      case OP_FIR:
+        rc = fir_resample_nhwc_launch(W(o.a), W(o.out), B, o.i0, o.i0, o.i1, c.fir_kernel, o.i2, s);
+        break;
+      case OP_GN_APPLY32:
+        rc = gn_apply_launch(W(o.a), W(o.d), W(o.e), W(o.out), B, o.i1, o.i0, o.act, s);
+        break;
       case OP_LINEAR:
         rc = linear_launch(W(o.a), pk + o.pk0, pk + o.pk1, W(o.out), B, o.i0, o.i1, o.act, s);
         break;
@@ -898,7 +1368,7 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         break;
       case OP_GN_FINAL_TILES:
         rc = gn_finalize_tiles_launch(reinterpret_cast<const double*>(W(o.a)), o.i0, o.i1,
-                                      reinterpret_cast<const double*>(W(o.b)), o.i2, o.i3, B, o.i4, 32, pk + o.pk0,
+                                      reinterpret_cast<const double*>(W(o.b)), o.i2, o.i3, B, o.i4, o.gp.G, pk + o.pk0,
                                       pk + o.pk1, 1e-6f, W(o.out), W(o.c), s);
         break;
       case OP_GN_APPLY16:
@@ -917,7 +1387,7 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         a.out_stride = o.cp.Cout; a.out_coff = 0;
         a.out_nchw = o.out_external;
         a.act = o.act;
-        a.out_scale = 1.f;
+        a.out_scale = o.fscale;
         a.dbg = nullptr;
         a.stats = reinterpret_cast<double*>(W(o.stats));
         rc = o.i2 == 2 ? conv16q_launch(o.cp, o.i4, a, s)

@@ -64,7 +64,7 @@ class HipUNet(nn.Module):
         self.conditional = bool(m.conditional)
         self.centered = bool(d.centered)
         self.image_size = int(d.effective_image_size)
-        self.out_channels = int(m.output_channels)
+        self.out_channels = int(self._out_channels(config))
         self.x_channels, self.y_channels = self._channels(config)
         act = m.nonlinearity.lower()
         if act not in _lib.ACT_IDS or act == 'none':
@@ -86,6 +86,7 @@ class HipUNet(nn.Module):
         cfg.centered = int(self.centered)
         cfg.act = _lib.ACT_IDS[act]
         cfg.precision = _lib.PREC_IDS[precision]
+        self._extra_config(cfg, config)
         self._cfg = cfg
         self._h = ctypes.c_void_p()
         check(lib().csd_unet_create(ctypes.byref(cfg), ctypes.byref(self._h)), 'unet_create')
@@ -98,6 +99,12 @@ class HipUNet(nn.Module):
     # -- parameters ------------------------------------------------------------------------------
     def _channels(self, config):
         raise NotImplementedError
+
+    def _out_channels(self, config):
+        return config.model.output_channels
+
+    def _extra_config(self, cfg, config):
+        """hook: architecture-specific fields of csd_unet_config"""
 
     def _param_table(self):
         n = lib().csd_unet_num_params(self._h)

@@ -26,7 +26,7 @@ import torch.nn as nn
 from .. import _lib, ops
 from .._lib import require_gpu_tensor
 from . import utils
-from .ddpm import _Node, _fan_avg_uniform
+from .ddpm import HipUNet, _Node, _fan_avg_uniform
 
 
 def _groups(c):
@@ -325,7 +325,6 @@ class NCSNpp(nn.Module):
         return h
 
 
-utils.register_model(NCSNpp, name='ncsnpp')
 
 
 class NCSNpp_paired(NCSNpp):
@@ -338,4 +337,94 @@ class NCSNpp_paired(NCSNpp):
         return {'x': out[:, :xc], 'y': out[:, xc:]}
 
 
-utils.register_model(NCSNpp_paired, name='ncsnpp_paired')
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Planned-graph executor (csrc/unet.hip, arch 1): the same NHWC kernels, fused GroupNorm statistics, fp16-MFMA conv
+# schedules and fused PC loop as the DDPM family.  These are the classes the registry hands out; the operator-granular
+# classes above stay available as ``ncsnpp_ops`` / ``ncsnpp_paired_ops`` (A/B reference for the graph executor).
+# ------------------------------------------------------------------------------------------------------------------
+class HipNCSNpp(HipUNet):
+    arch = 1
+
+    def __init__(self, config, precision=None):
+        m = config.model
+        if m.resblock_type.lower() != 'biggan':
+            raise NotImplementedError("ncsnpp on the HIP path: resblock_type 'biggan' only (got %r)" % m.resblock_type)
+        if not m.fir:
+            raise NotImplementedError('ncsnpp on the HIP path: fir=True only')
+        if m.progressive.lower() == 'residual' or m.progressive_input.lower() == 'residual':
+            raise NotImplementedError("ncsnpp on the HIP path: 'residual' progressive growing is not provided yet")
+        if m.progressive_combine.lower() != 'sum':
+            raise NotImplementedError("ncsnpp on the HIP path: progressive_combine 'sum' only")
+        if not m.conditional:
+            raise NotImplementedError('ncsnpp on the HIP path: time-conditional networks only')
+        assert m.progressive.lower() in ['none', 'output_skip'] and m.progressive_input.lower() in ['none', 'input_skip']
+        assert m.embedding_type.lower() in ['fourier', 'positional']
+        if m.embedding_type.lower() == 'fourier':
+            assert config.training.continuous, "Fourier features are only used for continuous training."
+        self.embedding_type = m.embedding_type.lower()
+        self._fourier_scale = float(m.get('fourier_scale', 16) if hasattr(m, 'get') else getattr(m, 'fourier_scale', 16))
+        self._init_scale = float(m.init_scale)
+        self._pyramid_out = m.progressive.lower() == 'output_skip'
+        super().__init__(config, precision)
+        self._reinit_special()
+
+    def _out_channels(self, config):
+        return config.data.num_channels
+
+    def _extra_config(self, cfg, config):
+        m = config.model
+        cfg.skip_rescale = int(bool(m.skip_rescale))
+        cfg.progressive = 1 if m.progressive.lower() == 'output_skip' else 0
+        cfg.progressive_input = 1 if m.progressive_input.lower() == 'input_skip' else 0
+        cfg.embedding_type = 1 if m.embedding_type.lower() == 'fourier' else 0
+        taps = list(m.fir_kernel)
+        if len(taps) != 4:
+            raise NotImplementedError('ncsnpp on the HIP path: 4-tap FIR kernels only (got %r)' % (taps,))
+        cfg.n_fir = 4
+        for i, v in enumerate(taps):
+            cfg.fir_kernel[i] = float(v)
+
+    def _reinit_special(self):
+        """initialisation the generic rules of HipUNet._build_params do not cover: the Gaussian Fourier W
+        (layerspp.py:37) and the init_scale of the pyramid / output convolutions (ncsnpp.py:203-233)."""
+        sd = dict(self.named_parameters())
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k.endswith('.W') and v.dim() == 1:
+                    v.copy_(torch.randn(v.shape) * self._fourier_scale)
+                    v.requires_grad_(False)
+                parts = k.split('.')
+                if len(parts) == 3 and parts[2] == 'weight' and v.dim() == 4 and v.shape[0] == self.out_channels:
+                    v.copy_(_fan_avg_uniform(tuple(v.shape), self._init_scale, False))
+
+
+class NCSNppPlanned(HipNCSNpp):
+    """``ncsnpp`` (models/ncsnpp.py:39-388): ``model(x, time_cond) -> Tensor``."""
+
+    def _channels(self, config):
+        return int(config.data.num_channels), 0
+
+    def forward(self, x, time_cond):
+        return self._run(x, None, time_cond)
+
+
+class NCSNppPairedPlanned(HipNCSNpp):
+    """``ncsnpp_paired`` (models/ncsnpp.py:390-401): ``model({'x','y'}, labels) -> {'x','y'}``."""
+
+    def _channels(self, config):
+        d = config.data
+        cx = int(d.shape_x[0]) if ('shape_x' in d if hasattr(d, '__contains__') else hasattr(d, 'shape_x')) else int(d.num_channels) // 2
+        return cx, int(d.num_channels) - cx
+
+    def forward(self, input_dict, labels):
+        out = self._run(input_dict['x'], input_dict['y'], labels)
+        c = self.x_channels
+        return {'x': out[:, :c], 'y': out[:, c:]}
+
+
+utils.register_model(NCSNppPlanned, name='ncsnpp')
+utils.register_model(NCSNppPairedPlanned, name='ncsnpp_paired')
+utils.register_model(NCSNpp, name='ncsnpp_ops')
+utils.register_model(NCSNpp_paired, name='ncsnpp_paired_ops')

@@ -80,7 +80,7 @@ int csd_profile_stop(int n_classes, double* ms, int64_t* launches, double* flops
 #define CSD_MAX_ATTN 8
 
 typedef struct csd_unet_config {
-  int32_t arch;                 /* 0 = DDPM family (models/ddpm.py)                         */
+  int32_t arch;                 /* 0 = DDPM family (models/ddpm.py); 1 = NCSN++ (models/ncsnpp.py), see below */
   int32_t nf;                   /* config.model.nf                                           */
   int32_t n_levels;             /* len(config.model.ch_mult)                                 */
   int32_t ch_mult[CSD_MAX_LEVELS];
@@ -96,6 +96,13 @@ typedef struct csd_unet_config {
   int32_t centered;             /* config.data.centered: 0 -> h = 2x-1 (models/ddpm.py:163-168)*/
   int32_t act;                  /* CSD_ACT_*                                                 */
   int32_t precision;            /* CSD_PREC_*                                                */
+  /* ---- arch 1 (NCSN++, models/ncsnpp.py:44-236) only; resblock_type 'biggan', fir = True, combine 'sum' ---- */
+  int32_t skip_rescale;         /* config.model.skip_rescale: (x + h)/sqrt(2)                */
+  int32_t progressive;          /* 0 'none', 1 'output_skip'                                 */
+  int32_t progressive_input;    /* 0 'none', 1 'input_skip'                                  */
+  int32_t embedding_type;       /* 0 'positional', 1 'fourier' (W [nf] is parameter all_modules.0.W) */
+  int32_t n_fir;                /* taps of config.model.fir_kernel (<= 8)                    */
+  float fir_kernel[8];
 } csd_unet_config;
 
 typedef struct csd_unet csd_unet;

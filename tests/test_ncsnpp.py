@@ -129,3 +129,38 @@ def test_larger_config_vs_oracle():
         got = torch.cat([r['x'], r['y']], dim=1).cpu()
         ref = so.ncsnpp_forward(p, cfg, x, labels)
     assert (got - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_fused_pc_loop_on_ncsnpp_vs_oracle():
+    """The planned NCSN++ executor shares the fused device PC loop (csd_pc_sample) with the DDPM family: 6-step
+    unconditional sampling with a noise tape and Fourier labels (log sigma) against the oracle's PC loop around
+    oracle.ncsnpp_forward."""
+    import score_oracle as so
+    from conditional_score_diffusion_amd import sde_lib
+    from conditional_score_diffusion_amd.models import utils as mutils
+    from conditional_score_diffusion_amd.sampling import correctors, predictors, unconditional
+    cfg, B, _, _ = cases.ncsnpp_case('ncsnpp_fourier_skip')
+    dev = torch.device('cuda:0')
+    model = mutils.create_model(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    p = cases.ncsnpp_params(shapes, 5)
+    model.load_state_dict(p)
+    model = model.to(dev).eval()
+    smin, smax, P = 0.01, 50., 6
+    sde = sde_lib.VESDE(sigma_min=smin, sigma_max=smax, N=1000)
+    shape = (B, 3, 16, 16)
+    tp = cases.tape([shape] * (1 + 2 * P), seed=21)
+    fn = unconditional.get_pc_sampler(sde, shape, predictors.get_predictor('reverse_diffusion'),
+                                      correctors.get_corrector('langevin'), snr=0.075, p_steps=P, c_steps=1, continuous=True,
+                                      denoise=True, eps=1e-5)
+    got, info = fn(model, noise_tape=tp)             # noise_tape is only accepted by the fused path
+    ve = so.VE(smin, smax, 1000)
+
+    def score_fn(x, t):
+        std = ve.std(t)
+        return so.ncsnpp_forward(p, cfg, x, torch.log(std)) / std[:, None, None, None]
+
+    with torch.no_grad():
+        ref = so.pc_sample_unconditional(score_fn, shape, so.NoiseTape(tp), ve, p_steps=P, snr=0.075, eps=1e-5, denoise=True)
+    assert (got.cpu() - ref).abs().max().item() / smax < 2e-4

@@ -39,8 +39,8 @@ def cmde128(B=64, steps=20):
                       'precision': prec, 'batch': B, 'ms_per_pc_step': t_step * 1e3, 'images_per_sec_1000_steps': B / (1000 * t_step)}))
 
 
-def ncsnpp(B=8, reps=3):
-    cfg = cases.make_ncsnpp_config(name='ncsnpp_paired', channels=6, nf=96, ch_mult=(1, 1, 2, 2, 3, 3), num_res_blocks=2,
+def ncsnpp(name='ncsnpp_paired', B=8, reps=3):
+    cfg = cases.make_ncsnpp_config(name=name, channels=6, nf=96, ch_mult=(1, 1, 2, 2, 3, 3), num_res_blocks=2,
                                    attn_resolutions=(20, 10, 5), image_size=160, embedding_type='positional')
     cfg.model.csd_precision = prec
     model = mutils.create_model(cfg)
@@ -56,11 +56,13 @@ def ncsnpp(B=8, reps=3):
         for _ in range(reps):
             model({'x': x, 'y': y}, lab)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
-    print(json.dumps({'workload': 'NCSN++ (ncsnpp_paired) with the SR3-160 hyper-parameters, forward only, operator-granular executor',
+    print(json.dumps({'workload': 'NCSN++ (%s) with the SR3-160 hyper-parameters, forward only' % name,
                       'precision': prec, 'batch': B, 'ms_per_forward': dt * 1e3, 'images_per_sec_per_nfe': B / dt,
                       'params': sum(v.numel() for v in model.state_dict().values())}))
 
 
 if __name__ == '__main__':
     cmde128()
-    ncsnpp()
+    ncsnpp('ncsnpp_paired', 8)
+    ncsnpp('ncsnpp_paired_ops', 8)
+    ncsnpp('ncsnpp_paired', 64)
