@@ -52,9 +52,9 @@ def test_two_rank_sharded_sampling_gloo():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=300)
         assert p.exitcode == 0
     y = torch.arange(8 * 3 * 2 * 2, dtype=torch.float32).reshape(8, 3, 2, 2)
     expect = torch.cat([y[:4] * 2 + float(D.rank_seed(5, 0) % 97), y[4:] * 2 + float(D.rank_seed(5, 1) % 97)])
@@ -122,9 +122,9 @@ def test_global_norm_langevin_equals_single_process_gloo():
     procs = [ctx.Process(target=_global_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=300)
         assert p.exitcode == 0
     got, got_mean = torch.cat([r[1] for r in res]), torch.cat([r[2] for r in res])
     # the reference's Langevin corrector (sampling/correctors.py:88-108, alpha = 1) on the whole batch in ONE process
