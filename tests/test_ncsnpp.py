@@ -164,3 +164,30 @@ def test_fused_pc_loop_on_ncsnpp_vs_oracle():
     with torch.no_grad():
         ref = so.pc_sample_unconditional(score_fn, shape, so.NoiseTape(tp), ve, p_steps=P, snr=0.075, eps=1e-5, denoise=True)
     assert (got.cpu() - ref).abs().max().item() / smax < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision,tol', [('fp16x3', 5e-5), ('fp32', 5e-5)])
+def test_full_size_ncsnpp_160_vs_oracle(precision, tol):
+    """NCSN++ with the SR3-160 hyper-parameters (nf=96, ch_mult (1,1,2,2,3,3), attention at 20/10/5, 6 -> 6 channels,
+    input/output skips, B = 2): the planned executor at the sizes the quad / loader-consumer / pointwise kernels and the
+    unmasked-tile GroupNorm fusion actually run at, against the CPU oracle."""
+    import score_oracle as so
+    from conditional_score_diffusion_amd.models import utils as mutils
+    cfg = cases.make_ncsnpp_config(name='ncsnpp_paired', channels=6, nf=96, ch_mult=(1, 1, 2, 2, 3, 3), num_res_blocks=2,
+                                   attn_resolutions=(20, 10, 5), image_size=160, embedding_type='positional')
+    cfg.model.csd_precision = precision
+    dev = torch.device('cuda:0')
+    model = mutils.create_model(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    p = cases.ncsnpp_params(shapes, 2)
+    model.load_state_dict(p)
+    model = model.to(dev).eval()
+    rs = np.random.RandomState(8)
+    x = torch.from_numpy(rs.uniform(-1, 2, size=(2, 6, 160, 160)).astype(np.float32))
+    labels = torch.tensor([17.0, 803.0])
+    with torch.no_grad():
+        r = model({'x': x[:, :3].to(dev), 'y': x[:, 3:].to(dev)}, labels.to(dev))
+        got = torch.cat([r['x'], r['y']], dim=1).cpu()
+        ref = so.ncsnpp_forward(p, cfg, x, labels)
+    assert (got - ref).abs().max().item() <= tol * ref.abs().max().item()
