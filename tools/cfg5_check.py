@@ -1,0 +1,28 @@
+import sys, os, time
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/oracle')
+import numpy as np, torch
+import cases, score_oracle as so
+from conditional_score_diffusion_amd.models import utils as mutils
+cfg = cases.make_ncsnpp_config(name='ncsnpp', channels=3, nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2,
+                               attn_resolutions=(16,), image_size=256, embedding_type='fourier')
+cfg.model.csd_precision = sys.argv[1] if len(sys.argv) > 1 else 'fp16x3'
+dev = torch.device('cuda:0')
+model = mutils.create_model(cfg)
+shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+print('params', sum(int(np.prod(s)) for s in shapes.values()))
+p = cases.ncsnpp_params(shapes, 3)
+model.load_state_dict(p); model = model.to(dev).eval()
+rs = np.random.RandomState(8)
+x = torch.from_numpy(rs.uniform(-1, 2, size=(1, 3, 256, 256)).astype(np.float32))
+labels = torch.tensor([np.log(3.7)], dtype=torch.float32)
+with torch.no_grad():
+    got = model(x.to(dev), labels.to(dev)).cpu()
+    t0 = time.time(); ref = so.ncsnpp_forward(p, cfg, x, labels); print('oracle %.1f s' % (time.time() - t0))
+print('rel err', float((got - ref).abs().max() / ref.abs().max()))
+B = 8
+xb = torch.randn(B, 3, 256, 256, device=dev); lb = torch.full((B,), 1.0, device=dev)
+with torch.no_grad():
+    model(xb, lb); torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(3): model(xb, lb)
+    torch.cuda.synchronize(); dt = (time.time() - t0) / 3
+print('B=%d forward %.1f ms -> %.1f img*NFE/s' % (B, dt * 1e3, B / dt))
