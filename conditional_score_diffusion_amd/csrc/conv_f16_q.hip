@@ -114,10 +114,13 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
     const int pr = pix / k.PW, pc = pix - pr * k.PW;
     const int vr = prow0 + pr, col = pcol0 + pc;
     // (MASK == false: the tile lies inside ONE sample; halo rows of its neighbours are padding)
-    const int img_lo = MASK ? 0 : (ov0 / k.OH) * k.IH;
-    const int img_hi = MASK ? k.B * k.IH : img_lo + k.IH;
-    const bool in = vr >= img_lo && vr < img_hi && col >= 0 && col < k.IW;
-    stab[pix] = in ? vr * k.IW + col : -1;
+    const int img_lo = MASK ? 0 : (ov0 / k.OH) * k.OH;
+    const int img_hi = MASK ? k.B * k.OH : img_lo + k.OH;
+    // (k.up: the conv runs on the nearest-x2 upsampled image (models/layers.py:600-604); the patch is in upsampled
+    // coordinates and each of its pixels is fetched from source pixel (row >> 1, col >> 1) of the same sample)
+    const bool in = vr >= img_lo && vr < img_hi && col >= 0 && col < k.OW;
+    const int sb = vr / k.OH, sr = vr - sb * k.OH;
+    stab[pix] = in ? (sb * k.IH + (sr >> k.up)) * k.IW + (col >> k.up) : -1;
     dtab[pix] = (pr * PWC + pc) * PSB;
   }
   // per-lane pixels of this wave's M half: LDS offset of tap (0,0) + this lane's 8-channel K slice
@@ -351,7 +354,8 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
 // host side
 // ---------------------------------------------------------------------------------------------
 bool conv16q_supported(const ConvPlan& p, int ns) {
-  return (ns == 1 || ns == 2) && p.taps == 9 && p.stride == 1 && p.up == 0 && p.C1 == 0 && p.C0 % 32 == 0 && p.Cout % 96 == 0;
+  return (ns == 1 || ns == 2) && p.taps == 9 && p.stride == 1 && (p.up == 0 || p.up == 1) && p.C1 == 0 && p.C0 % 32 == 0 &&
+         p.Cout % 96 == 0;
 }
 
 size_t conv16q_packed_bytes(const ConvPlan& p, int ns) {
@@ -484,7 +488,7 @@ int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) 
 #endif
   k.B = p.B; k.IH = p.IH; k.IW = p.IW; k.OH = p.OH; k.OW = p.OW;
   k.C0 = p.C0; k.C1 = 0; k.Cout = p.Cout;
-  k.stride = 1; k.pad = 1; k.up = 0;
+  k.stride = 1; k.pad = 1; k.up = p.up;
   k.TH = p.TH; k.TW = p.TW; k.PH = p.PH; k.PW = p.PW;
   k.tiles_x = p.tiles_x; k.n_groups = p.n_groups;
   k.nblocks = p.tiles_x * p.tiles_y * p.n_groups;

@@ -208,12 +208,19 @@ __global__ __launch_bounds__(GA_THREADS) void gn_apply16_kernel(
   int Cs;
   if (c < C0) { src = src0 + (size_t)b * HW * C0 + c; Cs = C0; }
   else { src = src1 + (size_t)b * HW * C1 + (c - C0); Cs = C1; }
-  const float4 sca = *reinterpret_cast<const float4*>(nscale + (size_t)b * C + c);
-  const float4 scb = *reinterpret_cast<const float4*>(nscale + (size_t)b * C + c + 4);
-  const float4 sha = *reinterpret_cast<const float4*>(nshift + (size_t)b * C + c);
-  const float4 shb = *reinterpret_cast<const float4*>(nshift + (size_t)b * C + c + 4);
-  const float sc[8] = {sca.x, sca.y, sca.z, sca.w, scb.x, scb.y, scb.z, scb.w};
-  const float sh[8] = {sha.x, sha.y, sha.z, sha.w, shb.x, shb.y, shb.z, shb.w};
+  // (nscale == nullptr: identity affine - a plain fp32 -> fp16 hi|lo split for convolutions without a GroupNorm)
+  float sc[8], sh[8];
+  if (nscale) {
+    const float4 sca = *reinterpret_cast<const float4*>(nscale + (size_t)b * C + c);
+    const float4 scb = *reinterpret_cast<const float4*>(nscale + (size_t)b * C + c + 4);
+    const float4 sha = *reinterpret_cast<const float4*>(nshift + (size_t)b * C + c);
+    const float4 shb = *reinterpret_cast<const float4*>(nshift + (size_t)b * C + c + 4);
+    sc[0] = sca.x; sc[1] = sca.y; sc[2] = sca.z; sc[3] = sca.w; sc[4] = scb.x; sc[5] = scb.y; sc[6] = scb.z; sc[7] = scb.w;
+    sh[0] = sha.x; sh[1] = sha.y; sh[2] = sha.z; sh[3] = sha.w; sh[4] = shb.x; sh[5] = shb.y; sh[6] = shb.z; sh[7] = shb.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
+  }
   half8_t* hdst = hi + ((size_t)b * HW * C + c) / 8;
   half8_t* ldst = lo ? lo + ((size_t)b * HW * C + c) / 8 : nullptr;
   for (int p = p0 + row; p < p1; p += rows) {

@@ -579,7 +579,8 @@ static int build_packed_layout(Net& n) {
     if (!c.resamp_with_conv) return CSD_OK;
     return add_conv(std::to_string(m.idx) + ".Conv_0", m.cin, 0, m.cin, 9,
                     {{n.P(mname(m.idx, "Conv_0.weight")), n.P(mname(m.idx, "Conv_0.bias")), 0, m.cin, 0}},
-                    /*stride1=*/true);   // (the fp16 kernel also covers the stride-2 Downsample)
+                    /*stride1=*/true,    // (the fp16 kernel also covers the stride-2 Downsample)
+                    /*quad-eligible=*/m.kind == M_UP);   // Upsample: plain fp16 split of the low-res tensor + quad schedule
   };
   auto is_attn = [&](int res) {
     for (int i = 0; i < c.n_attn; ++i) if (c.attn_resolutions[i] == res) return true;
@@ -595,7 +596,8 @@ static int build_packed_layout(Net& n) {
       // Conv_0 reads the GroupNorm-ed input directly only in plain blocks; up/down blocks feed it the FIR-resampled
       // activation (an fp32 tensor without a norm)
       int r = add_conv(k + ".Conv_0", c0, c1, m.cout, 9,
-                       {{n.P(mname(m.idx, "Conv_0.weight")), n.P(mname(m.idx, "Conv_0.bias")), 0, m.cout, 0}}, true, plain);
+                       {{n.P(mname(m.idx, "Conv_0.weight")), n.P(mname(m.idx, "Conv_0.bias")), 0, m.cout, 0}}, true,
+                       /*quad-eligible (plain split of the resampled tensor in up/down blocks)=*/true);
       if (r) return r;
       add_copy(mname(m.idx, "GroupNorm_1.weight"));
       add_copy(mname(m.idx, "GroupNorm_1.bias"));
@@ -823,7 +825,7 @@ struct Builder {
     }
     if (fused) {
     } else if (pc.q) {
-      if (!norm || stride != 1 || up || external_nchw) { set_error("quad fp16 conv on an unsupported layer"); rc = CSD_ERR_INVALID; return NONE; }
+      if (stride != 1 || external_nchw || (!norm && o.cp.C1 != 0)) { set_error("quad fp16 conv on an unsupported layer"); rc = CSD_ERR_INVALID; return NONE; }
       o.cp.C0 = o.cp.C0 + o.cp.C1; o.cp.C1 = 0;
       if (conv16q_plan_tiles(&o.cp, pc.ns)) { rc = CSD_ERR_INVALID; return NONE; }
     } else if (pc.pw) {
@@ -836,13 +838,14 @@ struct Builder {
     o.d = norm ? nscale : NONE;
     o.e = norm ? nshift : NONE;
     size_t hi16 = NONE, lo16 = NONE;
-    if (pc.ns && !pc.pw && norm && !fused) {
+    if (pc.ns && !pc.pw && (norm || pc.q) && !fused) {
       // fp16 kernel: normalise + activate + split ONCE per element into fp16 planes, conv copies them
+      // (a quad-schedule conv without a GroupNorm - Upsample, the FIR-resampled Conv_0 of NCSN++ - gets a plain split)
       const size_t nh = ((size_t)B * ih * iw * (o.cp.C0 + o.cp.C1) + 1) / 2;      // halves -> floats
       Op ap;
       ap.kind = OP_GN_APPLY16;
       ap.a = src0; ap.b = src1; ap.i0 = pc.proto.C0; ap.i1 = pc.proto.C1; ap.i2 = ih * iw;
-      ap.d = nscale; ap.e = nshift; ap.act = act;
+      ap.d = norm ? nscale : NONE; ap.e = norm ? nshift : NONE; ap.act = norm ? act : (int)CSD_ACT_NONE;
       hi16 = alloc_(nh);
       if (pc.ns == 2) lo16 = alloc_(nh);
       ap.out = hi16; ap.c = lo16;
