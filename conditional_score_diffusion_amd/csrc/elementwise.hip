@@ -335,6 +335,39 @@ __global__ void fir_resample_nhwc_kernel(const float* __restrict__ in, float* __
     out[i] = acc;
   }
 }
+// float4-over-channels variant (C % 4 == 0): one thread per (output pixel, 4 channels)
+__global__ void fir_resample_nhwc4_kernel(const float4* __restrict__ in, float4* __restrict__ out, int H, int W, int C4, int up,
+                                          Fir16 f, size_t total) {
+  const int OH = up ? H * 2 : H / 2, OW = up ? W * 2 : W / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    size_t r = i / C4;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const size_t b = r / OH;
+    const float4* src = in + b * (size_t)H * W * C4 + c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      const int my = up ? oy + ky - 2 : oy * 2 + ky - 1;
+      if (my < 0 || (up && (my & 1))) continue;
+      const int iy = up ? my >> 1 : my;
+      if (iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const int mx = up ? ox + kx - 2 : ox * 2 + kx - 1;
+        if (mx < 0 || (up && (mx & 1))) continue;
+        const int ix = up ? mx >> 1 : mx;
+        if (ix >= W) continue;
+        const float4 v = src[((size_t)iy * W + ix) * C4];
+        const float w = f.k[(3 - ky) * 4 + (3 - kx)];
+        acc.x += v.x * w; acc.y += v.y * w; acc.z += v.z * w; acc.w += v.w * w;
+      }
+    }
+    out[i] = acc;
+  }
+}
 int fir_resample_nhwc_launch(const float* in, float* out, int B, int H, int W, int C, const float* taps4, int up, hipStream_t s) {
   // _setup_kernel (up_or_down_sampling.py:181-189): outer product, normalised, times the gain (factor^2 when upsampling)
   Fir16 f;
@@ -343,8 +376,13 @@ int fir_resample_nhwc_launch(const float* in, float* out, int B, int H, int W, i
     for (int b = 0; b < 4; ++b) { f.k[a * 4 + b] = taps4[a] * taps4[b]; sum += f.k[a * 4 + b]; }
   for (int a = 0; a < 16; ++a) f.k[a] = f.k[a] / sum * (up ? 4.f : 1.f);
   const size_t total = (size_t)B * (up ? H * 2 : H / 2) * (up ? W * 2 : W / 2) * C;
-  hipLaunchKernelGGL(fir_resample_nhwc_kernel, dim3((unsigned)std::min<size_t>(cdiv64(total, 256), 65536)), dim3(256), 0, s, in,
-                     out, H, W, C, up, f, total);
+  if (C % 4 == 0) {
+    hipLaunchKernelGGL(fir_resample_nhwc4_kernel, dim3((unsigned)std::min<size_t>(cdiv64(total / 4, 256), 65536)), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), H, W, C / 4, up, f, total / 4);
+  } else {
+    hipLaunchKernelGGL(fir_resample_nhwc_kernel, dim3((unsigned)std::min<size_t>(cdiv64(total, 256), 65536)), dim3(256), 0, s, in,
+                       out, H, W, C, up, f, total);
+  }
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
