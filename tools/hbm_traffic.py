@@ -24,7 +24,7 @@ def main(tag, outpath):
         fetch = 2.0 * f[key][0] * 1024
         write = w[key][0] * 1024
         n = f[key][1]
-        rows.append({'kernel': key[0], 'workgroups': key[1], 'launches_per_pc_step': n,
+        rows.append({'kernel': key[0], 'workgroups': key[1], 'launches_in_run': n,
                      'fetch_bytes_per_launch': fetch, 'write_bytes_per_launch': write})
         name = key[0]
         in16_old = name.startswith('conv_f16_kernel') and name.rstrip('>').split(',')[-2].strip() == 'true'
@@ -35,7 +35,7 @@ def main(tag, outpath):
     res = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 1 --warmup 0`, '
                      'tools/pmc_hbm.sh; fetch = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB (calibrated on the sampler '
                      'update kernels of the same run)',
-           'conv3x3_class': {'launches_per_pc_step': cls['launches'],
+           'conv3x3_class': {'launches_in_run': cls['launches'], 'run': 'bench.py --steps 1 --warmup 0 = 1 timed + 1 profiled PC step',
                              'hbm_bytes_per_launch': (cls['fetch'] + cls['write']) / max(cls['launches'], 1),
                              'fetch_bytes_per_launch': cls['fetch'] / max(cls['launches'], 1),
                              'write_bytes_per_launch': cls['write'] / max(cls['launches'], 1)},

@@ -1,14 +1,29 @@
 """Summarise a rocprofv3 kernel-trace csv per (kernel, grid) and PMC counter csv per kernel."""
 import collections
 import csv
+import functools
+import subprocess
 import sys
+
+
+@functools.lru_cache(maxsize=None)
+def demangle(name):
+    """rocprofv3 sometimes reports a kernel by its mangled symbol (_ZN3csd...): normalise with llvm-cxxfilt."""
+    if not name.startswith('_Z'):
+        return name
+    for exe in ('/opt/rocm/lib/llvm/bin/llvm-cxxfilt', 'c++filt'):
+        try:
+            return subprocess.run([exe, name], capture_output=True, text=True, timeout=10).stdout.strip() or name
+        except Exception:
+            continue
+    return name
 
 
 def trace(path, filt='conv_f'):
     rows = list(csv.DictReader(open(path)))
     agg = collections.OrderedDict()
     for r in rows:
-        n = r['Kernel_Name']
+        n = demangle(r['Kernel_Name'])
         if filt not in n:
             continue
         key = (n.split('(')[0].replace('void csd::', ''), int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']),
@@ -26,7 +41,7 @@ def counters(path, filt='conv_f'):
     rows = list(csv.DictReader(open(path)))
     agg = collections.OrderedDict()
     for r in rows:
-        n = r['Kernel_Name']
+        n = demangle(r['Kernel_Name'])
         if filt not in n:
             continue
         key = (n.split('(')[0].replace('void csd::', ''), int(r['Grid_Size']) // int(r['Workgroup_Size']), r['Counter_Name'])
