@@ -103,8 +103,8 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
 #pragma unroll
     for (int r = 0; r < KS; ++r) {
       const int iy = oy + r - 1, ix = ox + r - 1;
-      vb |= ((mv && iy >= 0 && iy < k.IH) ? 1u : 0u) << r;
-      vb |= ((mv && ix >= 0 && ix < k.IW) ? 1u : 0u) << (3 + r);
+      vb |= ((mv && iy >= 0 && iy < (k.IH << k.up)) ? 1u : 0u) << r;      // (bounds of the image the conv runs on: upsampled when k.up)
+      vb |= ((mv && ix >= 0 && ix < (k.IW << k.up)) ? 1u : 0u) << (3 + r);
     }
     otab[m] = mv ? (ov - ov0) * k.OW + ox : -1;
     btab[m] = mv ? b : 0;
