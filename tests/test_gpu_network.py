@@ -208,6 +208,34 @@ def test_full_size_sr3_160_forward_vs_oracle(precision, tol):
         assert rel(out.cpu().numpy(), ref.numpy()) < tol
 
 
+def test_full_size_fused_pc_steps_vs_oracle():
+    """Three fused PC steps (6 network evaluations) of the 1000-step schedule at full size (SR3-160, B = 2, default
+    fp16x3 arithmetic) with a noise tape against the oracle's loop: sampler kernels, batch-mean coupling and the network
+    at the benchmarked shapes in one go."""
+    from conditional_score_diffusion_amd.sampling import conditional
+    from conditional_score_diffusion_amd.sampling.correctors import get_corrector
+    from conditional_score_diffusion_amd.sampling.predictors import get_predictor
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    cfg = cases.make_config(name='ddpm_paired_SR3', nf=96, ch_mult=(1, 1, 2, 2, 3, 3), attn_resolutions=(20, 10, 5),
+                            image_size=160)
+    cfg, nc, p, model = build(cfg, 'fp16x3')
+    sde = sdes_for(cfg)
+    rs = np.random.RandomState(9)
+    lr = rs.uniform(0, 1, size=(2, 3, 20, 20)).astype(np.float32)
+    y = torch.from_numpy(np.repeat(np.repeat(lr, 8, axis=2), 8, axis=3))
+    P = 3
+    xs = (2, 3, 160, 160)
+    tp = cases.tape([xs] * (1 + 2 * P), seed=33)
+    sampler = conditional.get_pc_conditional_sampler(sde, xs, get_predictor('conditional_reverse_diffusion'),
+                                                     get_corrector('conditional_langevin'), snr=cfg.sampling.snr, p_steps=P,
+                                                     c_steps=1, continuous=True, denoise=True, eps=1e-5)
+    got, _ = sampler(model, y.to(dev()), noise_tape=tp)
+    with torch.no_grad():
+        ref = so.pc_sample_conditional(p, nc, y, so.NoiseTape(tp), (cfg.model.sigma_min_x, cfg.model.sigma_max_x), None,
+                                       sr3=True, p_steps=P, snr=cfg.sampling.snr, N=1000)
+    assert np.abs(got.cpu().numpy() - ref.numpy()).max() / cfg.model.sigma_max_x < 2e-5
+
+
 def test_batch_independence_of_network():
     """same sample, different batch position / batch size -> identical output (tiles straddle images)"""
     cfg, nc, p, model = build('sr3_tiny')
