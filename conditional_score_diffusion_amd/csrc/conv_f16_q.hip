@@ -44,7 +44,9 @@ __device__ __forceinline__ double dpp_row16_sum(double v) {
   return v;
 }
 
-template <int MQ, int NS, bool MASK, int PWC>
+// S: stride.  S = 2 is the reference Downsample (pad (0,1,0,1), models/layers.py:619-625): the patch of a TH x TW output
+// tile is (2*TH+1) x (2*TW+1) input pixels and a lane's tap (0,0) sits at (2*ty, 2*tx).
+template <int MQ, int NS, bool MASK, int PWC, int S>
 __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void* __restrict__ g_hi,
                                                                     const void* __restrict__ g_lo,
                                                                     const char* __restrict__ g_wpack,
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
   constexpr int PSB = 32 * KCS * NS + 16;    // bytes per staged pixel
   constexpr int NPIX = 2 * MQ * 16;          // pixels per workgroup tile
   constexpr int SPP = 2 * NS * KCS;          // 16-byte slots per patch pixel per stage
-  constexpr int NU = (NS == 2) ? 7 : 4;      // staging slots per thread (host: patch * SPP <= NU * 256)
+  constexpr int NU = (S == 2) ? ((NS == 2) ? 10 : 5) : ((NS == 2) ? 7 : 4);      // staging slots per thread (host: patch * SPP <= NU * 256)
   constexpr int rstride = PWC * PSB;
   constexpr int WSTEP = 3 * NS * 1024;       // weight bytes per K step per wave
   extern __shared__ __attribute__((aligned(16))) char smem16[];
@@ -83,7 +85,9 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
   const int tile = w / k.n_groups;
   const int tile_y = tile / k.tiles_x;
   const int ov0 = tile_y * k.TH, ox0 = (tile - tile_y * k.tiles_x) * k.TW;
-  const int prow0 = ov0 - 1, pcol0 = ox0 - 1;
+  constexpr int P = (S == 2) ? 0 : 1;        // top/left padding
+  const int prow0 = ov0 * S - P, pcol0 = ox0 * S - P;
+  const int EH = (S == 2) ? k.IH : k.OH, EW = (S == 2) ? k.IW : k.OW;     // the image the patch coordinates live in
   const int Cin = k.C0;
   const int npatch = k.PH * k.PW;
   const int patch_bytes = k.PH * PWC * PSB;
@@ -102,9 +106,9 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
     unsigned vb = 0;
 #pragma unroll
     for (int r = 0; r < KS; ++r) {
-      const int iy = oy + r - 1, ix = ox + r - 1;
-      vb |= ((mv && iy >= 0 && iy < (k.IH << k.up)) ? 1u : 0u) << r;      // (bounds of the image the conv runs on: upsampled when k.up)
-      vb |= ((mv && ix >= 0 && ix < (k.IW << k.up)) ? 1u : 0u) << (3 + r);
+      const int iy = oy * S + r - P, ix = ox * S + r - P;
+      vb |= ((mv && iy >= 0 && iy < EH) ? 1u : 0u) << r;      // (bounds of the image the conv runs on: upsampled when k.up)
+      vb |= ((mv && ix >= 0 && ix < EW) ? 1u : 0u) << (3 + r);
     }
     otab[m] = mv ? (ov - ov0) * k.OW + ox : -1;
     btab[m] = mv ? b : 0;
@@ -114,12 +118,12 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
     const int pr = pix / k.PW, pc = pix - pr * k.PW;
     const int vr = prow0 + pr, col = pcol0 + pc;
     // (MASK == false: the tile lies inside ONE sample; halo rows of its neighbours are padding)
-    const int img_lo = MASK ? 0 : (ov0 / k.OH) * k.OH;
-    const int img_hi = MASK ? k.B * k.OH : img_lo + k.OH;
+    const int img_lo = MASK ? 0 : (ov0 / k.OH) * EH;
+    const int img_hi = MASK ? k.B * EH : img_lo + EH;
     // (k.up: the conv runs on the nearest-x2 upsampled image (models/layers.py:600-604); the patch is in upsampled
     // coordinates and each of its pixels is fetched from source pixel (row >> 1, col >> 1) of the same sample)
-    const bool in = vr >= img_lo && vr < img_hi && col >= 0 && col < k.OW;
-    const int sb = vr / k.OH, sr = vr - sb * k.OH;
+    const bool in = vr >= img_lo && vr < img_hi && col >= 0 && col < EW;
+    const int sb = vr / EH, sr = vr - sb * EH;
     stab[pix] = in ? (sb * k.IH + (sr >> k.up)) * k.IW + (col >> k.up) : -1;
     dtab[pix] = (pr * PWC + pc) * PSB;
   }
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
   for (int j = 0; j < MQ; ++j) {
     const int m = (mi * MQ + j) * 16 + l16;
     const int ty = m / k.TW, tx = m - ty * k.TW;
-    base[j] = (m < k.TH * k.TW) ? ty * rstride + tx * PSB + kq * 16 : kq * 16;
+    base[j] = (m < k.TH * k.TW) ? ty * S * rstride + tx * S * PSB + kq * 16 : kq * 16;
   }
   __syncthreads();
   Q_TSTAMP();
@@ -354,8 +358,8 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
 // host side
 // ---------------------------------------------------------------------------------------------
 bool conv16q_supported(const ConvPlan& p, int ns) {
-  return (ns == 1 || ns == 2) && p.taps == 9 && p.stride == 1 && (p.up == 0 || p.up == 1) && p.C1 == 0 && p.C0 % 32 == 0 &&
-         p.Cout % 96 == 0;
+  return (ns == 1 || ns == 2) && p.taps == 9 && ((p.stride == 1 && (p.up == 0 || p.up == 1)) || (p.stride == 2 && p.up == 0)) &&
+         p.C1 == 0 && p.C0 % 32 == 0 && p.Cout % 96 == 0;
 }
 
 size_t conv16q_packed_bytes(const ConvPlan& p, int ns) {
@@ -403,7 +407,7 @@ int conv16q_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, i
   return CSD_OK;
 }
 
-static int in_coord_q(int t) { return t + 2; }      // patch extent of a t-pixel tile edge (3x3, stride 1)
+static int in_coord_q(int t, int stride = 1) { return stride * (t - 1) + 3; }      // patch extent of a t-pixel tile edge (3x3)
 
 int conv16q_plan_tiles(ConvPlan* p, int ns) {
   CSD_REQUIRE(conv16q_supported(*p, ns), "conv16q: unsupported shape (Cin=%d Cout=%d)", p->C0, p->Cout);
@@ -415,8 +419,9 @@ int conv16q_plan_tiles(ConvPlan* p, int ns) {
   p->LC = 0;
   const int psb = 32 * 2 * ns + 16;
   const int spp = 2 * ns * 2;
-  const int nu = ns == 2 ? 7 : 4;
-  auto pitch = [&](int tw) { return in_coord_q(tw) <= 24 ? 24 : 34; };
+  const int st = p->stride;
+  const int nu = st == 2 ? (ns == 2 ? 10 : 5) : (ns == 2 ? 7 : 4);
+  auto pitch = [&](int tw) { return in_coord_q(tw, st) <= 24 ? 24 : 34; };
   int best_mq = 0, best_tw = 0, best_th = 0;
   for (int mq = 4; mq >= 2; mq >>= 1) {        // 128- or 64-pixel tiles
     const int npix = 2 * mq * 16;
@@ -425,25 +430,29 @@ int conv16q_plan_tiles(ConvPlan* p, int ns) {
     bool bunm = false;
     for (int tw = 1; tw <= 32 && tw <= p->OW; ++tw) {
       if (p->OW % tw != 0 && !(tw == 32 && p->OW > 32)) continue;
-      const int th = npix / tw;       // (th * tw may be < npix: the spare pixels are masked)
-      if (th < 1) continue;
-      const int patch = in_coord_q(th) * in_coord_q(tw);
-      const int lds = in_coord_q(th) * pitch(tw) * psb;
-      if (lds > 72 * 1024 || patch * spp > nu * C16Q_THREADS) continue;
-      const double cov = (double)th * tw * p->OW / ((double)cdiv(p->OW, tw) * tw);
-      const bool unm = (p->OH % th) == 0;
-      if (cov > bcov + 1e-9 || (cov > bcov - 1e-9 && ((unm && !bunm) || (unm == bunm && lds < blds)))) {
-        bcov = cov; blds = lds; btw = tw; bth = th; bunm = unm;
+      if (in_coord_q(tw, st) > 34) continue;
+      // the tallest tile of this width that fits LDS and the staging slots (th * tw may be < npix: spare pixels are masked)
+      for (int th = npix / tw; th >= 1; --th) {
+        const int patch = in_coord_q(th, st) * in_coord_q(tw, st);
+        const int lds = in_coord_q(th, st) * pitch(tw) * psb;
+        if (lds > 72 * 1024 || patch * spp > nu * C16Q_THREADS) continue;
+        const double cov = (double)th * tw * p->OW / ((double)cdiv(p->OW, tw) * tw);
+        const bool unm = (p->OH % th) == 0;
+        if (cov > bcov + 1e-9 || (cov > bcov - 1e-9 && ((unm && !bunm) || (unm == bunm && lds < blds)))) {
+          bcov = cov; blds = lds; btw = tw; bth = th; bunm = unm;
+        }
+        break;
       }
     }
     if (btw == 0) continue;
+    if (mq > 2 && bcov < 0.75 * npix) continue;        // a large tile that would be mostly masked: try the smaller one
     best_mq = mq; best_tw = btw; best_th = bth;
     const long nwg = (long)cdiv(p->OW, btw) * cdiv(p->B * p->OH, bth) * p->n_groups;
     if (nwg >= 512 || mq == 2) break;
   }
   CSD_REQUIRE(best_tw > 0, "conv16q: no feasible tile for OW=%d", p->OW);
   p->TW = best_tw; p->TH = best_th;
-  p->PH = in_coord_q(p->TH); p->PW = in_coord_q(p->TW);
+  p->PH = in_coord_q(p->TH, st); p->PW = in_coord_q(p->TW, st);
   p->tiles_x = cdiv(p->OW, p->TW);
   p->tiles_y = cdiv(p->B * p->OH, p->TH);
   p->MT = best_mq;           // (field reused: 16-pixel tiles per wave)
@@ -452,9 +461,9 @@ int conv16q_plan_tiles(ConvPlan* p, int ns) {
   return CSD_OK;
 }
 
-template <int MQ, int NS, bool MASK, int PWC>
+template <int MQ, int NS, bool MASK, int PWC, int S>
 static int launch_q(const Conv16KArgs& k, size_t lds, hipStream_t s) {
-  auto kern = conv_f16_q_kernel<MQ, NS, MASK, PWC>;
+  auto kern = conv_f16_q_kernel<MQ, NS, MASK, PWC, S>;
   static bool attr_set = false;
   if (!attr_set) {
     CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -488,7 +497,7 @@ int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) 
 #endif
   k.B = p.B; k.IH = p.IH; k.IW = p.IW; k.OH = p.OH; k.OW = p.OW;
   k.C0 = p.C0; k.C1 = 0; k.Cout = p.Cout;
-  k.stride = 1; k.pad = 1; k.up = p.up;
+  k.stride = p.stride; k.pad = p.stride == 2 ? 0 : 1; k.up = p.up;
   k.TH = p.TH; k.TW = p.TW; k.PH = p.PH; k.PW = p.PW;
   k.tiles_x = p.tiles_x; k.n_groups = p.n_groups;
   k.nblocks = p.tiles_x * p.tiles_y * p.n_groups;
@@ -497,13 +506,21 @@ int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) 
   k.ntiles_n = p.Cout / 32;
   const bool mask = (p.OH % p.TH) != 0;
 #define CSD_Q_CASE(MQ_, NS_)                                                  \
-  if (p.MT == MQ_ && ns == NS_) {                                             \
+  if (p.MT == MQ_ && ns == NS_ && p.stride == 1) {                            \
     if (p.PW <= 24) {                                                         \
-      if (mask) return launch_q<MQ_, NS_, true, 24>(k, p.lds_bytes, s);       \
-      return launch_q<MQ_, NS_, false, 24>(k, p.lds_bytes, s);                \
+      if (mask) return launch_q<MQ_, NS_, true, 24, 1>(k, p.lds_bytes, s);    \
+      return launch_q<MQ_, NS_, false, 24, 1>(k, p.lds_bytes, s);             \
     }                                                                         \
-    if (mask) return launch_q<MQ_, NS_, true, 34>(k, p.lds_bytes, s);         \
-    return launch_q<MQ_, NS_, false, 34>(k, p.lds_bytes, s);                  \
+    if (mask) return launch_q<MQ_, NS_, true, 34, 1>(k, p.lds_bytes, s);      \
+    return launch_q<MQ_, NS_, false, 34, 1>(k, p.lds_bytes, s);               \
+  }                                                                           \
+  if (p.MT == MQ_ && ns == NS_ && p.stride == 2) {                            \
+    if (p.PW <= 24) {                                                         \
+      if (mask) return launch_q<MQ_, NS_, true, 24, 2>(k, p.lds_bytes, s);    \
+      return launch_q<MQ_, NS_, false, 24, 2>(k, p.lds_bytes, s);             \
+    }                                                                         \
+    if (mask) return launch_q<MQ_, NS_, true, 34, 2>(k, p.lds_bytes, s);      \
+    return launch_q<MQ_, NS_, false, 34, 2>(k, p.lds_bytes, s);               \
   }
   CSD_Q_CASE(4, 2) CSD_Q_CASE(2, 2) CSD_Q_CASE(4, 1) CSD_Q_CASE(2, 1)
 #undef CSD_Q_CASE

@@ -580,7 +580,7 @@ static int build_packed_layout(Net& n) {
     return add_conv(std::to_string(m.idx) + ".Conv_0", m.cin, 0, m.cin, 9,
                     {{n.P(mname(m.idx, "Conv_0.weight")), n.P(mname(m.idx, "Conv_0.bias")), 0, m.cin, 0}},
                     /*stride1=*/true,    // (the fp16 kernel also covers the stride-2 Downsample)
-                    /*quad-eligible=*/m.kind == M_UP);   // Upsample: plain fp16 split of the low-res tensor + quad schedule
+                    /*quad-eligible=*/true);   // plain fp16 split of the source tensor + quad schedule (x2 addressing / stride 2)
   };
   auto is_attn = [&](int res) {
     for (int i = 0; i < c.n_attn; ++i) if (c.attn_resolutions[i] == res) return true;
@@ -825,7 +825,7 @@ struct Builder {
     }
     if (fused) {
     } else if (pc.q) {
-      if (stride != 1 || external_nchw || (!norm && o.cp.C1 != 0)) { set_error("quad fp16 conv on an unsupported layer"); rc = CSD_ERR_INVALID; return NONE; }
+      if (external_nchw || (!norm && o.cp.C1 != 0) || (stride == 2 && (norm || up))) { set_error("quad fp16 conv on an unsupported layer"); rc = CSD_ERR_INVALID; return NONE; }
       o.cp.C0 = o.cp.C0 + o.cp.C1; o.cp.C1 = 0;
       if (conv16q_plan_tiles(&o.cp, pc.ns)) { rc = CSD_ERR_INVALID; return NONE; }
     } else if (pc.pw) {
