@@ -483,7 +483,8 @@ static int build_packed_layout(Net& n) {
   // opt-in experiment (measured slower: one loader wave cannot convert a patch as fast as three waves consume it)
   const bool fused_norm = getenv("CSD_FUSED_NORM") != nullptr;
   auto add_conv = [&](const std::string& key, int c0, int c1, int cout, int taps,
-                      std::vector<PackedConv::Src> srcs, bool stride1 = true, bool normed = false) -> int {
+                      std::vector<PackedConv::Src> srcs, bool stride1 = true, bool normed = false,
+                      bool resample = false) -> int {
     PackedConv pc;
     int rc = proto_conv(&pc.proto, c0, c1, cout, taps);
     if (rc) return rc;
@@ -491,7 +492,10 @@ static int build_packed_layout(Net& n) {
     one.C0 = c0 + c1; one.C1 = 0;
     // high-resolution GroupNorm-ed convs run the loader/consumer schedule with the norm fused into its loader
     // (standard fragment layout); the quad schedule serves the lower levels, whose tiles straddle samples
-    if (use_q && normed && stride1 && !(fused_norm && cur_res >= 64) && conv16q_supported(one, net_ns)) {
+    // (fp16 mode: the loader/consumer schedule wins on the GroupNorm-ed convs, the quad schedule on the resampling ones,
+    // which would otherwise convert fp32 -> fp16 inside the old kernel's staging loop)
+    const bool q_here = use_q || (net_ns == 1 && resample && !getenv("CSD_NO_Q"));
+    if (q_here && normed && stride1 && !(fused_norm && cur_res >= 64) && conv16q_supported(one, net_ns)) {
       pc.ns = net_ns;
       pc.q = true;
       pc.proto.KC = 16;
@@ -580,7 +584,7 @@ static int build_packed_layout(Net& n) {
     return add_conv(std::to_string(m.idx) + ".Conv_0", m.cin, 0, m.cin, 9,
                     {{n.P(mname(m.idx, "Conv_0.weight")), n.P(mname(m.idx, "Conv_0.bias")), 0, m.cin, 0}},
                     /*stride1=*/true,    // (the fp16 kernel also covers the stride-2 Downsample)
-                    /*quad-eligible=*/true);   // plain fp16 split of the source tensor + quad schedule (x2 addressing / stride 2)
+                    /*quad-eligible=*/true, /*resample=*/true);   // plain fp16 split of the source tensor + quad schedule (x2 addressing / stride 2)
   };
   auto is_attn = [&](int res) {
     for (int i = 0; i < c.n_attn; ++i) if (c.attn_resolutions[i] == res) return true;
@@ -597,7 +601,7 @@ static int build_packed_layout(Net& n) {
       // activation (an fp32 tensor without a norm)
       int r = add_conv(k + ".Conv_0", c0, c1, m.cout, 9,
                        {{n.P(mname(m.idx, "Conv_0.weight")), n.P(mname(m.idx, "Conv_0.bias")), 0, m.cout, 0}}, true,
-                       /*quad-eligible (plain split of the resampled tensor in up/down blocks)=*/true);
+                       /*quad-eligible (plain split of the resampled tensor in up/down blocks)=*/true, /*resample=*/!plain);
       if (r) return r;
       add_copy(mname(m.idx, "GroupNorm_1.weight"));
       add_copy(mname(m.idx, "GroupNorm_1.bias"));
