@@ -99,6 +99,17 @@ SIGNATURES = {
     'csd_fused_bias_act': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i64, _i, _i, _f, _f, _vp]),
     'csd_nearest_up2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'csd_timestep_embedding': (_i, [_vp, _vp, _i, _i, _vp]),
+    'csd_conv_wgrad_scratch_bytes': (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    'csd_conv2d_wgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'csd_groupnorm_act_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    'csd_attention_backward_scratch_bytes': (_sz, [_i, _i, _i, _i]),
+    'csd_attention_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'csd_bgemm': (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i64, _i64, _i64, _f, _vp]),
+    'csd_sum_inner': (_i, [_vp, _vp, _i64, _i64, _vp]),
+    'csd_sum_rows': (_i, [_vp, _vp, _i, _i, _vp]),
+    'csd_act': (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
+    'csd_mul': (_i, [_vp, _vp, _vp, _i64, _vp]),
+    'csd_dropout': (_i, [_vp, _vp, _vp, _f, _u64, _u64, _i64, _vp]),
 }
 
 

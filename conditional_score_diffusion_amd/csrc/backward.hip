@@ -1,0 +1,517 @@
+// backward.hip - gradient kernels of the score network's layers (the autograd backward
+// of conv / NIN / Linear / GroupNorm(+act) / attention / dropout that the reference gets from torch) behind the
+// NCHW fp32 C ABI of include/csd.h.  The data gradient of a convolution is itself a convolution with the flipped,
+// transposed weight and runs on the forward kernels (csd_conv2d); what is new here:
+//   conv_wgrad_kernel   dW = dY^T (x) X as an implicit GEMM over pixels on the fp32 matrix cores, split-K over
+//                       workgroups with a deterministic two-stage reduction
+//   gn_bwd_kernel       GroupNorm(+activation) backward, one workgroup per (sample, group), fp64 statistics
+//   bgemm_kernel        strided batched fp32 GEMM (attention backward, Linear backward)
+//   softmax / dsoftmax rows, row / column sums, activation fwd/bwd, dropout (Philox4x32-10), elementwise product
+#include <algorithm>
+
+#include "common.h"
+
+using namespace csd;
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+inline size_t al64(size_t v) { return (v + 63) / 64 * 64; }
+
+__device__ __forceinline__ float bw_act(float v, int act) {
+  switch (act) {
+    case CSD_ACT_SWISH: return v / (1.0f + expf(-v));
+    case CSD_ACT_RELU: return v > 0.f ? v : 0.f;
+    case CSD_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+    case CSD_ACT_ELU: return v > 0.f ? v : expm1f(v);
+    default: return v;
+  }
+}
+// d act(v) / dv
+__device__ __forceinline__ float bw_dact(float v, int act) {
+  switch (act) {
+    case CSD_ACT_SWISH: { const float s = 1.0f / (1.0f + expf(-v)); return s * (1.0f + v * (1.0f - s)); }
+    case CSD_ACT_RELU: return v > 0.f ? 1.f : 0.f;
+    case CSD_ACT_LRELU: return v > 0.f ? 1.f : 0.2f;
+    case CSD_ACT_ELU: return v > 0.f ? 1.f : expf(v);
+    default: return 1.f;
+  }
+}
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {   // 256 threads; result broadcast to all
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// convolution weight gradient.  x [B, IH, IW, Cs] NHWC (Cin real channels), dy [B, OH, OW, Cout] NHWC.
+// GEMM: M = 32 couts (A = dY), N = 32 cins (B = X shifted by the tap), K = pixels, v_mfma_f32_32x32x2_f32
+// (2 pixels per instruction).  A wave keeps the 32x32 tile of EVERY tap (TAPS x 16 accumulators): dY is read once
+// per pixel, X once per tap.  Workgroup = 4 waves on interleaved pixel pairs of one K-split, reduced through LDS;
+// partial [split][Cout][Cin][TAPS] is summed in split order by wgrad_reduce_kernel (bit-reproducible).
+// ---------------------------------------------------------------------------------------------------------------
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         float* __restrict__ partial, int B, int IH, int IW, int Cs,
+                                                         int Cin, int OH, int OW, int Cout, int stride, int pad, int up,
+                                                         int per_split) {
+  constexpr int KS = TAPS == 9 ? 3 : 1;
+  __shared__ float red[TAPS * 1024];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = lane & 31, kk = lane >> 5;
+  const int co = blockIdx.z * 32 + m, ci = blockIdx.y * 32 + m;
+  const bool cov = co < Cout, civ = ci < Cin;
+  const long long npix = (long long)B * OH * OW;
+  const long long p_begin = (long long)blockIdx.x * per_split;
+  const long long p_end = p_begin + per_split < npix ? p_begin + per_split : npix;
+  const int EH = IH << up, EW = IW << up;
+  floatx16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  for (long long p0 = p_begin + wave * 2; p0 < p_end; p0 += 8) {
+    const long long p = p0 + kk;
+    const bool v = p < p_end;
+    const long long pc = v ? p : p_begin;
+    const int ox = (int)(pc % OW);
+    const long long row = pc / OW;
+    const int oy = (int)(row % OH);
+    const int b = (int)(row / OH);
+    const float a = (v && cov) ? dy[(size_t)pc * Cout + co] : 0.f;
+    float bv[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int ky = t / KS, kx = t % KS;
+      const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+      const bool ok = v && civ && iy >= 0 && iy < EH && ix >= 0 && ix < EW;
+      const size_t off = (((size_t)b * IH + (ok ? (iy >> up) : 0)) * IW + (ok ? (ix >> up) : 0)) * Cs + (civ ? ci : 0);
+      const float xv = x[off];
+      bv[t] = ok ? xv : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[t], acc[t], 0, 0, 0);
+  }
+
+  // cross-wave reduction (fixed order: wave 0, 1, 2, 3)
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* d = &red[(t * 16 + r) * 64 + lane];
+          *d = (w == 0) ? acc[t][r] : *d + acc[t][r];
+        }
+    }
+    __syncthreads();
+  }
+  // partial[split][co][ci][tap]; accumulator r of lane holds D[row = (r&3) + 8*(r>>2) + 4*kk][col = m]
+  float* dst = partial + (size_t)blockIdx.x * Cout * Cin * TAPS;
+  for (int e = threadIdx.x; e < TAPS * 1024; e += 256) {
+    const int l = e & 63, r = (e >> 6) & 15, t = e >> 10;
+    const int rco = blockIdx.z * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    const int rci = blockIdx.y * 32 + (l & 31);
+    if (rco < Cout && rci < Cin) dst[((size_t)rco * Cin + rci) * TAPS + t] = red[e];
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, size_t n, int splits) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int k = 0; k < splits; ++k) s += (double)partial[(size_t)k * n + i];
+    dw[i] = (float)s;
+  }
+}
+
+int wgrad_splits(int B, int OH, int OW, int Cin, int Cout, int* per_split) {
+  const long long npix = (long long)B * OH * OW;
+  const int tiles = cdiv(Cout, 32) * cdiv(Cin, 32);
+  long long S = std::max(1, 1024 / tiles);
+  const long long max_s = std::max<long long>(1, npix / 64);
+  if (S > max_s) S = max_s;
+  long long per = (npix + S - 1) / S;
+  per = (per + 7) / 8 * 8;
+  S = (npix + per - 1) / per;
+  *per_split = (int)per;
+  return (int)S;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm (+activation) backward on NCHW: a group of one sample is one contiguous run of cpg*HW floats.
+//   u = xhat*gamma + beta, y = act(u);  du = dy*act'(u);  dgamma_c = sum du*xhat, dbeta_c = sum du (per sample here,
+//   summed over the batch by csd_sum_rows);  dx = rstd*(du*gamma - mean(du*gamma) - xhat*mean(du*gamma*xhat))
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ dy,
+                                                     float* __restrict__ dx, float* __restrict__ dgamma_s,
+                                                     float* __restrict__ dbeta_s, int C, int HW, int G, float eps,
+                                                     int act) {
+  __shared__ double sh[4];
+  const int b = blockIdx.x / G, g = blockIdx.x % G;
+  const int cpg = C / G;
+  const size_t base = ((size_t)b * C + (size_t)g * cpg) * HW;
+  const size_t n = (size_t)cpg * HW;
+  double s = 0.0, q = 0.0;
+  for (size_t i = threadIdx.x; i < n; i += 256) {
+    const double v = x[base + i];
+    s += v;
+    q += v * v;
+  }
+  s = block_sum(s, sh);
+  q = block_sum(q, sh);
+  const double mean = s / (double)n;
+  double var = q / (double)n - mean * mean;
+  if (var < 0) var = 0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float mu = (float)mean;
+  double A = 0.0, Bq = 0.0;       // sum dxhat, sum dxhat*xhat over the group
+  for (int c = 0; c < cpg; ++c) {
+    const int ch = g * cpg + c;
+    const float ga = gamma[ch], be = beta[ch];
+    double s1 = 0.0, s2 = 0.0;
+    const size_t cb = base + (size_t)c * HW;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+      const float xh = (x[cb + i] - mu) * rstd;
+      const float du = dy[cb + i] * bw_dact(xh * ga + be, act);
+      s1 += du;
+      s2 += (double)du * xh;
+    }
+    s1 = block_sum(s1, sh);
+    s2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) {
+      dbeta_s[(size_t)b * C + ch] = (float)s1;
+      dgamma_s[(size_t)b * C + ch] = (float)s2;
+    }
+    A += (double)ga * s1;
+    Bq += (double)ga * s2;
+  }
+  const float mA = (float)(A / (double)n), mB = (float)(Bq / (double)n);
+  for (int c = 0; c < cpg; ++c) {
+    const int ch = g * cpg + c;
+    const float ga = gamma[ch], be = beta[ch];
+    const size_t cb = base + (size_t)c * HW;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+      const float xh = (x[cb + i] - mu) * rstd;
+      const float du = dy[cb + i] * bw_dact(xh * ga + be, act);
+      dx[cb + i] = rstd * (du * ga - mA - xh * mB);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// strided batched GEMM, fp32 FMA:  C[z][m][n] = alpha * sum_k A[z][m*sam + k*sak] * B[z][k*sbk + n*sbn]
+// 64x64 tile, 256 threads x (4x4), K step 16 through LDS.  Used where the contraction is a few % of the network's
+// FLOPs (attention backward at L <= 400, Linear backward on [B, <= 2048]).
+// ---------------------------------------------------------------------------------------------------------------
+struct GemmDesc {
+  int M, N, K;
+  long long sam, sak, sbk, sbn, scm, scn, za, zb, zc;
+  float alpha;
+};
+
+__global__ __launch_bounds__(256) void bgemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                    float* __restrict__ Cm, GemmDesc d) {
+  __shared__ float As[16][65], Bs[16][65];
+  const int z = blockIdx.z;
+  A += (size_t)z * d.za; Bm += (size_t)z * d.zb; Cm += (size_t)z * d.zc;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  // loader mapping: pick the thread->element order that makes the unit-stride index the fast one
+  const bool a_mfast = d.sam == 1 || (d.sak != 1 && d.sam < d.sak);
+  const bool b_nfast = d.sbn == 1 || (d.sbk != 1 && d.sbn < d.sbk);
+  for (int k0 = 0; k0 < d.K; k0 += 16) {
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+      const int mm = a_mfast ? (e & 63) : (e >> 4), kk = a_mfast ? (e >> 6) : (e & 15);
+      const int gm = m0 + mm, gk = k0 + kk;
+      As[kk][mm] = (gm < d.M && gk < d.K) ? A[(long long)gm * d.sam + (long long)gk * d.sak] : 0.f;
+      const int nn = b_nfast ? (e & 63) : (e >> 4), kb = b_nfast ? (e >> 6) : (e & 15);
+      const int gn = n0 + nn, gkb = k0 + kb;
+      Bs[kb][nn] = (gn < d.N && gkb < d.K) ? Bm[(long long)gkb * d.sbk + (long long)gn * d.sbn] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = As[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gm = m0 + ty * 4 + i, gn = n0 + tx * 4 + j;
+      if (gm < d.M && gn < d.N) Cm[(long long)gm * d.scm + (long long)gn * d.scn] = d.alpha * acc[i][j];
+    }
+}
+
+int bgemm_launch(const float* A, const float* Bm, float* Cm, const GemmDesc& d, int batch, hipStream_t s) {
+  hipLaunchKernelGGL(bgemm_kernel, dim3(cdiv(d.N, 64), cdiv(d.M, 64), batch), dim3(256), 0, s, A, Bm, Cm, d);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+// softmax over the rows of [R, L] in place (one wave per row)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S, long long R, int L) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int lane = threadIdx.x & 63;
+  float* row = S + r * L;
+  float mx = -INFINITY;
+  for (int j = lane; j < L; j += 64) mx = fmaxf(mx, row[j]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  float sum = 0.f;
+  for (int j = lane; j < L; j += 64) { const float e = expf(row[j] - mx); row[j] = e; sum += e; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  const float inv = 1.0f / sum;
+  for (int j = lane; j < L; j += 64) row[j] *= inv;
+}
+
+// dS = P * (dP - sum_j P*dP), written over dP
+__global__ __launch_bounds__(256) void dsoftmax_rows_kernel(const float* __restrict__ P, float* __restrict__ dP, long long R,
+                                                            int L) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int lane = threadIdx.x & 63;
+  const float* p = P + r * L;
+  float* g = dP + r * L;
+  float dot = 0.f;
+  for (int j = lane; j < L; j += 64) dot += p[j] * g[j];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+  for (int j = lane; j < L; j += 64) g[j] = p[j] * (g[j] - dot);
+}
+
+// out[r] = sum over `inner` contiguous floats of row r (fp64 accumulation); one wave per row
+__global__ __launch_bounds__(256) void sum_inner_kernel(const float* __restrict__ x, float* __restrict__ out, long long rows,
+                                                        long long inner) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* p = x + r * inner;
+  double s = 0.0;
+  for (long long i = lane; i < inner; i += 64) s += (double)p[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) out[r] = (float)s;
+}
+
+// out[c] = sum_r x[r][c]  (fp64 accumulation, fixed order)
+__global__ void sum_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int r = 0; r < R; ++r) s += (double)x[(size_t)r * C + c];
+  out[c] = (float)s;
+}
+
+// dy == null: out = act(x);  else out = dy * act'(x)
+__global__ void act_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out, int act,
+                           size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = dy ? dy[i] * bw_dact(x[i], act) : bw_act(x[i], act);
+}
+
+__global__ void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = a[i] * b[i];
+}
+
+// Philox4x32-10 (same generator as csd_randn): 4 uniforms per counter
+__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+// nn.Dropout(p) in training mode: mask = (u >= p) / (1 - p), out = x * mask
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ out, float* __restrict__ mask, float p,
+                               uint64_t seed, uint64_t stream_id, size_t n) {
+  const float keep = 1.0f / (1.0f - p);
+  const size_t n4 = (n + 3) / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+    philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t e = i * 4 + j;
+      if (e < n) {
+        const float u = (float)(c[j] >> 8) * (1.0f / 16777216.0f);
+        const float mk = u >= p ? keep : 0.f;
+        mask[e] = mk;
+        out[e] = x[e] * mk;
+      }
+    }
+  }
+}
+
+inline unsigned ew_grid(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 65536); }
+
+}  // namespace
+
+// ===============================================================================================================
+// C ABI
+// ===============================================================================================================
+extern "C" size_t csd_conv_wgrad_scratch_bytes(int B, int Cin, int Cout, int H, int W, int ksize, int stride, int up2) {
+  const int OH = (H << (up2 ? 1 : 0)) / stride, OW = (W << (up2 ? 1 : 0)) / stride;
+  int per;
+  const int S = wgrad_splits(B, OH, OW, Cin, Cout, &per);
+  return (al64((size_t)B * H * W * Cin) + al64((size_t)B * OH * OW * Cout) +
+          al64((size_t)S * Cout * Cin * ksize * ksize)) * sizeof(float) + 1024;
+}
+
+extern "C" int csd_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W,
+                                int ksize, int stride, int pad_mode, int up2, void* scratch, void* stream) {
+  CSD_REQUIRE(x && dy && dw && scratch, "conv2d_wgrad: null argument");
+  CSD_REQUIRE(ksize == 1 || ksize == 3, "conv2d_wgrad: ksize must be 1 or 3");
+  CSD_REQUIRE(stride == 1 || stride == 2, "conv2d_wgrad: stride must be 1 or 2");
+  CSD_REQUIRE(!(up2 && stride != 1), "conv2d_wgrad: up2 requires stride 1");
+  int pad;
+  if (stride == 2) {
+    CSD_REQUIRE(pad_mode == 1 && ksize == 3 && H % 2 == 0 && W % 2 == 0, "conv2d_wgrad: stride 2 is the reference Downsample");
+    pad = 0;
+  } else {
+    CSD_REQUIRE(pad_mode == 0, "conv2d_wgrad: stride 1 uses symmetric padding");
+    pad = ksize / 2;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int up = up2 ? 1 : 0;
+  const int OH = (H << up) / stride, OW = (W << up) / stride;
+  int per;
+  const int S = wgrad_splits(B, OH, OW, Cin, Cout, &per);
+  float* f = static_cast<float*>(scratch);
+  float* xh = f; f += al64((size_t)B * H * W * Cin);
+  float* dyh = f; f += al64((size_t)B * OH * OW * Cout);
+  float* partial = f;
+  int rc;
+  if ((rc = nchw_to_nhwc_launch(x, xh, B, Cin, H * W, Cin, Cin, s))) return rc;
+  if ((rc = nchw_to_nhwc_launch(dy, dyh, B, Cout, OH * OW, Cout, Cout, s))) return rc;
+  const dim3 grid(S, cdiv(Cin, 32), cdiv(Cout, 32));
+  if (ksize == 3)
+    hipLaunchKernelGGL(conv_wgrad_kernel<9>, grid, dim3(256), 0, s, xh, dyh, partial, B, H, W, Cin, Cin, OH, OW, Cout, stride,
+                       pad, up, per);
+  else
+    hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, s, xh, dyh, partial, B, H, W, Cin, Cin, OH, OW, Cout, stride,
+                       pad, up, per);
+  CSD_LAUNCH_CHECK();
+  const size_t n = (size_t)Cout * Cin * ksize * ksize;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(n)), dim3(256), 0, s, partial, dw, n, S);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+extern "C" int csd_groupnorm_act_backward(const float* x, const float* gamma, const float* beta, const float* dy, float* dx,
+                                          float* dgamma_rows, float* dbeta_rows, int B, int C, int H, int W, int groups,
+                                          float eps, int act, void* stream) {
+  CSD_REQUIRE(x && gamma && beta && dy && dx && dgamma_rows && dbeta_rows, "groupnorm_act_backward: null argument");
+  CSD_REQUIRE(groups > 0 && C % groups == 0, "groupnorm_act_backward: %d channels not divisible into %d groups", C, groups);
+  hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, dy, dx, dgamma_rows,
+                     dbeta_rows, C, H * W, groups, eps, act);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+extern "C" int csd_bgemm(const float* A, const float* Bm, float* Cm, int M, int N, int K, int64_t sam, int64_t sak,
+                         int64_t sbk, int64_t sbn, int64_t scm, int64_t scn, int batch, int64_t za, int64_t zb, int64_t zc,
+                         float alpha, void* stream) {
+  CSD_REQUIRE(A && Bm && Cm && M > 0 && N > 0 && K > 0 && batch > 0, "bgemm: bad arguments");
+  GemmDesc d{M, N, K, sam, sak, sbk, sbn, scm, scn, za, zb, zc, alpha};
+  return bgemm_launch(A, Bm, Cm, d, batch, (hipStream_t)stream);
+}
+
+extern "C" size_t csd_attention_backward_scratch_bytes(int B, int C, int H, int W) {
+  const size_t L = (size_t)H * W;
+  return 2 * al64((size_t)B * L * L) * sizeof(float) + 1024;
+}
+
+// q, k, v, dout, dq, dk, dv: [B, C, H, W]; the forward is csd_attention (models/layers.py:584-588)
+extern "C" int csd_attention_backward(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
+                                      float* dv, int B, int C, int H, int W, void* scratch, void* stream) {
+  CSD_REQUIRE(q && k && v && dout && dq && dk && dv && scratch, "attention_backward: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int L = H * W;
+  const long long zq = (long long)C * L, zs = (long long)L * L;
+  const float scale = 1.0f / sqrtf((float)C);
+  float* P = static_cast<float*>(scratch);
+  float* dP = P + al64((size_t)B * L * L);
+  int rc;
+  // S[i][j] = scale * sum_c q[c][i] k[c][j]
+  if ((rc = bgemm_launch(q, k, P, GemmDesc{L, L, C, 1, L, L, 1, L, 1, zq, zq, zs, scale}, B, s))) return rc;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv64((long long)B * L, 4)), dim3(256), 0, s, P, (long long)B * L, L);
+  CSD_LAUNCH_CHECK();
+  // dV[c][j] = sum_i dO[c][i] P[i][j]
+  if ((rc = bgemm_launch(dout, P, dv, GemmDesc{C, L, L, L, 1, L, 1, L, 1, zq, zs, zq, 1.f}, B, s))) return rc;
+  // dP[i][j] = sum_c dO[c][i] v[c][j]
+  if ((rc = bgemm_launch(dout, v, dP, GemmDesc{L, L, C, 1, L, L, 1, L, 1, zq, zq, zs, 1.f}, B, s))) return rc;
+  hipLaunchKernelGGL(dsoftmax_rows_kernel, dim3((unsigned)cdiv64((long long)B * L, 4)), dim3(256), 0, s, P, dP, (long long)B * L,
+                     L);
+  CSD_LAUNCH_CHECK();
+  // dq[c][i] = scale * sum_j k[c][j] dS[i][j]
+  if ((rc = bgemm_launch(k, dP, dq, GemmDesc{C, L, L, L, 1, 1, L, L, 1, zq, zs, zq, scale}, B, s))) return rc;
+  // dk[c][j] = scale * sum_i q[c][i] dS[i][j]
+  return bgemm_launch(q, dP, dk, GemmDesc{C, L, L, L, 1, L, 1, L, 1, zq, zs, zq, scale}, B, s);
+}
+
+extern "C" int csd_sum_inner(const float* x, float* out, int64_t rows, int64_t inner, void* stream) {
+  CSD_REQUIRE(x && out && rows > 0 && inner > 0, "sum_inner: bad arguments");
+  hipLaunchKernelGGL(sum_inner_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, out,
+                     (long long)rows, (long long)inner);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+extern "C" int csd_sum_rows(const float* x, float* out, int R, int C, void* stream) {
+  CSD_REQUIRE(x && out && R > 0 && C > 0, "sum_rows: bad arguments");
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, x, out, R, C);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+extern "C" int csd_act(const float* x, const float* dy, float* out, int act, int64_t n, void* stream) {
+  CSD_REQUIRE(x && out && n > 0, "act: bad arguments");
+  hipLaunchKernelGGL(act_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)stream, x, dy, out, act, (size_t)n);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+extern "C" int csd_mul(const float* a, const float* b, float* out, int64_t n, void* stream) {
+  CSD_REQUIRE(a && b && out && n > 0, "mul: bad arguments");
+  hipLaunchKernelGGL(mul_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (size_t)n);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+extern "C" int csd_dropout(const float* x, float* out, float* mask, float p, uint64_t seed, uint64_t stream_id, int64_t n,
+                           void* stream) {
+  CSD_REQUIRE(x && out && mask && n > 0 && p >= 0.f && p < 1.f, "dropout: bad arguments");
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid((size_t)(n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, out, mask, p, seed,
+                     stream_id, (size_t)n);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}

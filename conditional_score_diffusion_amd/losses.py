@@ -1,4 +1,4 @@
-"""Score-matching losses with the reference's factories (losses.py:55-232) - **evaluation (forward) value only**.
+"""Score-matching losses with the reference's factories (losses.py:55-232): evaluation value and training loss.
 
 ``get_sde_loss_fn`` / ``get_general_sde_loss_fn`` return ``loss_fn(model, batch) -> scalar tensor`` with the reference's
 argument meaning: per-sample ``t ~ U(eps, T)``, perturbation ``x_t = mean + std * z``, score evaluation, and the
@@ -6,13 +6,15 @@ argument meaning: per-sample ``t ~ U(eps, T)``, perturbation ``x_t = mean + std 
 batch.  Every pixel-sized operation runs on the HIP kernels (perturbation: csd_scale_rows + csd_axpby; residual:
 csd_scale_rows + csd_axpby; per-sample squared norms: csd_row_norms); the remaining arithmetic is on B scalars.
 
-The value carries NO autograd graph: the backward of the network (dX/dW of every layer and the
-gradient all-reduce) is not built yet, so ``train=True`` raises NotImplementedError instead of returning a loss that
-silently cannot be differentiated.
+``train=False`` (the reference's eval step) evaluates the network on the planned graph executor and returns a plain value.
+``train=True`` puts the model in training mode: the network runs on the differentiable HIP operators (grad_ops: forward and
+backward kernels of csrc/backward.hip, dropout on), the residual / per-sample reduction are differentiable HIP operators too,
+and the returned scalar is autograd-connected - ``loss.backward()`` fills ``param.grad`` of every network parameter
+(SURVEY.md 8 rows a19/a20).  The last reduction over the B per-sample values is torch arithmetic on a [B] tensor.
 """
 import torch
 
-from . import ops, sde_lib
+from . import grad_ops, ops, sde_lib
 from .models import utils as mutils
 
 
@@ -33,6 +35,12 @@ def _perturb(x, z, m, std):
 def _residual_sumsq(score, z, std, weighting):
     """per-sample sum of squares of (score*std + z) [weighting False] or (score + z/std) [True] -> [B] host tensor."""
     dev = score.device
+    if score.requires_grad:            # training: differentiable operators, [B] device tensor
+        if weighting:
+            d = grad_ops.axpby(score, ops.scale_rows(z, std.to(dev), divide=True))
+        else:
+            d = grad_ops.axpby(grad_ops.scale_rows(score, std.to(dev)), z)
+        return grad_ops.sumsq_rows(d)
     if weighting:
         d = ops.axpby(score, ops.scale_rows(z, std.to(dev), divide=True))
     else:
@@ -50,18 +58,11 @@ def _g2(sde, t):
     return (sde.sde(torch.zeros(t.shape[0], 1, 1, 1), t)[1].flatten().double()) ** 2
 
 
-def _check_eval(train):
-    if train:
-        raise NotImplementedError('training loss needs the network backward (SURVEY.md 8 a19/a20), which the HIP path does '
-                                  'not provide yet; use train=False for the evaluation loss value')
-
-
 def get_sde_loss_fn(sde, train, reduce_mean=True, continuous=True, likelihood_weighting=True, eps=1e-5):
     """losses.py:55-97 (unconditional)."""
-    _check_eval(train)
 
     def loss_fn(model, batch):
-        score_fn = mutils.get_score_fn(sde, model, train=False, continuous=continuous)
+        score_fn = mutils.get_score_fn(sde, model, train=train, continuous=continuous)
         t = torch.rand(batch.shape[0]) * (sde.T - eps) + eps
         z = torch.randn_like(batch)
         m, std = _bstd(sde, batch, t)
@@ -69,7 +70,7 @@ def get_sde_loss_fn(sde, train, reduce_mean=True, continuous=True, likelihood_we
         per = batch[0].numel()
         losses = _reduce(_residual_sumsq(score, z, std, likelihood_weighting), per, reduce_mean)
         if likelihood_weighting:
-            losses = losses * _g2(sde, t)
+            losses = losses * _g2(sde, t).to(losses)
         return losses.mean().float()
 
     return loss_fn
@@ -78,7 +79,6 @@ def get_sde_loss_fn(sde, train, reduce_mean=True, continuous=True, likelihood_we
 def get_general_sde_loss_fn(sde, train, conditional=False, reduce_mean=True, continuous=True, likelihood_weighting=True,
                             eps=1e-5):
     """losses.py:99-232: unconditional, SR3 (one conditional SDE, clean y) and the two-SDE CMDE / VS-CMDE branch."""
-    _check_eval(train)
     if not conditional:
         return get_sde_loss_fn(sde, train, reduce_mean, continuous, likelihood_weighting, eps)
     if isinstance(sde, dict):
@@ -88,15 +88,17 @@ def get_general_sde_loss_fn(sde, train, conditional=False, reduce_mean=True, con
 
         def loss_fn(model, batch):
             y, x = batch
-            score_fn = mutils.get_score_fn(sde, model, conditional=True, train=False, continuous=continuous)
+            score_fn = mutils.get_score_fn(sde, model, conditional=True, train=train, continuous=continuous)
             t = torch.rand(x.shape[0]) * (sde['x'].T - eps) + eps
             z_y = torch.randn_like(y)
             m_y, std_y = _bstd(sde['y'], y, t)
             z_x = torch.randn_like(x)
             m_x, std_x = _bstd(sde['x'], x, t)
             score = score_fn({'x': _perturb(x, z_x, m_x, std_x), 'y': _perturb(y, z_y, m_y, std_y)}, t.to(x.device))
-            sx = _residual_sumsq(score['x'].contiguous(), z_x, std_x, True) * _g2(sde['x'], t)
-            sy = _residual_sumsq(score['y'].contiguous(), z_y, std_y, True) * _g2(sde['y'], t)
+            sx = _residual_sumsq(score['x'].contiguous(), z_x, std_x, True)
+            sx = sx * _g2(sde['x'], t).to(sx)
+            sy = _residual_sumsq(score['y'].contiguous(), z_y, std_y, True)
+            sy = sy * _g2(sde['y'], t).to(sy)
             numel = x[0].numel() + y[0].numel()          # the reference concatenates both residuals before reducing
             return _reduce(sx + sy, numel, reduce_mean).mean().float()
 
@@ -104,14 +106,14 @@ def get_general_sde_loss_fn(sde, train, conditional=False, reduce_mean=True, con
 
     def loss_fn(model, batch):          # SR3 estimator (losses.py:185-205)
         y, x = batch
-        score_fn = mutils.get_score_fn(sde, model, conditional=True, train=False, continuous=continuous)
+        score_fn = mutils.get_score_fn(sde, model, conditional=True, train=train, continuous=continuous)
         t = torch.rand(x.shape[0]) * (sde.T - eps) + eps
         z = torch.randn_like(x)
         m, std = _bstd(sde, x, t)
         score = score_fn({'x': _perturb(x, z, m, std), 'y': y}, t.to(x.device))
         losses = _reduce(_residual_sumsq(score, z, std, likelihood_weighting), x[0].numel(), reduce_mean)
         if likelihood_weighting:
-            losses = losses * _g2(sde, t)
+            losses = losses * _g2(sde, t).to(losses)
         return losses.mean().float()
 
     return loss_fn

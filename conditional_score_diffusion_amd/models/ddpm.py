@@ -69,6 +69,9 @@ class HipUNet(nn.Module):
         act = m.nonlinearity.lower()
         if act not in _lib.ACT_IDS or act == 'none':
             raise NotImplementedError('activation function does not exist!')   # models/layers.py:29-41
+        self._act_name = act
+        self._train_calls = 0
+        self.dropout_seed = int(getattr(config, 'seed', 0) or 0)   # Philox key of the dropout masks
         cfg = _lib.UNetConfig()
         cfg.arch = self.arch
         cfg.nf = m.nf
@@ -196,10 +199,11 @@ class HipUNet(nn.Module):
 
     # -- evaluation --------------------------------------------------------------------------------
     def _run(self, x, y, labels, y_noise=None, y_sigma=0.0):
-        if self.training and self._dropout > 0 and torch.is_grad_enabled():
-            raise RuntimeError('training-mode evaluation (dropout %.2f + autograd) is not provided by the HIP '
-                               'library yet; call model.eval() / torch.no_grad()' % self._dropout)
         require_gpu_tensor(x, 'x')
+        if self.training and torch.is_grad_enabled():
+            if y_noise is not None:
+                raise RuntimeError('the fused y-perturbation is a sampling feature; perturb y before a training step')
+            return self._train_forward(x, y, labels)
         B = x.shape[0]
         S = self.image_size
         if tuple(x.shape) != (B, self.x_channels, S, S):
@@ -220,6 +224,91 @@ class HipUNet(nn.Module):
                                      ptr(y_noise) if y_noise is not None else None, float(y_sigma),
                                      current_stream(x.device)), 'unet_forward')
         return out
+
+
+    # -- training-mode evaluation: differentiable, operator-granular ------------------------------------------
+    def _train_forward(self, x, y, labels):
+        """``model.train()`` + autograd: the reference forward (models/ddpm.py:149-213) layer by layer on the
+        differentiable HIP operators of grad_ops (forward AND backward kernels behind include/csd.h), with
+        ``nn.Dropout`` active (models/layers.py:647,662).  The planned graph executor (csd_unet_forward) stays the
+        inference path; this one keeps every activation that a gradient needs."""
+        from .. import grad_ops as G, ops
+        if self.arch != 0:
+            raise NotImplementedError('training-mode evaluation of this architecture uses its operator-granular class')
+        if not self._cfg.resamp_with_conv:
+            raise NotImplementedError('training with resamp_with_conv=False is not provided')
+        m, prec, act = self.all_modules, self.precision, self._act_name
+        B, S = x.shape[0], self.image_size
+        if tuple(x.shape) != (B, self.x_channels, S, S):
+            raise RuntimeError('x has shape %s, expected %s' % (tuple(x.shape), (B, self.x_channels, S, S)))
+        labels = labels.to(device=x.device, dtype=torch.float32).contiguous()
+        self._train_calls += 1
+        drop = [0]
+
+        def dropout(h):
+            drop[0] += 1
+            return G.dropout(h, self._dropout, self.dropout_seed, (self._train_calls << 16) + drop[0])
+
+        def res(node, h, temb):
+            cin, cout = h.shape[1], node.Conv_0.weight.shape[0]
+            t = G.groupnorm_act(h, node.GroupNorm_0.weight, node.GroupNorm_0.bias, 32, 1e-6, act)
+            t = G.conv2d(t, node.Conv_0.weight, node.Conv_0.bias, precision=prec)
+            if temb is not None:
+                t = G.bias_add_nchw(t, G.linear(temb, node.Dense_0.weight, node.Dense_0.bias, act_in=act))
+            t = G.groupnorm_act(t, node.GroupNorm_1.weight, node.GroupNorm_1.bias, 32, 1e-6, act)
+            t = G.conv2d(dropout(t), node.Conv_1.weight, node.Conv_1.bias, precision=prec)
+            if cin != cout:
+                h = G.nin(h, node.NIN_0.W, node.NIN_0.b, prec)
+            return G.axpby(h, t)
+
+        def attn(node, h):
+            t = G.groupnorm_act(h, node.GroupNorm_0.weight, node.GroupNorm_0.bias, 32, 1e-6, 'none')
+            q = G.nin(t, node.NIN_0.W, node.NIN_0.b, prec)
+            k = G.nin(t, node.NIN_1.W, node.NIN_1.b, prec)
+            v = G.nin(t, node.NIN_2.W, node.NIN_2.b, prec)
+            t = G.nin(G.attention(q, k, v), node.NIN_3.W, node.NIN_3.b, prec)
+            return G.axpby(h, t)
+
+        h = torch.cat([x, y], dim=1) if self.y_channels else x
+        i = 0
+        temb = None
+        if self.conditional:
+            temb = ops.timestep_embedding(labels, self.nf)
+            temb = G.linear(temb, m[0].weight, m[0].bias)
+            temb = G.linear(temb, m[1].weight, m[1].bias, act_in=act)
+            i = 2
+        if not self.centered:
+            h = G.axpby(h, None, 2.0, 0.0, -1.0, 1.0)
+        hs = [G.conv2d(h, m[i].weight, m[i].bias, precision=prec)]
+        i += 1
+        for lvl in range(self.num_resolutions):
+            for _ in range(self.num_res_blocks):
+                h = res(m[i], hs[-1], temb)
+                i += 1
+                if h.shape[-1] in self.attn_resolutions:
+                    h = attn(m[i], h)
+                    i += 1
+                hs.append(h)
+            if lvl != self.num_resolutions - 1:
+                hs.append(G.conv2d(hs[-1], m[i].Conv_0.weight, m[i].Conv_0.bias, stride=2, downsample_pad=True, precision=prec))
+                i += 1
+        h = res(m[i], hs[-1], temb)
+        h = attn(m[i + 1], h)
+        h = res(m[i + 2], h, temb)
+        i += 3
+        for lvl in reversed(range(self.num_resolutions)):
+            for _ in range(self.num_res_blocks + 1):
+                h = res(m[i], torch.cat([h, hs.pop()], dim=1), temb)
+                i += 1
+            if h.shape[-1] in self.attn_resolutions:
+                h = attn(m[i], h)
+                i += 1
+            if lvl != 0:
+                h = G.conv2d(h, m[i].Conv_0.weight, m[i].Conv_0.bias, up2=True, precision=prec)
+                i += 1
+        assert not hs and i == len(m) - 2
+        h = G.groupnorm_act(h, m[i].weight, m[i].bias, 32, 1e-6, act)
+        return G.conv2d(h, m[i + 1].weight, m[i + 1].bias, precision=prec)
 
 
 @utils.register_model(name='ddpm')

@@ -71,6 +71,9 @@ def get_model_fn(model, train=False):
 def _div_rows(h, denom):
     """h / denom[b] with the HIP row-scale kernel on GPU tensors (host torch only for CPU inputs,
     e.g. the loss-side bookkeeping of tiny tensors)."""
+    if h.is_cuda and h.requires_grad:
+        from .. import grad_ops
+        return grad_ops.scale_rows(h, denom.to(device=h.device, dtype=torch.float32).contiguous(), divide=True)
     if h.is_cuda:
         return ops.scale_rows(h, denom.to(device=h.device, dtype=torch.float32).contiguous(), divide=True)
     return h / denom[(...,) + (None,) * (h.dim() - 1)]

@@ -245,6 +245,43 @@ int csd_axpby(const float* a, const float* b, float* out, float alpha, float bet
 int csd_bias_add_nchw(const float* x, const float* bias, float* out, int B, int C, int64_t inner,
                       int bias_stride, int act, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Gradient operators (csrc/backward.hip) - the autograd backward the reference gets from torch for its layers
+ * (the training step of run_lib.py:55-73 / losses.py:99-232).  NCHW fp32 like the forward
+ * operators.  The DATA gradient of a convolution is csd_conv2d on dy with the flipped, transposed weight (stride 2:
+ * dy zero-inserted with csd_upfirdn2d; nearest-x2: a 2x2 sum of the result), so only the weight gradient is new.
+ * ---------------------------------------------------------------------------------------- */
+/* dw[Cout, Cin, k, k] = sum over batch and pixels of dy (x) x for the convolution csd_conv2d(x; ksize, stride,
+ * pad_mode, up2) with x [B, Cin, H, W], dy [B, Cout, OH, OW].  fp32 MFMA, deterministic split-K reduction. */
+size_t csd_conv_wgrad_scratch_bytes(int B, int Cin, int Cout, int H, int W, int ksize, int stride, int up2);
+int csd_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W, int ksize,
+                     int stride, int pad_mode, int up2, void* scratch, void* stream);
+/* backward of csd_groupnorm_act: dx [B,C,H,W]; dgamma_rows / dbeta_rows [B, C] hold the per-sample sums
+ * (dgamma = csd_sum_rows of them) */
+int csd_groupnorm_act_backward(const float* x, const float* gamma, const float* beta, const float* dy, float* dx,
+                               float* dgamma_rows, float* dbeta_rows, int B, int C, int H, int W, int groups, float eps,
+                               int act, void* stream);
+/* backward of csd_attention: dq, dk, dv from dout; scratch csd_attention_backward_scratch_bytes() */
+size_t csd_attention_backward_scratch_bytes(int B, int C, int H, int W);
+int csd_attention_backward(const float* q, const float* k, const float* v, const float* dout, float* dq, float* dk,
+                           float* dv, int B, int C, int H, int W, void* scratch, void* stream);
+/* strided batched fp32 GEMM  C[z][m*scm + n*scn] = alpha * sum_k A[z][m*sam + k*sak] * B[z][k*sbk + n*sbn]
+ * (z-strides za, zb, zc): the Linear / NIN-free contractions of the backward (dIn = dOut.W, dW = dOut^T.act(in)) */
+int csd_bgemm(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbk,
+              int64_t sbn, int64_t scm, int64_t scn, int batch, int64_t za, int64_t zb, int64_t zc, float alpha,
+              void* stream);
+/* out[r] = sum of row r ([rows, inner], fp64 accumulation): per-(sample, channel) sums of dy = gradient of a
+ * broadcast bias / time-embedding add;  out[c] = sum_r x[r][c]: the batch reduction that follows */
+int csd_sum_inner(const float* x, float* out, int64_t rows, int64_t inner, void* stream);
+int csd_sum_rows(const float* x, float* out, int R, int C, void* stream);
+/* dy == NULL: out = act(x); else out = dy * act'(x) */
+int csd_act(const float* x, const float* dy, float* out, int act, int64_t n, void* stream);
+int csd_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* nn.Dropout(p) in training mode (models/layers.py:647,662): mask = (u >= p)/(1-p) from Philox4x32-10 keyed by
+ * (seed, stream_id), out = x * mask; the backward is csd_mul(dy, mask) */
+int csd_dropout(const float* x, float* out, float* mask, float p, uint64_t seed, uint64_t stream_id, int64_t n,
+                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

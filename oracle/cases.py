@@ -144,3 +144,24 @@ def pc_tape_shapes(case, p_steps, B=None):
     for _ in range(p_steps):
         shapes += per_phase + per_phase
     return shapes
+
+
+def grad_case(case):
+    """Inputs of the training-loss / gradient fixtures (tests/golden/grads.npz): config with dropout off, data batch,
+    fixed times and the noise tape in the loss's draw order."""
+    cfg, B = case_config(case)
+    cfg.model.dropout = 0.0
+    rs = np.random.RandomState(11)
+    xs, ys = (B,) + tuple(cfg.data.shape_x), (B,) + tuple(cfg.data.shape_y)
+    x = torch.from_numpy(rs.uniform(0, 1, size=xs).astype(np.float32))
+    y = case_y(case)
+    t = torch.tensor([0.83, 0.21][:B])
+    shapes = [ys, xs] if cfg.model.name == 'ddpm_paired' else [xs]
+    return cfg, B, x, y, t, tape(shapes, 3)
+
+
+def grad_sample_index(name, numel, n=48):
+    """the fixed entries of a parameter's gradient that the fixture stores"""
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7fffffff)
+    return np.sort(rs.choice(numel, size=min(n, numel), replace=False))

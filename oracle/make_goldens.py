@@ -295,6 +295,46 @@ def gen_losses(ref):
     np.savez_compressed(os.path.join(OUT, 'losses.npz'), **out)
 
 
+def gen_grads(ref):
+    """Training loss (losses.py:99-232, train=True, dropout 0) and its parameter gradients from the reference's autograd on the
+    tiny cases -> tests/golden/grads.npz: loss, and per parameter the gradient's L2 norm and its values at fixed entries."""
+    L = ref['losses']
+    out = {}
+    for case in cases.CASES:
+        cfg, B, x, y, tvals, tape = cases.grad_case(case)
+        model, _ = build_ref_model(ref, cfg)
+        sde = sdes_for(ref, cfg)
+        if cfg.model.name == 'ddpm':
+            model.embedding_type = 'positional'
+            fn, batch = L.get_general_sde_loss_fn(sde, True, False, True, True, True), x
+        else:
+            fn, batch = L.get_general_sde_loss_fn(sde, True, True, True, True, True), (y, x)
+        orig = torch.rand
+        torch.rand = lambda *a, **k: tvals.clone()
+        try:
+            with ref_import.TapeRandn(tape):
+                loss = fn(model, batch)
+        finally:
+            torch.rand = orig
+        assert model.training
+        loss.backward()
+        out[case + '_loss'] = np.float64(loss.item())
+        names, norms, samples = [], [], []
+        for k, prm in model.named_parameters():
+            g = prm.grad.detach().reshape(-1).double().numpy()
+            names.append(k)
+            norms.append(np.sqrt((g * g).sum()))
+            idx = cases.grad_sample_index(k, g.size)
+            sm = np.zeros(48)
+            sm[:idx.size] = g[idx]
+            samples.append(sm)
+        out[case + '_names'] = np.array(names)
+        out[case + '_norms'] = np.array(norms)
+        out[case + '_samples'] = np.array(samples)
+        print(case, 'loss', float(loss), 'grad norm', float(np.sqrt((np.array(norms) ** 2).sum())), len(names), 'tensors')
+    np.savez_compressed(os.path.join(OUT, 'grads.npz'), **out)
+
+
 def gen_ncsnpp(ref):
     """Reference NCSN++ forward (models/ncsnpp.py) on the seeded cases of cases.NCSNPP_CASES -> tests/golden/ncsnpp.npz:
     state_dict key order + shapes (as a string table) and the network output."""
@@ -322,6 +362,11 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = ref_import.modules()
+    if len(sys.argv) > 1:          # regenerate selected fixtures only: python oracle/make_goldens.py grads losses
+        for name in sys.argv[1:]:
+            globals()['gen_' + name](ref)
+        return
+    gen_grads(ref)
     gen_sde_tables(ref)
     gen_modules(ref)
     gen_steps(ref)

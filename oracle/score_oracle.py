@@ -583,3 +583,38 @@ def pc_sample_unconditional(score_fn, shape, noise, ve, p_steps=1000, snr=0.15, 
         s = score_fn(x, vec_t)
         x, x_mean = reverse_diffusion_update(s, x, noise(x), ve.G(vec_t))
     return x_mean if denoise else x
+
+
+# ------------------------------------------------------------------------------------------
+# denoising score-matching loss (training objective), VE SDEs
+# ------------------------------------------------------------------------------------------
+def _g2(ve, t):
+    """diffusion^2 of (c)VESDE.sde (sde_lib.py:310-314,383-388): (sigma(t) sqrt(2 ln(smax/smin)))^2"""
+    return (ve.std(t) * torch.sqrt(torch.tensor(2 * (np.log(ve.sigma_max) - np.log(ve.sigma_min))).type_as(t))) ** 2
+
+
+def dsm_loss(p, cfg, name, ve_x, ve_y, x, y, t, z_x, z_y=None, reduce_mean=True, likelihood_weighting=True):
+    """get_general_sde_loss_fn (losses.py:99-232) for the VE SDEs with supplied t and noise (dropout off):
+    ``name`` 'ddpm' = unconditional branch (:208-232, score_fn models/utils.py:246-253: label sigma(t)),
+    'ddpm_paired_SR3' = SR3 branch (:185-205), 'ddpm_paired' = two-SDE branch (:120-146)."""
+    red = (lambda v: v.mean(dim=-1)) if reduce_mean else (lambda v: 0.5 * v.sum(dim=-1))
+    std_x = ve_x.std(t)
+    xt = x + _b(std_x) * z_x
+    if name == 'ddpm_paired':
+        std_y = ve_y.std(t)
+        yt = y + _b(std_y) * z_y
+        out = paired_forward(p, cfg, xt, yt, t * (ve_x.N - 1), sr3=False)
+        sx, sy = out['x'] / _b(std_x), out['y'] / _b(std_y)
+        lx = torch.square(sx + z_x / _b(std_x)) * _b(_g2(ve_x, t))
+        ly = torch.square(sy + z_y / _b(std_y)) * _b(_g2(ve_y, t))
+        losses = red(torch.cat([lx.reshape(lx.shape[0], -1), ly.reshape(ly.shape[0], -1)], dim=-1))
+        return losses.mean()
+    if name == 'ddpm':
+        score = ddpm_forward(p, cfg, xt, std_x) / _b(std_x)
+    else:
+        score = paired_forward(p, cfg, xt, y, t * (ve_x.N - 1), sr3=True) / _b(std_x)
+    if likelihood_weighting:
+        losses = red(torch.square(score + z_x / _b(std_x)).reshape(x.shape[0], -1)) * _g2(ve_x, t)
+    else:
+        losses = red(torch.square(score * _b(std_x) + z_x).reshape(x.shape[0], -1))
+    return losses.mean()

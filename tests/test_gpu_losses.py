@@ -44,9 +44,3 @@ def test_loss_values_vs_reference(golden_dir, case):
                 torch.rand, torch.randn_like = o_rand, o_like
             ref = float(g['%s_lw%d_rm%d' % (case, lw, rm)])
             assert abs(v - ref) <= 2e-5 * abs(ref), (case, lw, rm, v, ref)
-
-
-def test_training_loss_is_refused():
-    from conditional_score_diffusion_amd import losses, sde_lib
-    with pytest.raises(NotImplementedError):
-        losses.get_sde_loss_fn(sde_lib.VESDE(0.01, 50., 1000), train=True)

@@ -1,0 +1,235 @@
+"""Training side of the path: the backward kernels of csrc/backward.hip behind the differentiable
+operators of grad_ops, and the training loss + parameter gradients of the whole network against the reference's own autograd
+(tests/golden/grads.npz, oracle/make_goldens.py:gen_grads) and against the oracle's autograd.  Tolerance: 1e-3 relative fp32
+(north star); the per-operator checks are tighter."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases
+from test_gpu_network import build, dev, sdes_for
+from test_oracle_golden import check_grads_vs_fixture, oracle_loss_and_grads
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rnd(rs, *shape):
+    return torch.from_numpy(rs.standard_normal(shape).astype(np.float32))
+
+
+CONV_CASES = [  # B, Cin, Cout, H, k, stride, up2
+    (2, 32, 32, 16, 3, 1, False), (3, 6, 32, 12, 3, 1, False), (2, 32, 3, 12, 3, 1, False), (2, 40, 72, 10, 3, 1, False),
+    (2, 64, 32, 8, 1, 1, False), (2, 32, 32, 16, 3, 2, False), (2, 32, 64, 8, 3, 1, True), (1, 96, 96, 5, 3, 1, False),
+]
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,k,stride,up2', CONV_CASES)
+def test_conv2d_backward_vs_torch(B, Cin, Cout, H, k, stride, up2):
+    from conditional_score_diffusion_amd import grad_ops as G
+    rs = np.random.RandomState(5)
+    x, w, b = rnd(rs, B, Cin, H, H), rnd(rs, Cout, Cin, k, k) * 0.1, rnd(rs, Cout)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    u = F.interpolate(xr, scale_factor=2, mode='nearest') if up2 else xr
+    if stride == 2:
+        ref = F.conv2d(F.pad(u, (0, 1, 0, 1)), wr, br, stride=2)
+    else:
+        ref = F.conv2d(u, wr, br, padding=k // 2)
+    dy = rnd(rs, *ref.shape)
+    ref.backward(dy)
+    xd, wd, bd = (t.to(dev()).requires_grad_(True) for t in (x, w, b))
+    out = G.conv2d(xd, wd, bd, stride=stride, downsample_pad=stride == 2, up2=up2)
+    assert rel(out, ref) < 1e-5
+    out.backward(dy.to(dev()))
+    assert rel(xd.grad, xr.grad) < 1e-5
+    assert rel(wd.grad, wr.grad) < 1e-5
+    assert rel(bd.grad, br.grad) < 1e-5
+
+
+def test_conv2d_wgrad_is_deterministic_and_large():
+    """split-K partials are reduced in a fixed order: two runs agree bit for bit; a level-0-sized layer against torch"""
+    from conditional_score_diffusion_amd import grad_ops as G
+    rs = np.random.RandomState(6)
+    x, w = rnd(rs, 4, 96, 64, 64), rnd(rs, 96, 96, 3, 3) * 0.05
+    dy = rnd(rs, 4, 96, 64, 64)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(x, wr, None, padding=1).backward(dy)
+    got = []
+    for _ in range(2):
+        wd = w.to(dev()).requires_grad_(True)
+        G.conv2d(x.to(dev()), wd, None).backward(dy.to(dev()))
+        got.append(wd.grad.clone())
+    assert torch.equal(got[0], got[1])
+    assert rel(got[0], wr.grad) < 2e-5
+
+
+@pytest.mark.parametrize('B,C,H,groups,act', [(2, 32, 8, 32, 'swish'), (3, 64, 5, 32, 'none'), (2, 96, 12, 32, 'swish'),
+                                               (2, 48, 6, 12, 'swish')])
+def test_groupnorm_act_backward_vs_torch(B, C, H, groups, act):
+    from conditional_score_diffusion_amd import grad_ops as G
+    rs = np.random.RandomState(7)
+    x, ga, be = rnd(rs, B, C, H, H) * 2 + 0.3, rnd(rs, C) * 0.5 + 1, rnd(rs, C) * 0.2
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, ga, be))
+    ref = F.group_norm(xr, groups, gr, br, eps=1e-6)
+    ref = F.silu(ref) if act == 'swish' else ref
+    dy = rnd(rs, *ref.shape)
+    ref.backward(dy)
+    xd, gd, bd = (t.to(dev()).requires_grad_(True) for t in (x, ga, be))
+    out = G.groupnorm_act(xd, gd, bd, groups, 1e-6, act)
+    assert rel(out, ref) < 1e-5
+    out.backward(dy.to(dev()))
+    assert rel(xd.grad, xr.grad) < 2e-5
+    assert rel(gd.grad, gr.grad) < 2e-5
+    assert rel(bd.grad, br.grad) < 2e-5
+
+
+@pytest.mark.parametrize('B,C,H', [(2, 32, 4), (2, 64, 8), (1, 96, 10), (2, 288, 5)])
+def test_attention_backward_vs_torch(B, C, H):
+    from conditional_score_diffusion_amd import grad_ops as G
+    rs = np.random.RandomState(8)
+    q, k, v = rnd(rs, B, C, H, H), rnd(rs, B, C, H, H), rnd(rs, B, C, H, H)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    w = torch.einsum('bchw,bcij->bhwij', qr, kr) * (int(C) ** (-0.5))        # models/layers.py:584-588
+    w = F.softmax(w.reshape(B, H, H, H * H), dim=-1).reshape(B, H, H, H, H)
+    ref = torch.einsum('bhwij,bcij->bchw', w, vr)
+    do = rnd(rs, *ref.shape)
+    ref.backward(do)
+    qd, kd, vd = (t.to(dev()).requires_grad_(True) for t in (q, k, v))
+    out = G.attention(qd, kd, vd)
+    assert rel(out, ref) < 1e-5
+    out.backward(do.to(dev()))
+    assert rel(qd.grad, qr.grad) < 2e-5
+    assert rel(kd.grad, kr.grad) < 2e-5
+    assert rel(vd.grad, vr.grad) < 2e-5
+
+
+@pytest.mark.parametrize('B,K,N,act', [(2, 32, 128, 'none'), (5, 128, 128, 'swish'), (3, 512, 96, 'swish')])
+def test_linear_backward_vs_torch(B, K, N, act):
+    from conditional_score_diffusion_amd import grad_ops as G
+    rs = np.random.RandomState(9)
+    x, w, b = rnd(rs, B, K), rnd(rs, N, K) * 0.1, rnd(rs, N)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = F.linear(F.silu(xr) if act == 'swish' else xr, wr, br)
+    dy = rnd(rs, B, N)
+    ref.backward(dy)
+    xd, wd, bd = (t.to(dev()).requires_grad_(True) for t in (x, w, b))
+    out = G.linear(xd, wd, bd, act_in=act)
+    out.backward(dy.to(dev()))
+    assert rel(out, ref) < 1e-5
+    assert rel(xd.grad, xr.grad) < 1e-5
+    assert rel(wd.grad, wr.grad) < 1e-5
+    assert rel(bd.grad, br.grad) < 1e-5
+
+
+def test_small_differentiable_ops():
+    from conditional_score_diffusion_amd import grad_ops as G
+    rs = np.random.RandomState(10)
+    x, bias, z = rnd(rs, 3, 8, 5, 5), rnd(rs, 3, 8), rnd(rs, 3, 8, 5, 5)
+    sc = torch.tensor([0.5, 2.0, 3.0])
+    xr, br = x.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ref = (((xr + br[:, :, None, None]) * 2 - 1) / np.sqrt(2.) + z) / sc[:, None, None, None]
+    ref = (ref ** 2).reshape(3, -1).sum(-1)
+    wts = torch.tensor([1.0, -2.0, 0.5])
+    (ref * wts).sum().backward()
+    xd, bd = x.to(dev()).requires_grad_(True), bias.to(dev()).requires_grad_(True)
+    h = G.bias_add_nchw(xd, bd)
+    h = G.axpby(G.axpby(h, None, 2.0, 0.0, -1.0, 1.0 / np.sqrt(2.)), z.to(dev()))
+    out = G.sumsq_rows(G.scale_rows(h, sc.to(dev()), divide=True))
+    (out * wts.to(dev())).sum().backward()
+    assert rel(out, ref) < 1e-5
+    assert rel(xd.grad, xr.grad) < 1e-5
+    assert rel(bd.grad, br.grad) < 1e-5
+
+
+def test_dropout_mask_and_backward():
+    from conditional_score_diffusion_amd import grad_ops as G
+    x = torch.ones(4, 32, 16, 16, device=dev(), requires_grad=True)
+    y = G.dropout(x, 0.1, 1234, 7)
+    assert torch.equal(y, G.dropout(x, 0.1, 1234, 7))                 # counter-based: same key -> same mask
+    assert not torch.equal(y, G.dropout(x, 0.1, 1234, 8))
+    kept = (y != 0).float().mean().item()
+    assert abs(kept - 0.9) < 0.01
+    assert torch.allclose(y[y != 0], torch.tensor(1 / 0.9, device=dev()))
+    g = torch.randn_like(y)
+    y.backward(g)
+    assert torch.allclose(x.grad, g * y.detach())
+
+
+def _hip_loss_and_grads(case, precision='fp32'):
+    from conditional_score_diffusion_amd import losses
+    cfg, B, x, y, u, tape = cases.grad_case(case)
+    cfg, nc, p, model = build(cfg, precision)
+    sde = sdes_for(cfg)
+    if cfg.model.name == 'ddpm':
+        fn, batch = losses.get_general_sde_loss_fn(sde, True, False, True, True, True), x.to(dev())
+    else:
+        fn, batch = losses.get_general_sde_loss_fn(sde, True, True, True, True, True), (y.to(dev()), x.to(dev()))
+    it = iter(tape)
+    o_rand, o_like = torch.rand, torch.randn_like
+    torch.rand = lambda *a, **k: u.clone()
+    torch.randn_like = lambda t, **k: next(it).to(t.device)
+    try:
+        loss = fn(model, batch)
+    finally:
+        torch.rand, torch.randn_like = o_rand, o_like
+    assert model.training and loss.requires_grad
+    loss.backward()
+    return float(loss.detach()), {k: v.grad for k, v in model.named_parameters()}, model
+
+
+@pytest.mark.parametrize('case', list(cases.CASES))
+def test_training_loss_and_grads_vs_reference(golden_dir, case):
+    """loss.backward() through the HIP backward kernels vs the reference's autograd (fixture) and the oracle's (all entries)."""
+    g = np.load(os.path.join(golden_dir, 'grads.npz'))
+    loss, grads, _ = _hip_loss_and_grads(case)
+    worst = check_grads_vs_fixture(g, case, loss, grads, 1e-3)
+    o_loss, o_grads = oracle_loss_and_grads(case)
+    assert abs(loss - o_loss) <= 1e-4 * abs(o_loss)
+    total = float(np.sqrt(sum(float((v.double() ** 2).sum()) for v in o_grads.values())))
+    for k, v in o_grads.items():
+        err = float((grads[k].cpu().double() - v.double()).abs().max())
+        scale = max(float(v.abs().max()), float(v.double().norm()) / np.sqrt(v.numel()))
+        assert err <= 1e-3 * scale + 1e-6 * total / np.sqrt(v.numel()), (k, err, scale)
+    print(case, 'worst sampled rel err vs reference', worst)
+
+
+def test_training_fp16x3_grads_close_to_fp32():
+    """the split-fp16 convolutions in forward and data-gradient (weight gradient stays fp32 MFMA): fp32-class gradients"""
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'grads.npz'))
+    loss, grads, _ = _hip_loss_and_grads('sr3_tiny', 'fp16x3')
+    check_grads_vs_fixture(g, 'sr3_tiny', loss, grads, 1e-3)
+
+
+def test_sgd_steps_reduce_the_loss_with_dropout():
+    """a few plain SGD steps on a fixed batch with dropout 0.1 active: loss is finite, gradients flow to every parameter,
+    and the objective goes down."""
+    from conditional_score_diffusion_amd import losses
+    cfg, B, x, y, u, tape = cases.grad_case('sr3_tiny')
+    cfg.model.dropout = 0.1
+    cfg, nc, p, model = build(cfg)
+    sde = sdes_for(cfg)
+    fn = losses.get_general_sde_loss_fn(sde, True, True, True, True, True)
+    batch = (y.to(dev()), x.to(dev()))
+    vals = []
+    for step in range(4):
+        torch.manual_seed(0)
+        loss = fn(model, batch)
+        model.zero_grad()
+        loss.backward()
+        assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in model.parameters())
+        with torch.no_grad():
+            for q in model.parameters():
+                q -= 2e-4 * q.grad
+        vals.append(float(loss))
+    assert np.isfinite(vals).all() and vals[-1] < vals[0], vals
+    model.eval()
+    with torch.no_grad():
+        out = model({'x': batch[1], 'y': batch[0]}, torch.full((B,), 500., device=dev()))     # planned executor, repacked weights
+    assert torch.isfinite(out).all()

@@ -142,3 +142,48 @@ def test_ncsnpp_oracle_vs_reference(golden_dir, case):
         y = so.ncsnpp_forward(p, cfg, x, labels)
     ref = torch.from_numpy(g[case + '_out'])
     assert (y - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
+def oracle_loss_and_grads(case):
+    """training loss + parameter gradients of the oracle (autograd over its functional restatement) on cases.grad_case"""
+    cfg, B, x, y, u, tape = cases.grad_case(case)
+    t = u * (1 - 1e-5) + 1e-5          # losses.py:124,190,217: t = rand * (T - eps) + eps
+    nc = so.NetCfg.from_config(cfg)
+    p = {k: v.clone().requires_grad_(True) for k, v in so.synth_params(so.ddpm_param_shapes(nc), 0).items()}
+    ve_x = so.VE(cfg.model.sigma_min_x, cfg.model.sigma_max_x, cfg.model.num_scales)
+    ve_y = so.VE(cfg.model.sigma_min_y, cfg.model.sigma_max_y, cfg.model.num_scales)
+    if cfg.model.name == 'ddpm_paired':
+        loss = so.dsm_loss(p, nc, cfg.model.name, ve_x, ve_y, x, y, t, tape[1], tape[0])
+    else:
+        loss = so.dsm_loss(p, nc, cfg.model.name, ve_x, ve_y, x, y, t, tape[0])
+    loss.backward()
+    return float(loss.detach()), {k: v.grad for k, v in p.items()}
+
+
+def check_grads_vs_fixture(g, case, loss, grads, tol):
+    """loss and every parameter gradient (L2 norm + the fixture's sampled entries) against tests/golden/grads.npz"""
+    assert abs(loss - float(g[case + '_loss'])) <= tol * abs(float(g[case + '_loss']))
+    names = [str(n) for n in g[case + '_names']]
+    assert sorted(names) == sorted(grads)
+    total = float(np.sqrt((g[case + '_norms'] ** 2).sum()))
+    worst = 0.0
+    for i, k in enumerate(names):
+        gr = grads[k].detach().reshape(-1).double().cpu().numpy()
+        ref_norm = float(g[case + '_norms'][i])
+        idx = cases.grad_sample_index(k, gr.size)
+        # absolute floor: tensors whose gradient is tiny relative to the whole (e.g. behind init_scale=0 layers)
+        floor = 1e-6 * total
+        assert abs(np.sqrt((gr * gr).sum()) - ref_norm) <= tol * ref_norm + floor, (k, ref_norm)
+        err = np.abs(gr[idx] - g[case + '_samples'][i][:idx.size]).max()
+        scale = max(np.abs(g[case + '_samples'][i][:idx.size]).max(), ref_norm / np.sqrt(gr.size))
+        assert err <= tol * scale + floor / np.sqrt(gr.size), (k, err, scale)
+        worst = max(worst, err / max(scale, 1e-30))
+    return worst
+
+
+@pytest.mark.parametrize('case', list(cases.CASES))
+def test_training_loss_and_grads(golden_dir, case):
+    """a19/a20: the oracle's loss and autograd gradients reproduce the reference's (losses.py:99-232 + torch autograd)."""
+    g = load(golden_dir, 'grads')
+    loss, grads = oracle_loss_and_grads(case)
+    check_grads_vs_fixture(g, case, loss, grads, 2e-4)
