@@ -53,6 +53,7 @@ def build(verbose=False):
 
 
 _lib = None
+WEIGHT_EPOCH = [0]     # bumped by every raw-kernel write to model parameters (optimizer step, EMA copy): invalidates packed weights
 
 # name -> (restype, argtypes); mirrors include/csd.h one to one
 _vp, _i, _i64, _f, _sz, _u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
@@ -109,6 +110,8 @@ SIGNATURES = {
     'csd_sum_rows': (_i, [_vp, _vp, _i, _i, _vp]),
     'csd_act': (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
     'csd_mul': (_i, [_vp, _vp, _vp, _i64, _vp]),
+    'csd_adam_step': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _f, _vp]),
+    'csd_ema_update': (_i, [_vp, _vp, _i64, _f, _vp]),
     'csd_dropout': (_i, [_vp, _vp, _vp, _f, _u64, _u64, _i64, _vp]),
 }
 

@@ -164,7 +164,7 @@ class HipUNet(nn.Module):
     # -- packing -----------------------------------------------------------------------------------
     def _ensure_packed(self):
         params = dict(self.named_parameters())
-        key = tuple((p.data_ptr(), p._version) for p in params.values())
+        key = (_lib.WEIGHT_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in params.values())
         if self._packed is not None and key == self._packed_key:
             return
         dev = self.device

@@ -39,7 +39,10 @@ def make_config(name='ddpm_paired_SR3', nf=32, ch_mult=(1, 2, 2), num_res_blocks
                          sigma_min=sigma_min_x, sigma_max=sigma_max_x,
                          input_channels=(x_ch + y_ch) if paired else x_ch,
                          output_channels=x_ch if name != 'ddpm_paired' else x_ch + y_ch,
-                         embedding_type='positional', scale_by_sigma=True)
+                         embedding_type='positional', scale_by_sigma=True, ema_rate=0.999)
+    # configs/ve/inverse_problems/super_resolution/celebA_SR3_160.py:149-157
+    c.optim = ConfigDict(weight_decay=0, optimizer='Adam', lr=2e-4, beta1=0.9, eps=1e-8, warmup=2500, grad_clip=1)
+    c.seed = 42
     return c
 
 

@@ -233,3 +233,64 @@ def test_sgd_steps_reduce_the_loss_with_dropout():
     with torch.no_grad():
         out = model({'x': batch[1], 'y': batch[0]}, torch.full((B,), 500., device=dev()))     # planned executor, repacked weights
     assert torch.isfinite(out).all()
+
+
+def test_fused_adam_ema_vs_torch():
+    """csd_adam_step (clip + Adam + EMA in one pass over flat buffers) vs torch.optim.Adam + clip_grad_norm_ + the
+    reference's EMA recurrence (losses.py:26-53, models/ema.py:61-90) on the host."""
+    from conditional_score_diffusion_amd import optim
+    rs = np.random.RandomState(3)
+    shapes = [(7, 5), (33,), (4, 3, 3, 3), (129,)]
+    ref = [torch.nn.Parameter(rnd(rs, *s)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().to(dev())) for p in ref]
+    topt = torch.optim.Adam(ref, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    flat = optim.FlatParams(mine)
+    opt = optim.FusedAdam(flat, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    ema = optim.ExponentialMovingAverage(flat, 0.999)
+    shadow = [p.detach().clone() for p in ref]
+    for step in range(1, 6):
+        grads = [rnd(rs, *s) * (3.0 if step % 2 else 0.05) for s in shapes]      # norms above and below max_norm
+        for p, q, g in zip(ref, mine, grads):
+            p.grad = g.clone()
+        opt.zero_grad()
+        for q, g in zip(mine, grads):
+            q.grad.add_(g.to(dev()))
+        torch.nn.utils.clip_grad_norm_(ref, max_norm=1.0)
+        topt.step()
+        decay = min(0.999, (1 + step) / (10 + step))
+        for sp, p in zip(shadow, ref):
+            sp.sub_((1 - decay) * (sp - p.detach()))
+        opt.max_norm = 1.0
+        opt.step(ema=ema)
+        for p, q in zip(ref, mine):
+            assert rel(q, p) < 2e-6
+        got = [ema.shadow[int(o):int(o) + p.numel()].view_as(p) for p, o in zip(ref, flat.offsets[:-1])]
+        for sp, gq in zip(shadow, got):
+            assert rel(gq, sp) < 2e-6
+    ema.store()
+    ema.copy_to()
+    assert rel(mine[0], shadow[0]) < 2e-6
+    ema.restore()
+    assert rel(mine[0], ref[0]) < 2e-6
+
+
+def test_trainer_steps_single_process():
+    """Trainer.train_step: loss -> HIP backward -> (1-rank) GradSync -> clip + Adam + EMA; the planned inference executor picks
+    up the updated weights afterwards."""
+    from conditional_score_diffusion_amd import train
+    cfg, B, x, y, u, tape = cases.grad_case('sr3_tiny')
+    cfg.model.dropout = 0.1
+    cfg.optim.warmup = 2
+    cfg, nc, p, model = build(cfg)
+    tr = train.Trainer(cfg, model, sdes_for(cfg))
+    batch = (y.to(dev()), x.to(dev()))
+    w0 = tr.flat.data.clone()
+    vals = [float(tr.train_step(batch)) for _ in range(4)]
+    assert np.isfinite(vals).all()
+    assert tr.optimizer.num_steps == 4 and tr.step == 4
+    assert float(tr.optimizer.last_grad_norm) > 0
+    assert not torch.equal(tr.flat.data, w0)                       # (step 0 has warm-up factor 0; later steps move the weights)
+    assert not torch.equal(tr.ema.shadow, tr.flat.data)
+    ev = float(tr.eval_loss(batch))
+    ev_ema = float(tr.eval_loss(batch, use_ema=True))
+    assert np.isfinite([ev, ev_ema]).all()
