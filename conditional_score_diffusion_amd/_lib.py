@@ -111,6 +111,8 @@ SIGNATURES = {
     'csd_act': (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
     'csd_mul': (_i, [_vp, _vp, _vp, _i64, _vp]),
     'csd_adam_step': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _f, _vp]),
+    'csd_global_norm_scratch_bytes': (_sz, []),
+    'csd_global_norm': (_i, [_vp, _vp, _i64, _vp, _vp]),
     'csd_ema_update': (_i, [_vp, _vp, _i64, _f, _vp]),
     'csd_dropout': (_i, [_vp, _vp, _vp, _f, _u64, _u64, _i64, _vp]),
 }

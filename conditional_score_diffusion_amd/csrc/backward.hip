@@ -57,7 +57,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {   // 256 thr
 // partial [split][Cout][Cin][TAPS] is summed in split order by wgrad_reduce_kernel (bit-reproducible).
 // ---------------------------------------------------------------------------------------------------------------
 template <int TAPS>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          float* __restrict__ partial, int B, int IH, int IW, int Cs,
                                                          int Cin, int OH, int OW, int Cout, int stride, int pad, int up,
                                                          int per_split) {
@@ -67,37 +67,66 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   const int m = lane & 31, kk = lane >> 5;
   const int co = blockIdx.z * 32 + m, ci = blockIdx.y * 32 + m;
   const bool cov = co < Cout, civ = ci < Cin;
-  const long long npix = (long long)B * OH * OW;
-  const long long p_begin = (long long)blockIdx.x * per_split;
-  const long long p_end = p_begin + per_split < npix ? p_begin + per_split : npix;
+  // K runs over output rows r = b*OH + oy (a K-split is a run of rows; wave w takes rows w, w+4, ...) and, inside a row,
+  // over pixel pairs: all addresses advance by constants, so a step costs ~60 VALU instructions next to 9 MFMAs.
+  const unsigned nrows = (unsigned)B * OH;
+  const unsigned r_begin = blockIdx.x * (unsigned)per_split;
+  const unsigned r_end = r_begin + per_split < nrows ? r_begin + per_split : nrows;
   const int EH = IH << up, EW = IW << up;
   floatx16 acc[TAPS];
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const unsigned cio = civ ? ci : 0, coo = cov ? co : 0;
 
-  for (long long p0 = p_begin + wave * 2; p0 < p_end; p0 += 8) {
-    const long long p = p0 + kk;
-    const bool v = p < p_end;
-    const long long pc = v ? p : p_begin;
-    const int ox = (int)(pc % OW);
-    const long long row = pc / OW;
-    const int oy = (int)(row % OH);
-    const int b = (int)(row / OH);
-    const float a = (v && cov) ? dy[(size_t)pc * Cout + co] : 0.f;
-    float bv[TAPS];
+  for (unsigned r = r_begin + wave; r < r_end; r += 4) {
+    const unsigned b = r / (unsigned)OH, oy = r % (unsigned)OH;
+    unsigned rowoff[KS];
+    bool rowok[KS];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      const int ky = t / KS, kx = t % KS;
-      const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
-      const bool ok = v && civ && iy >= 0 && iy < EH && ix >= 0 && ix < EW;
-      const size_t off = (((size_t)b * IH + (ok ? (iy >> up) : 0)) * IW + (ok ? (ix >> up) : 0)) * Cs + (civ ? ci : 0);
-      const float xv = x[off];
-      bv[t] = ok ? xv : 0.f;
+    for (int ky = 0; ky < KS; ++ky) {
+      const int iy = (int)oy * stride + ky - pad;
+      rowok[ky] = civ && iy >= 0 && iy < EH;
+      rowoff[ky] = ((b * (unsigned)IH + (rowok[ky] ? (unsigned)(iy >> up) : 0u)) * (unsigned)IW) * (unsigned)Cs + cio;
     }
+    const float* dyp = dy + (size_t)(r * (unsigned)OW) * Cout + coo;
+    // U pixel pairs per step: all their operand loads (U*(1+TAPS) dwords per lane, unconditional on clamped addresses) are
+    // issued before the first MFMA, so ~10 KB per wave is in flight - the stream comes from HBM/L2 with ~2 us latency and
+    // the second wave of the SIMD covers it with its own U*TAPS MFMAs.
+    constexpr int U = 4;
+    for (int ox0 = 0; ox0 < OW; ox0 += 2 * U) {
+      float a[U], bv[U][TAPS];
+      bool va[U], vb[U][TAPS];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[t], acc[t], 0, 0, 0);
+      for (int u = 0; u < U; ++u) {
+        const int ox = ox0 + 2 * u + kk;
+        const bool v = ox < OW;
+        a[u] = dyp[(unsigned)(v ? ox : 0) * (unsigned)Cout];
+        va[u] = v && cov;
+        unsigned xo[KS];
+        bool okx[KS];
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const int ix = ox * stride + kx - pad;
+          okx[kx] = v && ix >= 0 && ix < EW;
+          xo[kx] = okx[kx] ? (unsigned)(ix >> up) * (unsigned)Cs : 0u;
+        }
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          bv[u][t] = x[(size_t)(rowoff[t / KS] + xo[t % KS])];
+          vb[u][t] = rowok[t / KS] && okx[t % KS];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);          // keep every load of the step ahead of its MFMAs
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float av = va[u] ? a[u] : 0.f;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, vb[u][t] ? bv[u][t] : 0.f, acc[t], 0, 0, 0);
+      }
+    }
   }
 
   // cross-wave reduction (fixed order: wave 0, 1, 2, 3)
@@ -132,14 +161,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
 }
 
 int wgrad_splits(int B, int OH, int OW, int Cin, int Cout, int* per_split) {
-  const long long npix = (long long)B * OH * OW;
+  // K-splits are runs of output rows; ~1024 workgroups per launch, at least 4 rows (one per wave) and ~64 pixels each
+  const long long nrows = (long long)B * OH;
   const int tiles = cdiv(Cout, 32) * cdiv(Cin, 32);
   long long S = std::max(1, 1024 / tiles);
-  const long long max_s = std::max<long long>(1, npix / 64);
+  const long long min_rows = std::max<long long>(4, cdiv(64, OW));
+  const long long max_s = std::max<long long>(1, nrows / min_rows);
   if (S > max_s) S = max_s;
-  long long per = (npix + S - 1) / S;
-  per = (per + 7) / 8 * 8;
-  S = (npix + per - 1) / per;
+  const long long per = (nrows + S - 1) / S;
+  S = (nrows + per - 1) / per;
   *per_split = (int)per;
   return (int)S;
 }
@@ -403,6 +433,7 @@ extern "C" int csd_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
   hipStream_t s = (hipStream_t)stream;
   const int up = up2 ? 1 : 0;
   const int OH = (H << up) / stride, OW = (W << up) / stride;
+  CSD_REQUIRE((double)B * H * W * Cin < 4.0e9 && (double)B * OH * OW * Cout < 4.0e9, "conv2d_wgrad: tensor exceeds 32-bit indexing");
   int per;
   const int S = wgrad_splits(B, OH, OW, Cin, Cout, &per);
   float* f = static_cast<float*>(scratch);

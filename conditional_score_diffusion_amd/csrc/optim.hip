@@ -47,7 +47,46 @@ __global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p,
   }
 }
 
+// ||a||_2 of one long vector: 1024 workgroups leave fp64 partials, the last stage adds them in index order (deterministic)
+#define GN_BLOCKS 1024
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ a, double* __restrict__ partial, size_t n) {
+  __shared__ double red[4];
+  double s = 0;
+  const size_t n4 = n / 4;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)GN_BLOCKS * 256) {
+    const float4 v = a4[i];
+    s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = a[n4 * 4 + threadIdx.x]; s += (double)v * v; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(64) void sumsq_final_kernel(const double* __restrict__ partial, float* __restrict__ out) {
+  double s = 0;
+  for (int i = threadIdx.x; i < GN_BLOCKS; i += 64) s += partial[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (threadIdx.x == 0) out[0] = (float)sqrt(s);
+}
+
 }  // namespace
+
+extern "C" size_t csd_global_norm_scratch_bytes(void) { return GN_BLOCKS * sizeof(double); }
+
+extern "C" int csd_global_norm(const float* a, float* out, int64_t n, void* scratch, void* stream) {
+  CSD_REQUIRE(a && out && scratch && n > 0, "global_norm: bad arguments");
+  CSD_REQUIRE(((uintptr_t)a & 15) == 0, "global_norm: the vector must be 16-byte aligned");
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(GN_BLOCKS), dim3(256), 0, (hipStream_t)stream, a, static_cast<double*>(scratch),
+                     (size_t)n);
+  CSD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, static_cast<const double*>(scratch), out);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
 
 extern "C" int csd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
                              const float* grad_norm, int64_t n, int step, float lr, float beta1, float beta2, float eps,

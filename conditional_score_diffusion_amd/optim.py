@@ -43,7 +43,7 @@ class FlatParams:
 
 
 class FusedAdam:
-    """``torch.optim.Adam`` semantics (losses.py:12-23) on a FlatParams; ``step()`` = csd_row_norms + csd_adam_step."""
+    """``torch.optim.Adam`` semantics (losses.py:12-23) on a FlatParams; ``step()`` = csd_global_norm + csd_adam_step."""
 
     def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.flat = params if isinstance(params, FlatParams) else FlatParams(list(params))
@@ -54,13 +54,17 @@ class FusedAdam:
         self.num_steps = 0
         self.max_norm = -1.0          # set by optimize_fn (grad_clip); < 0: no clipping
         self.last_grad_norm = None    # device scalar of the last step (no host sync)
+        self._norm_scratch = None
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
 
     def grad_norm(self):
         out = torch.empty(1, dtype=torch.float32, device=self.flat.grad.device)
-        check(lib().csd_row_norms(ptr(self.flat.grad), ptr(out), 1, self.flat.numel, current_stream(out.device)), 'row_norms')
+        if self._norm_scratch is None:
+            self._norm_scratch = torch.empty(lib().csd_global_norm_scratch_bytes(), dtype=torch.uint8, device=out.device)
+        check(lib().csd_global_norm(ptr(self.flat.grad), ptr(out), self.flat.numel, ptr(self._norm_scratch),
+                                    current_stream(out.device)), 'global_norm')
         return out
 
     def step(self, ema=None):

@@ -284,13 +284,16 @@ int csd_dropout(const float* x, float* out, float* mask, float p, uint64_t seed,
 
 /* ------------------------------------------------------------------------------------------
  * Parameter update of a training step on flat fp32 buffers (csrc/optim.hip): global-norm clipping
- * (torch.nn.utils.clip_grad_norm_, losses.py:48-49; grad_norm = device scalar ||grad||_2 from csd_row_norms, NULL
+ * (torch.nn.utils.clip_grad_norm_, losses.py:48-49; grad_norm = device scalar ||grad||_2 from csd_global_norm, NULL
  * or max_norm < 0: no clipping) + torch.optim.Adam (losses.py:12-23) + the EMA of models/ema.py:61-90 (ema may be
  * NULL) in one pass.  `step` is the 1-based update count (bias correction); lr already carries the warm-up factor.
  * ---------------------------------------------------------------------------------------- */
 int csd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
                   const float* grad_norm, int64_t n, int step, float lr, float beta1, float beta2, float eps,
                   float weight_decay, float max_norm, float ema_decay, void* stream);
+/* out[0] = ||a||_2 of one long vector (fp64 partials of 1024 workgroups added in index order): the total gradient norm */
+size_t csd_global_norm_scratch_bytes(void);
+int csd_global_norm(const float* a, float* out, int64_t n, void* scratch, void* stream);
 /* ema -= (1 - decay) * (ema - param)  (models/ema.py:85-89) */
 int csd_ema_update(float* ema, const float* param, int64_t n, float decay, void* stream);
 
