@@ -51,24 +51,23 @@ int timestep_embedding_launch(const float* t, float* out, int B, int dim, hipStr
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ in, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ out,
                                                      int B, int K, int N, int act_in) {
+  // one wave per (output column n, sample b): grid (N/4, B) - the weight rows are shared through L2
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
   if (n >= N) return;
   const float* wrow = W + (size_t)n * K;
-  const float bv = bias ? bias[n] : 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float* x = in + (size_t)b * K;
-    float acc = 0.f;
-    for (int k = lane; k < K; k += 64) acc += ew_act(x[k], act_in) * wrow[k];
+  const float* x = in + (size_t)b * K;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc += ew_act(x[k], act_in) * wrow[k];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if (lane == 0) out[(size_t)b * N + n] = acc + bv;
-  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) out[(size_t)b * N + n] = acc + (bias ? bias[n] : 0.f);
 }
 
 int linear_launch(const float* in, const float* W, const float* bias, float* out, int B, int K, int N,
                   int act_in, hipStream_t s) {
-  hipLaunchKernelGGL(linear_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, in, W, bias, out, B, K, N, act_in);
+  hipLaunchKernelGGL(linear_kernel, dim3(cdiv(N, 4), B), dim3(256), 0, s, in, W, bias, out, B, K, N, act_in);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }

@@ -233,8 +233,6 @@ class HipUNet(nn.Module):
         ``nn.Dropout`` active (models/layers.py:647,662).  The planned graph executor (csd_unet_forward) stays the
         inference path; this one keeps every activation that a gradient needs."""
         from .. import grad_ops as G, ops
-        if self.arch != 0:
-            raise NotImplementedError('training-mode evaluation of this architecture uses its operator-granular class')
         if not self._cfg.resamp_with_conv:
             raise NotImplementedError('training with resamp_with_conv=False is not provided')
         m, prec, act = self.all_modules, self.precision, self._act_name

@@ -131,6 +131,10 @@ class NCSNpp(nn.Module):
         self._mods = mods
         self.all_modules = nn.ModuleList([self._make_node(k, a) for k, a in mods])
         self._fir_cache = {}
+        self._dropout_p = float(get('dropout', 0.0) or 0.0)
+        self.dropout_seed = int(getattr(config, 'seed', 0) or 0)
+        self._train_calls = 0
+        self._drop_count = 0
 
     # ---- parameters: names, shapes and initialisation of the reference ----
     def _make_node(self, kind, a):
@@ -214,38 +218,56 @@ class NCSNpp(nn.Module):
         return ops.upfirdn2d(x, k, down=factor, pad=((p + 1) // 2, p // 2))
 
     # ---- blocks ----
+    @property
+    def _O(self):
+        """operator set: the differentiable shells of grad_ops (HIP forward + backward kernels) while training under autograd,
+        the plain forward wrappers otherwise"""
+        if self.training and torch.is_grad_enabled():
+            from .. import grad_ops
+            return grad_ops
+        return ops
+
+    def _dropout(self, h):
+        """Dropout_0 (models/layerspp.py:233,265): active only in training mode"""
+        if not (self.training and torch.is_grad_enabled()) or self._dropout_p <= 0:
+            return h
+        from .. import grad_ops
+        self._drop_count += 1
+        return grad_ops.dropout(h, self._dropout_p, self.dropout_seed, (self._train_calls << 16) + self._drop_count)
+
     def _conv(self, node, x, ksize):
-        return ops.conv2d(x, node.weight, node.bias, precision=self.precision if ksize == 3 else 'fp32')
+        return self._O.conv2d(x, node.weight, node.bias, precision=self.precision if ksize == 3 else 'fp32')
 
     def _res(self, node, a, x, temb):
         """ResnetBlockBigGANpp.forward (models/layerspp.py:242-274)."""
         cin, cout = a['cin'], a['cout']
-        h = ops.groupnorm_act(x, node.GroupNorm_0.weight, node.GroupNorm_0.bias, groups=_groups(cin), act=self.act)
+        O = self._O
+        h = O.groupnorm_act(x, node.GroupNorm_0.weight, node.GroupNorm_0.bias, groups=_groups(cin), act=self.act)
         if a['up']:
             h, x = self._upsample_2d(h), self._upsample_2d(x)
         elif a['down']:
             h, x = self._downsample_2d(h), self._downsample_2d(x)
         h = self._conv(node.Conv_0, h, 3)
         if temb is not None:
-            h = ops.bias_add_nchw(h, ops.linear(temb, node.Dense_0.weight, node.Dense_0.bias, act_in=self.act))
-        h = ops.groupnorm_act(h, node.GroupNorm_1.weight, node.GroupNorm_1.bias, groups=_groups(cout), act=self.act)
-        # (Dropout_0 is the identity: the score function always runs the model in eval mode, models/utils.py:145-147)
-        h = self._conv(node.Conv_1, h, 3)
+            h = O.bias_add_nchw(h, O.linear(temb, node.Dense_0.weight, node.Dense_0.bias, act_in=self.act))
+        h = O.groupnorm_act(h, node.GroupNorm_1.weight, node.GroupNorm_1.bias, groups=_groups(cout), act=self.act)
+        h = self._conv(node.Conv_1, self._dropout(h), 3)
         if cin != cout or a['up'] or a['down']:
             x = self._conv(node.Conv_2, x, 1)
-        return ops.axpby(x, h, post=(1.0 / math.sqrt(2.0)) if self.skip_rescale else 1.0)
+        return O.axpby(x, h, post=(1.0 / math.sqrt(2.0)) if self.skip_rescale else 1.0)
 
     def _attn(self, node, a, x):
         """AttnBlockpp.forward (models/layerspp.py:75-91)."""
         C = a['c']
-        h = ops.groupnorm_act(x, node.GroupNorm_0.weight, node.GroupNorm_0.bias, groups=_groups(C), act='none')
+        O = self._O
+        h = O.groupnorm_act(x, node.GroupNorm_0.weight, node.GroupNorm_0.bias, groups=_groups(C), act='none')
 
         def nin(n, t):        # NIN = per-pixel matmul with W [in, out] (models/layers.py:555-564) = 1x1 conv with W^T
-            return ops.conv2d(t, n.W.t().reshape(C, C, 1, 1).contiguous(), n.b, precision='fp32')
+            return O.conv2d(t, n.W.t().reshape(C, C, 1, 1).contiguous(), n.b, precision='fp32')
 
         q, k, v = nin(node.NIN_0, h), nin(node.NIN_1, h), nin(node.NIN_2, h)
-        h = nin(node.NIN_3, ops.attention(q, k, v))
-        return ops.axpby(x, h, post=(1.0 / math.sqrt(2.0)) if self.skip_rescale else 1.0)
+        h = nin(node.NIN_3, O.attention(q, k, v))
+        return O.axpby(x, h, post=(1.0 / math.sqrt(2.0)) if self.skip_rescale else 1.0)
 
     # ---- forward: NCSNpp.forward (models/ncsnpp.py:238-388) ----
     def forward(self, x, time_cond):
@@ -254,6 +276,9 @@ class NCSNpp(nn.Module):
         x = x.contiguous().float()
         time_cond = time_cond.contiguous().float()
         mods, nodes = self._mods, self.all_modules
+        O = self._O
+        self._train_calls += 1
+        self._drop_count = 0
         i = 0
         if self.embedding_type == 'fourier':
             temb = ops.fourier_embedding(time_cond, nodes[i].W)
@@ -261,14 +286,14 @@ class NCSNpp(nn.Module):
         else:
             temb = ops.timestep_embedding(time_cond, self.nf)
         if self.conditional:
-            temb = ops.linear(temb, nodes[i].weight, nodes[i].bias)
+            temb = O.linear(temb, nodes[i].weight, nodes[i].bias)
             i += 1
-            temb = ops.linear(temb, nodes[i].weight, nodes[i].bias, act_in=self.act)
+            temb = O.linear(temb, nodes[i].weight, nodes[i].bias, act_in=self.act)
             i += 1
         else:
             temb = None
         if not self.centered:
-            x = ops.axpby(x, None, alpha=2.0, gamma=-1.0)
+            x = O.axpby(x, None, alpha=2.0, gamma=-1.0)
         input_pyramid = x if self.progressive_input != 'none' else None
         hs = [self._conv(nodes[i], x, 3)]
         i += 1
@@ -286,7 +311,7 @@ class NCSNpp(nn.Module):
                 if self.progressive_input == 'input_skip':
                     input_pyramid = self._downsample_2d(input_pyramid)
                     # Combine 'sum' (models/layerspp.py:53-57): Conv_0(input_pyramid) + h
-                    h = ops.axpby(self._conv(nodes[i].Conv_0, input_pyramid, 1), h)
+                    h = O.axpby(self._conv(nodes[i].Conv_0, input_pyramid, 1), h)
                     i += 1
                 hs.append(h)
         h = hs[-1]
@@ -305,11 +330,11 @@ class NCSNpp(nn.Module):
                 h = self._attn(nodes[i], mods[i][1], h)
                 i += 1
             if self.progressive == 'output_skip':
-                ph = ops.groupnorm_act(h, nodes[i].weight, nodes[i].bias, groups=_groups(mods[i][1]['c']), act=self.act)
+                ph = O.groupnorm_act(h, nodes[i].weight, nodes[i].bias, groups=_groups(mods[i][1]['c']), act=self.act)
                 i += 1
                 ph = self._conv(nodes[i], ph, 3)
                 i += 1
-                pyramid = ph if pyramid is None else ops.axpby(self._upsample_2d(pyramid), ph)
+                pyramid = ph if pyramid is None else O.axpby(self._upsample_2d(pyramid), ph)
             if i_level != 0:
                 h = self._res(nodes[i], mods[i][1], h, temb)
                 i += 1
@@ -317,7 +342,7 @@ class NCSNpp(nn.Module):
         if self.progressive == 'output_skip':
             h = pyramid
         else:
-            h = ops.groupnorm_act(h, nodes[i].weight, nodes[i].bias, groups=_groups(mods[i][1]['c']), act=self.act)
+            h = O.groupnorm_act(h, nodes[i].weight, nodes[i].bias, groups=_groups(mods[i][1]['c']), act=self.act)
             i += 1
             h = self._conv(nodes[i], h, 3)
             i += 1
@@ -367,6 +392,7 @@ class HipNCSNpp(HipUNet):
         self._fourier_scale = float(m.get('fourier_scale', 16) if hasattr(m, 'get') else getattr(m, 'fourier_scale', 16))
         self._init_scale = float(m.init_scale)
         self._pyramid_out = m.progressive.lower() == 'output_skip'
+        self._config = config
         super().__init__(config, precision)
         self._reinit_special()
 
@@ -385,6 +411,26 @@ class HipNCSNpp(HipUNet):
         cfg.n_fir = 4
         for i, v in enumerate(taps):
             cfg.fir_kernel[i] = float(v)
+
+    def _train_forward(self, x, y, labels):
+        """training mode under autograd: the operator-granular NCSN++ (class NCSNpp above, differentiable HIP operators) on
+        THIS model's parameters - a twin whose nn.Parameters are the same objects, so gradients land in ``self.parameters()``."""
+        twin = self.__dict__.get('_twin')
+        if twin is None:
+            twin = NCSNpp(self._config, precision=self.precision)
+            mine = dict(self.named_parameters())
+            for name, _ in list(twin.named_parameters()):
+                mod = twin
+                parts = name.split('.')
+                for part in parts[:-1]:
+                    mod = getattr(mod, part)
+                setattr(mod, parts[-1], mine[name])
+            assert {k for k, _ in twin.named_parameters()} == set(mine)
+            self.__dict__['_twin'] = twin            # (not a registered submodule: the state_dict stays the reference's)
+        twin.train()
+        twin.dropout_seed = self.dropout_seed
+        inp = torch.cat([x, y], dim=1) if self.y_channels else x
+        return twin(inp, labels)
 
     def _reinit_special(self):
         """initialisation the generic rules of HipUNet._build_params do not cover: the Gaussian Fourier W

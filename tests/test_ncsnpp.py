@@ -191,3 +191,49 @@ def test_full_size_ncsnpp_160_vs_oracle(precision, tol):
         got = torch.cat([r['x'], r['y']], dim=1).cpu()
         ref = so.ncsnpp_forward(p, cfg, x, labels)
     assert (got - ref).abs().max().item() <= tol * ref.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', list(cases.NCSNPP_CASES))
+def test_training_mode_gradients_vs_oracle_autograd(case):
+    """model.train() + autograd: the NCSN++ forward runs on the differentiable HIP operators (FIR resampling backward =
+    upfirdn2d with the flipped kernel, BigGAN blocks, Combine, pyramid) and d(sum(out * w))/d(parameters) matches torch autograd
+    over the oracle's restatement (pinned to the reference's forward by tests/test_oracle_golden.py)."""
+    import score_oracle as so
+    from conditional_score_diffusion_amd.models import utils as mutils
+    cfg, B, x, labels = cases.ncsnpp_case(case)
+    cfg.model.dropout = 0.0
+    dev = torch.device('cuda:0')
+    model = mutils.create_model(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    params = cases.ncsnpp_params(shapes, 5)
+    model.load_state_dict(params)
+    model = model.to(dev).train()
+    w = torch.from_numpy(np.random.RandomState(2).standard_normal(tuple(x.shape[:1]) + (cfg.data.num_channels,) + tuple(x.shape[2:]))
+                         .astype(np.float32))
+    xd, ld = x.to(dev), labels.to(dev)
+    if cfg.model.name == 'ncsnpp_paired':
+        r = model({'x': xd[:, :3], 'y': xd[:, 3:]}, ld)
+        out = torch.cat([r['x'], r['y']], dim=1)
+    else:
+        out = model(xd, ld)
+    assert out.requires_grad
+    (out * w.to(dev)).sum().backward()
+    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in params.items()}
+    ref = so.ncsnpp_forward(p, cfg, x, labels)
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    (ref * w).sum().backward()
+    total = float(np.sqrt(sum(float((v.grad.double() ** 2).sum()) for v in p.values() if v.grad is not None)))
+    checked = 0
+    for k, q in model.named_parameters():
+        if not q.requires_grad:
+            assert q.grad is None                       # the Gaussian Fourier W is a fixed buffer (layerspp.py:37)
+            continue
+        g, r = q.grad.cpu().double(), p[k].grad.double()
+        scale = max(float(r.abs().max()), float(r.norm()) / np.sqrt(r.numel()))
+        assert float((g - r).abs().max()) <= 1e-3 * scale + 1e-6 * total / np.sqrt(r.numel()), (k, float((g - r).abs().max()), scale)
+        checked += 1
+    assert checked > 20
+    model.eval()
+    with torch.no_grad():
+        assert torch.isfinite(model(xd, ld) if cfg.model.name != 'ncsnpp_paired' else model({'x': xd[:, :3], 'y': xd[:, 3:]}, ld)['x']).all()
