@@ -110,6 +110,18 @@ SIGNATURES = {
     'csd_sum_rows': (_i, [_vp, _vp, _i, _i, _vp]),
     'csd_act': (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
     'csd_mul': (_i, [_vp, _vp, _vp, _i64, _vp]),
+    'csd_conv2d_ex': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'csd_conv2d_wgrad_ex': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'csd_groupnorm_nhwc_scratch_bytes': (_sz, [_i, _i, _i]),
+    'csd_groupnorm_act_nhwc': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    'csd_groupnorm_act_backward_nhwc': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'csd_bias_add_nhwc': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'csd_sum_pixels_scratch_bytes': (_sz, [_i, _i, _i]),
+    'csd_sum_pixels_nhwc': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    'csd_zero_insert_odd_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'csd_sumpool2_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'csd_attention_nhwc': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'csd_attention_backward_nhwc': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'csd_adam_step': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _f, _vp]),
     'csd_global_norm_scratch_bytes': (_sz, []),
     'csd_global_norm': (_i, [_vp, _vp, _i64, _vp, _vp]),

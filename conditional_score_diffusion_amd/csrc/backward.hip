@@ -416,8 +416,9 @@ extern "C" size_t csd_conv_wgrad_scratch_bytes(int B, int Cin, int Cout, int H, 
           al64((size_t)S * Cout * Cin * ksize * ksize)) * sizeof(float) + 1024;
 }
 
-extern "C" int csd_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W,
-                                int ksize, int stride, int pad_mode, int up2, void* scratch, void* stream) {
+// layout bit 0: x is NHWC [B,H,W,Cin]; bit 1: dy is NHWC [B,OH,OW,Cout]
+static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W, int ksize, int stride,
+                      int pad_mode, int up2, int layout, void* scratch, void* stream) {
   CSD_REQUIRE(x && dy && dw && scratch, "conv2d_wgrad: null argument");
   CSD_REQUIRE(ksize == 1 || ksize == 3, "conv2d_wgrad: ksize must be 1 or 3");
   CSD_REQUIRE(stride == 1 || stride == 2, "conv2d_wgrad: stride must be 1 or 2");
@@ -441,8 +442,10 @@ extern "C" int csd_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
   float* dyh = f; f += al64((size_t)B * OH * OW * Cout);
   float* partial = f;
   int rc;
-  if ((rc = nchw_to_nhwc_launch(x, xh, B, Cin, H * W, Cin, Cin, s))) return rc;
-  if ((rc = nchw_to_nhwc_launch(dy, dyh, B, Cout, OH * OW, Cout, Cout, s))) return rc;
+  if (layout & 1) xh = const_cast<float*>(x);
+  else if ((rc = nchw_to_nhwc_launch(x, xh, B, Cin, H * W, Cin, Cin, s))) return rc;
+  if (layout & 2) dyh = const_cast<float*>(dy);
+  else if ((rc = nchw_to_nhwc_launch(dy, dyh, B, Cout, OH * OW, Cout, Cout, s))) return rc;
   const dim3 grid(S, cdiv(Cin, 32), cdiv(Cout, 32));
   if (ksize == 3)
     hipLaunchKernelGGL(conv_wgrad_kernel<9>, grid, dim3(256), 0, s, xh, dyh, partial, B, H, W, Cin, Cin, OH, OW, Cout, stride,
@@ -455,6 +458,16 @@ extern "C" int csd_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(n)), dim3(256), 0, s, partial, dw, n, S);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
+}
+
+extern "C" int csd_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W,
+                                int ksize, int stride, int pad_mode, int up2, void* scratch, void* stream) {
+  return wgrad_impl(x, dy, dw, B, Cin, Cout, H, W, ksize, stride, pad_mode, up2, 0, scratch, stream);
+}
+
+extern "C" int csd_conv2d_wgrad_ex(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W,
+                                   int ksize, int stride, int pad_mode, int up2, int layout, void* scratch, void* stream) {
+  return wgrad_impl(x, dy, dw, B, Cin, Cout, H, W, ksize, stride, pad_mode, up2, layout, scratch, stream);
 }
 
 extern "C" int csd_groupnorm_act_backward(const float* x, const float* gamma, const float* beta, const float* dy, float* dx,
@@ -507,6 +520,30 @@ extern "C" int csd_attention_backward(const float* q, const float* k, const floa
   if ((rc = bgemm_launch(k, dP, dq, GemmDesc{C, L, L, L, 1, 1, L, L, 1, zq, zs, zq, scale}, B, s))) return rc;
   // dk[c][j] = scale * sum_i q[c][i] dS[i][j]
   return bgemm_launch(q, dP, dk, GemmDesc{C, L, L, L, 1, L, 1, L, 1, zq, zs, zq, scale}, B, s);
+}
+
+// the same on the packed NHWC tensors of the training graph: qkv, dqkv [B, L, 3C] (q | k | v per pixel), dout [B, L, C]
+extern "C" int csd_attention_backward_nhwc(const float* qkv, const float* dout, float* dqkv, int B, int L, int C, void* scratch,
+                                           void* stream) {
+  CSD_REQUIRE(qkv && dout && dqkv && scratch, "attention_backward_nhwc: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const long long C3 = 3LL * C, zq = (long long)L * C3, zo = (long long)L * C, zs = (long long)L * L;
+  const float scale = 1.0f / sqrtf((float)C);
+  const float *q = qkv, *k = qkv + C, *v = qkv + 2 * C;
+  float *dq = dqkv, *dk = dqkv + C, *dv = dqkv + 2 * C;
+  float* P = static_cast<float*>(scratch);
+  float* dP = P + al64((size_t)B * L * L);
+  int rc;
+  if ((rc = bgemm_launch(q, k, P, GemmDesc{L, L, C, C3, 1, 1, C3, L, 1, zq, zq, zs, scale}, B, s))) return rc;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv64((long long)B * L, 4)), dim3(256), 0, s, P, (long long)B * L, L);
+  CSD_LAUNCH_CHECK();
+  if ((rc = bgemm_launch(dout, P, dv, GemmDesc{C, L, L, 1, C, L, 1, 1, C3, zo, zs, zq, 1.f}, B, s))) return rc;
+  if ((rc = bgemm_launch(dout, v, dP, GemmDesc{L, L, C, C, 1, 1, C3, L, 1, zo, zq, zs, 1.f}, B, s))) return rc;
+  hipLaunchKernelGGL(dsoftmax_rows_kernel, dim3((unsigned)cdiv64((long long)B * L, 4)), dim3(256), 0, s, P, dP, (long long)B * L,
+                     L);
+  CSD_LAUNCH_CHECK();
+  if ((rc = bgemm_launch(k, dP, dq, GemmDesc{C, L, L, 1, C3, 1, L, 1, C3, zq, zs, zq, scale}, B, s))) return rc;
+  return bgemm_launch(q, dP, dk, GemmDesc{C, L, L, 1, C3, L, 1, 1, C3, zq, zs, zq, scale}, B, s);
 }
 
 extern "C" int csd_sum_inner(const float* x, float* out, int64_t rows, int64_t inner, void* stream) {

@@ -95,9 +95,9 @@ __global__ void gn_finalize_kernel(const double* __restrict__ partial, const flo
     double var = q / n - mean * mean;
     if (var < 0) var = 0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = rstd * gamma[c];
+    const float sc = rstd * (gamma ? gamma[c] : 1.f);          // gamma == null: the plain statistics (rstd, -mean*rstd)
     nscale[(size_t)b * C + c] = sc;
-    nshift[(size_t)b * C + c] = beta[c] - (float)mean * sc;
+    nshift[(size_t)b * C + c] = (beta ? beta[c] : 0.f) - (float)mean * sc;
   }
 }
 
@@ -148,9 +148,9 @@ __global__ void gn_finalize_tiles_kernel(const double* __restrict__ p0, int tpi0
     double var = gq / n - mean * mean;
     if (var < 0) var = 0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = rstd * gamma[c];
+    const float sc = rstd * (gamma ? gamma[c] : 1.f);          // gamma == null: the plain statistics (rstd, -mean*rstd)
     nscale[(size_t)b * C + c] = sc;
-    nshift[(size_t)b * C + c] = beta[c] - (float)mean * sc;
+    nshift[(size_t)b * C + c] = (beta ? beta[c] : 0.f) - (float)mean * sc;
   }
 }
 

@@ -87,15 +87,17 @@ extern "C" size_t csd_conv_scratch_bytes(int B, int Cin, int Cout, int H, int W,
           al64((size_t)B * p.OH * p.OW * Cout)) * sizeof(float) + 4096;
 }
 
-extern "C" int csd_conv2d(const float* x, const float* weight, const float* bias, float* y, int B, int Cin, int Cout,
-                          int H, int W, int ksize, int stride, int pad_mode, int up2, int precision, void* scratch,
-                          void* stream) {
+// layout bit 0: x is NHWC [B,H,W,Cin] (Cin must already be a multiple of the kernel's channel granule); bit 1: y is NHWC
+static int conv2d_impl(const float* x, const float* weight, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
+                       int ksize, int stride, int pad_mode, int up2, int precision, int layout, void* scratch, void* stream) {
   CSD_REQUIRE(x && weight && y && scratch, "conv2d: null argument");
   CSD_REQUIRE(precision >= CSD_PREC_F32 && precision <= CSD_PREC_F16, "conv2d: bad precision id %d", precision);
+  const bool in_nhwc = layout & 1, out_nhwc = layout & 2;
   hipStream_t s = (hipStream_t)stream;
   ConvPlan p;
   int rc = conv_api_plan(&p, B, Cin, Cout, H, W, ksize, stride, pad_mode, up2);
   if (rc) return rc;
+  CSD_REQUIRE(!in_nhwc || Cin % 8 == 0, "conv2d: an NHWC input needs Cin %% 8 == 0 (got %d)", Cin);
   int ns = precision_ns(precision);
   bool pw = false;
   if (ns) {   // fp16 MFMA kernel where it applies (3x3 stride 1, Cin padded to 16), else fp32 kernel
@@ -103,8 +105,8 @@ extern "C" int csd_conv2d(const float* x, const float* weight, const float* bias
     q.C0 = ceil16(Cin);
     ConvPlan q1 = p;
     q1.C0 = ceil32(Cin);
-    if (conv16_supported(q) && conv16_plan_tiles(&q, ns) == CSD_OK) p = q;
-    else if (pw16_supported(q1, ns)) { p = q1; pw = true; }
+    if ((!in_nhwc || Cin % 16 == 0) && conv16_supported(q) && conv16_plan_tiles(&q, ns) == CSD_OK) p = q;
+    else if ((!in_nhwc || Cin % 32 == 0) && pw16_supported(q1, ns)) { p = q1; pw = true; }
     else ns = 0;
   }
   float* f = static_cast<float*>(scratch);
@@ -112,7 +114,8 @@ extern "C" int csd_conv2d(const float* x, const float* weight, const float* bias
   float* wp = f; f += api_packed_floats(p, Cin);
   float* bp = f; f += al64((size_t)p.CoutPad);
   float* yh = f;
-  if ((rc = nchw_to_nhwc_launch(x, xh, B, Cin, H * W, p.C0, p.C0, s))) return rc;
+  if (in_nhwc) xh = const_cast<float*>(x);
+  else if ((rc = nchw_to_nhwc_launch(x, xh, B, Cin, H * W, p.C0, p.C0, s))) return rc;
   rc = pw ? pw16_pack_weight(p, ns, weight, 0, Cin, Cout, 0, wp, s)
           : ns ? conv16_pack_weight(p, ns, weight, 0, Cin, Cout, 0, wp, s) : conv_pack_weight(p, weight, 0, Cin, Cout, 0, wp, s);
   if (rc) return rc;
@@ -120,10 +123,23 @@ extern "C" int csd_conv2d(const float* x, const float* weight, const float* bias
   if (bias) CSD_CHECK_HIP(hipMemcpyAsync(bp, bias, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.src0 = xh; a.wpack = wp; a.bias = bp; a.out = yh;
+  a.src0 = xh; a.wpack = wp; a.bias = bp; a.out = out_nhwc ? y : yh;
   a.out_stride = Cout; a.out_nchw = 0; a.out_scale = 1.f;
   if ((rc = pw ? pw16_launch(p, ns, a, s) : ns ? conv16_launch(p, ns, a, s) : conv_launch(p, a, s))) return rc;
+  if (out_nhwc) return CSD_OK;
   return nhwc_to_nchw_launch(yh, y, B, Cout, p.OH * p.OW, Cout, s);
+}
+
+extern "C" int csd_conv2d(const float* x, const float* weight, const float* bias, float* y, int B, int Cin, int Cout,
+                          int H, int W, int ksize, int stride, int pad_mode, int up2, int precision, void* scratch,
+                          void* stream) {
+  return conv2d_impl(x, weight, bias, y, B, Cin, Cout, H, W, ksize, stride, pad_mode, up2, precision, 0, scratch, stream);
+}
+
+extern "C" int csd_conv2d_ex(const float* x, const float* weight, const float* bias, float* y, int B, int Cin, int Cout,
+                             int H, int W, int ksize, int stride, int pad_mode, int up2, int precision, int layout,
+                             void* scratch, void* stream) {
+  return conv2d_impl(x, weight, bias, y, B, Cin, Cout, H, W, ksize, stride, pad_mode, up2, precision, layout, scratch, stream);
 }
 
 // ---- attention ------------------------------------------------------------------------------------------

@@ -71,6 +71,7 @@ class HipUNet(nn.Module):
             raise NotImplementedError('activation function does not exist!')   # models/layers.py:29-41
         self._act_name = act
         self._train_calls = 0
+        self.train_layout = os.environ.get('CSD_TRAIN_LAYOUT', 'nhwc')     # 'nhwc' | 'nchw' (see _train_forward)
         self.dropout_seed = int(getattr(config, 'seed', 0) or 0)   # Philox key of the dropout masks
         cfg = _lib.UNetConfig()
         cfg.arch = self.arch
@@ -228,13 +229,20 @@ class HipUNet(nn.Module):
 
     # -- training-mode evaluation: differentiable, operator-granular ------------------------------------------
     def _train_forward(self, x, y, labels):
-        """``model.train()`` + autograd: the reference forward (models/ddpm.py:149-213) layer by layer on the
-        differentiable HIP operators of grad_ops (forward AND backward kernels behind include/csd.h), with
-        ``nn.Dropout`` active (models/layers.py:647,662).  The planned graph executor (csd_unet_forward) stays the
-        inference path; this one keeps every activation that a gradient needs."""
-        from .. import grad_ops as G, ops
+        """``model.train()`` + autograd: the reference forward (models/ddpm.py:149-213) layer by layer on differentiable HIP
+        operators (forward AND backward kernels behind include/csd.h), with ``nn.Dropout`` active (models/layers.py:647,662).
+        The planned graph executor (csd_unet_forward) stays the inference path; this one keeps every activation that a
+        gradient needs.  ``self.train_layout``: 'nhwc' (default) keeps activations in the library's layout between layers
+        (grad_ops_nhwc: no layout change anywhere but the network's NCHW input and output), 'nchw' runs every layer through
+        the NCHW per-operator ABI (grad_ops)."""
+        from .. import ops
         if not self._cfg.resamp_with_conv:
             raise NotImplementedError('training with resamp_with_conv=False is not provided')
+        nhwc = self.train_layout == 'nhwc'
+        if nhwc:
+            from .. import grad_ops_nhwc as G
+        else:
+            from .. import grad_ops as G
         m, prec, act = self.all_modules, self.precision, self._act_name
         B, S = x.shape[0], self.image_size
         if tuple(x.shape) != (B, self.x_channels, S, S):
@@ -242,17 +250,20 @@ class HipUNet(nn.Module):
         labels = labels.to(device=x.device, dtype=torch.float32).contiguous()
         self._train_calls += 1
         drop = [0]
+        cdim = 3 if nhwc else 1            # channel axis of an activation
+        side = (lambda t: t.shape[1]) if nhwc else (lambda t: t.shape[-1])
+        bias_add = G.bias_add if nhwc else G.bias_add_nchw
 
         def dropout(h):
             drop[0] += 1
             return G.dropout(h, self._dropout, self.dropout_seed, (self._train_calls << 16) + drop[0])
 
         def res(node, h, temb):
-            cin, cout = h.shape[1], node.Conv_0.weight.shape[0]
+            cin, cout = h.shape[cdim], node.Conv_0.weight.shape[0]
             t = G.groupnorm_act(h, node.GroupNorm_0.weight, node.GroupNorm_0.bias, 32, 1e-6, act)
             t = G.conv2d(t, node.Conv_0.weight, node.Conv_0.bias, precision=prec)
             if temb is not None:
-                t = G.bias_add_nchw(t, G.linear(temb, node.Dense_0.weight, node.Dense_0.bias, act_in=act))
+                t = bias_add(t, G.linear(temb, node.Dense_0.weight, node.Dense_0.bias, act_in=act))
             t = G.groupnorm_act(t, node.GroupNorm_1.weight, node.GroupNorm_1.bias, 32, 1e-6, act)
             t = G.conv2d(dropout(t), node.Conv_1.weight, node.Conv_1.bias, precision=prec)
             if cin != cout:
@@ -261,11 +272,14 @@ class HipUNet(nn.Module):
 
         def attn(node, h):
             t = G.groupnorm_act(h, node.GroupNorm_0.weight, node.GroupNorm_0.bias, 32, 1e-6, 'none')
-            q = G.nin(t, node.NIN_0.W, node.NIN_0.b, prec)
-            k = G.nin(t, node.NIN_1.W, node.NIN_1.b, prec)
-            v = G.nin(t, node.NIN_2.W, node.NIN_2.b, prec)
-            t = G.nin(G.attention(q, k, v), node.NIN_3.W, node.NIN_3.b, prec)
-            return G.axpby(h, t)
+            if nhwc:      # q | k | v from ONE 1x1 contraction (weights concatenated: data movement), packed per pixel
+                W = torch.cat([node.NIN_0.W, node.NIN_1.W, node.NIN_2.W], dim=1)
+                b = torch.cat([node.NIN_0.b, node.NIN_1.b, node.NIN_2.b])
+                a = G.attention(G.nin(t, W, b, prec))
+            else:
+                a = G.attention(G.nin(t, node.NIN_0.W, node.NIN_0.b, prec), G.nin(t, node.NIN_1.W, node.NIN_1.b, prec),
+                                G.nin(t, node.NIN_2.W, node.NIN_2.b, prec))
+            return G.axpby(h, G.nin(a, node.NIN_3.W, node.NIN_3.b, prec))
 
         h = torch.cat([x, y], dim=1) if self.y_channels else x
         i = 0
@@ -277,13 +291,16 @@ class HipUNet(nn.Module):
             i = 2
         if not self.centered:
             h = G.axpby(h, None, 2.0, 0.0, -1.0, 1.0)
-        hs = [G.conv2d(h, m[i].weight, m[i].bias, precision=prec)]
+        if nhwc:          # network input is the reference's NCHW; from here on activations are [B, H, W, C]
+            hs = [G.conv2d(h, m[i].weight, m[i].bias, precision=prec, layout=G.OUT_NHWC)]
+        else:
+            hs = [G.conv2d(h, m[i].weight, m[i].bias, precision=prec)]
         i += 1
         for lvl in range(self.num_resolutions):
             for _ in range(self.num_res_blocks):
                 h = res(m[i], hs[-1], temb)
                 i += 1
-                if h.shape[-1] in self.attn_resolutions:
+                if side(h) in self.attn_resolutions:
                     h = attn(m[i], h)
                     i += 1
                 hs.append(h)
@@ -296,9 +313,9 @@ class HipUNet(nn.Module):
         i += 3
         for lvl in reversed(range(self.num_resolutions)):
             for _ in range(self.num_res_blocks + 1):
-                h = res(m[i], torch.cat([h, hs.pop()], dim=1), temb)
+                h = res(m[i], torch.cat([h, hs.pop()], dim=cdim), temb)
                 i += 1
-            if h.shape[-1] in self.attn_resolutions:
+            if side(h) in self.attn_resolutions:
                 h = attn(m[i], h)
                 i += 1
             if lvl != 0:
@@ -306,6 +323,8 @@ class HipUNet(nn.Module):
                 i += 1
         assert not hs and i == len(m) - 2
         h = G.groupnorm_act(h, m[i].weight, m[i].bias, 32, 1e-6, act)
+        if nhwc:
+            return G.conv2d(h, m[i + 1].weight, m[i + 1].bias, precision=prec, layout=G.IN_NHWC)
         return G.conv2d(h, m[i + 1].weight, m[i + 1].bias, precision=prec)
 
 

@@ -297,6 +297,36 @@ int csd_global_norm(const float* a, float* out, int64_t n, void* scratch, void* 
 /* ema -= (1 - decay) * (ema - param)  (models/ema.py:85-89) */
 int csd_ema_update(float* ema, const float* param, int64_t n, float decay, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * NHWC forms of the training operators (csrc/train_nhwc.hip): the differentiable DDPM-family graph keeps activations in
+ * the library's internal layout [B, H, W, C], so no layer pays an NCHW<->NHWC change.  Same kernels as above.
+ * ---------------------------------------------------------------------------------------- */
+/* csd_conv2d / csd_conv2d_wgrad with layout flags: bit 0 = first tensor operand (x) is NHWC, bit 1 = second (y resp. dy) is
+ * NHWC.  An NHWC x needs Cin % 8 == 0. */
+int csd_conv2d_ex(const float* x, const float* weight, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
+                  int ksize, int stride, int pad_mode, int up2, int precision, int layout, void* scratch, void* stream);
+int csd_conv2d_wgrad_ex(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W, int ksize,
+                        int stride, int pad_mode, int up2, int layout, void* scratch, void* stream);
+/* GroupNorm(+act) on [B, HW, C]; rs / ms [B, C] receive (rstd, -mean*rstd) per channel for the backward */
+size_t csd_groupnorm_nhwc_scratch_bytes(int B, int C, int HW);
+int csd_groupnorm_act_nhwc(const float* x, const float* gamma, const float* beta, float* y, float* rs, float* ms, int B,
+                           int C, int HW, int groups, float eps, int act, void* scratch, void* stream);
+int csd_groupnorm_act_backward_nhwc(const float* x, const float* gamma, const float* beta, const float* rs, const float* ms,
+                                    const float* dy, float* dx, float* dgamma_rows, float* dbeta_rows, int B, int C, int HW,
+                                    int groups, int act, void* scratch, void* stream);
+/* out[b,p,c] = x[b,p,c] + bias[b,c];  out[b,c] = sum_p x[b,p,c] (its gradient, and a conv bias gradient after csd_sum_rows) */
+int csd_bias_add_nhwc(const float* x, const float* bias, float* out, int B, int HW, int C, void* stream);
+size_t csd_sum_pixels_scratch_bytes(int B, int HW, int C);
+int csd_sum_pixels_nhwc(const float* x, float* out, int B, int HW, int C, void* scratch, void* stream);
+/* data-gradient helpers of the resampling convolutions: dy on the odd positions of a 2h x 2w grid; 2x2 block sums */
+int csd_zero_insert_odd_nhwc(const float* dy, float* z, int B, int h, int w, int C, void* stream);
+int csd_sumpool2_nhwc(const float* in, float* out, int B, int h, int w, int C, void* stream);
+/* attention core and its backward on the packed qkv tensor [B, L, 3C] (q | k | v per pixel); out, dout [B, L, C];
+ * scratch of the backward: csd_attention_backward_scratch_bytes(B, C, L, 1) */
+int csd_attention_nhwc(const float* qkv, float* out, int B, int L, int C, void* stream);
+int csd_attention_backward_nhwc(const float* qkv, const float* dout, float* dqkv, int B, int L, int C, void* scratch,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

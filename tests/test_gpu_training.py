@@ -162,10 +162,11 @@ def test_dropout_mask_and_backward():
     assert torch.allclose(x.grad, g * y.detach())
 
 
-def _hip_loss_and_grads(case, precision='fp32'):
+def _hip_loss_and_grads(case, precision='fp32', layout='nhwc'):
     from conditional_score_diffusion_amd import losses
     cfg, B, x, y, u, tape = cases.grad_case(case)
     cfg, nc, p, model = build(cfg, precision)
+    model.train_layout = layout
     sde = sdes_for(cfg)
     if cfg.model.name == 'ddpm':
         fn, batch = losses.get_general_sde_loss_fn(sde, True, False, True, True, True), x.to(dev())
@@ -184,11 +185,13 @@ def _hip_loss_and_grads(case, precision='fp32'):
     return float(loss.detach()), {k: v.grad for k, v in model.named_parameters()}, model
 
 
+@pytest.mark.parametrize('layout', ['nhwc', 'nchw'])
 @pytest.mark.parametrize('case', list(cases.CASES))
-def test_training_loss_and_grads_vs_reference(golden_dir, case):
-    """loss.backward() through the HIP backward kernels vs the reference's autograd (fixture) and the oracle's (all entries)."""
+def test_training_loss_and_grads_vs_reference(golden_dir, case, layout):
+    """loss.backward() through the HIP backward kernels vs the reference's autograd (fixture) and the oracle's (all entries);
+    both executors of the training graph: NHWC activations (default) and the NCHW per-operator ABI."""
     g = np.load(os.path.join(golden_dir, 'grads.npz'))
-    loss, grads, _ = _hip_loss_and_grads(case)
+    loss, grads, _ = _hip_loss_and_grads(case, layout=layout)
     worst = check_grads_vs_fixture(g, case, loss, grads, 1e-3)
     o_loss, o_grads = oracle_loss_and_grads(case)
     assert abs(loss - o_loss) <= 1e-4 * abs(o_loss)
@@ -227,7 +230,7 @@ def test_sgd_steps_reduce_the_loss_with_dropout():
         with torch.no_grad():
             for q in model.parameters():
                 q -= 2e-4 * q.grad
-        vals.append(float(loss))
+        vals.append(float(loss.detach()))
     assert np.isfinite(vals).all() and vals[-1] < vals[0], vals
     model.eval()
     with torch.no_grad():
@@ -294,3 +297,80 @@ def test_trainer_steps_single_process():
     ev = float(tr.eval_loss(batch))
     ev_ema = float(tr.eval_loss(batch, use_ema=True))
     assert np.isfinite([ev, ev_ema]).all()
+
+
+def test_nhwc_operator_backward_vs_torch():
+    """the NHWC forms (grad_ops_nhwc) of conv (3x3, stride 2, nearest-x2, NCHW-in / NCHW-out ends), GroupNorm+act, packed
+    attention and the broadcast add against torch autograd"""
+    from conditional_score_diffusion_amd import grad_ops_nhwc as G
+    rs = np.random.RandomState(12)
+    to_nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    to_nchw = lambda t: t.permute(0, 3, 1, 2).contiguous()
+    for (B, Cin, Cout, H, k, stride, up2) in [(2, 32, 64, 12, 3, 1, False), (2, 64, 32, 8, 1, 1, False), (2, 32, 32, 16, 3, 2, False),
+                                               (2, 32, 64, 8, 3, 1, True), (3, 96, 40, 5, 3, 1, False)]:
+        x, w, b = rnd(rs, B, Cin, H, H), rnd(rs, Cout, Cin, k, k) * 0.1, rnd(rs, Cout)
+        xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+        u = F.interpolate(xr, scale_factor=2, mode='nearest') if up2 else xr
+        ref = F.conv2d(F.pad(u, (0, 1, 0, 1)), wr, br, stride=2) if stride == 2 else F.conv2d(u, wr, br, padding=k // 2)
+        dy = rnd(rs, *ref.shape)
+        ref.backward(dy)
+        xd, wd, bd = to_nhwc(x).to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+        out = G.conv2d(xd, wd, bd, stride=stride, downsample_pad=stride == 2, up2=up2)
+        assert rel(to_nchw(out), ref) < 1e-5
+        out.backward(to_nhwc(dy).to(dev()))
+        assert rel(to_nchw(xd.grad), xr.grad) < 1e-5 and rel(wd.grad, wr.grad) < 1e-5 and rel(bd.grad, br.grad) < 1e-5
+    # the two ends of the network: NCHW in -> NHWC out (Cin = 6), NHWC in -> NCHW out (Cout = 3)
+    x, w, b = rnd(rs, 2, 6, 12, 12), rnd(rs, 32, 6, 3, 3) * 0.1, rnd(rs, 32)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(x, wr, br, padding=1)
+    dy = rnd(rs, *ref.shape)
+    ref.backward(dy)
+    wd, bd = w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    out = G.conv2d(x.to(dev()), wd, bd, layout=G.OUT_NHWC)
+    out.backward(to_nhwc(dy).to(dev()))
+    assert rel(to_nchw(out), ref) < 1e-5 and rel(wd.grad, wr.grad) < 1e-5 and rel(bd.grad, br.grad) < 1e-5
+    x, w, b = rnd(rs, 2, 32, 12, 12), rnd(rs, 3, 32, 3, 3) * 0.1, rnd(rs, 3)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = F.conv2d(xr, wr, br, padding=1)
+    dy = rnd(rs, *ref.shape)
+    ref.backward(dy)
+    xd, wd, bd = to_nhwc(x).to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    out = G.conv2d(xd, wd, bd, layout=G.IN_NHWC)
+    out.backward(dy.to(dev()))
+    assert rel(out, ref) < 1e-5 and rel(to_nchw(xd.grad), xr.grad) < 1e-5 and rel(wd.grad, wr.grad) < 1e-5 and rel(bd.grad, br.grad) < 1e-5
+    # GroupNorm + SiLU
+    for (B, C, H, groups, act) in [(2, 32, 8, 32, 'swish'), (3, 96, 12, 32, 'swish'), (2, 64, 5, 32, 'none'), (2, 128, 16, 32, 'swish')]:
+        x, ga, be = rnd(rs, B, C, H, H) * 2 + 0.3, rnd(rs, C) * 0.5 + 1, rnd(rs, C) * 0.2
+        xr, gr, br = (t.clone().requires_grad_(True) for t in (x, ga, be))
+        ref = F.group_norm(xr, groups, gr, br, eps=1e-6)
+        ref = F.silu(ref) if act == 'swish' else ref
+        dy = rnd(rs, *ref.shape)
+        ref.backward(dy)
+        xd, gd, bd = to_nhwc(x).to(dev()).requires_grad_(True), ga.to(dev()).requires_grad_(True), be.to(dev()).requires_grad_(True)
+        out = G.groupnorm_act(xd, gd, bd, groups, 1e-6, act)
+        assert rel(to_nchw(out), ref) < 1e-5
+        out.backward(to_nhwc(dy).to(dev()))
+        assert rel(to_nchw(xd.grad), xr.grad) < 2e-5 and rel(gd.grad, gr.grad) < 2e-5 and rel(bd.grad, br.grad) < 2e-5
+    # packed attention
+    for (B, C, H) in [(2, 32, 4), (2, 64, 8), (1, 96, 10)]:
+        q, k, v = rnd(rs, B, C, H, H), rnd(rs, B, C, H, H), rnd(rs, B, C, H, H)
+        qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+        wgt = torch.einsum('bchw,bcij->bhwij', qr, kr) * (int(C) ** (-0.5))
+        wgt = F.softmax(wgt.reshape(B, H, H, H * H), dim=-1).reshape(B, H, H, H, H)
+        ref = torch.einsum('bhwij,bcij->bchw', wgt, vr)
+        do = rnd(rs, *ref.shape)
+        ref.backward(do)
+        qkv = torch.cat([to_nhwc(q), to_nhwc(k), to_nhwc(v)], dim=3).to(dev()).requires_grad_(True)
+        out = G.attention(qkv)
+        assert rel(to_nchw(out), ref) < 1e-5
+        out.backward(to_nhwc(do).to(dev()))
+        gq, gk, gv = (to_nchw(t) for t in qkv.grad.split(C, dim=3))
+        assert rel(gq, qr.grad) < 2e-5 and rel(gk, kr.grad) < 2e-5 and rel(gv, vr.grad) < 2e-5
+    # broadcast add
+    x, bias = rnd(rs, 3, 16, 5, 5), rnd(rs, 3, 16)
+    xd, bd = to_nhwc(x).to(dev()).requires_grad_(True), bias.to(dev()).requires_grad_(True)
+    out = G.bias_add(xd, bd)
+    assert rel(to_nchw(out), x + bias[:, :, None, None]) < 1e-6
+    g = rnd(rs, 3, 5, 5, 16)
+    out.backward(g.to(dev()))
+    assert rel(bd.grad, g.sum(dim=(1, 2))) < 1e-5 and rel(xd.grad, g) == 0
