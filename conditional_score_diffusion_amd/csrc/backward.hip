@@ -7,6 +7,8 @@
 //   gn_bwd_kernel       GroupNorm(+activation) backward, one workgroup per (sample, group), fp64 statistics
 //   bgemm_kernel        strided batched fp32 GEMM (attention backward, Linear backward)
 //   softmax / dsoftmax rows, row / column sums, activation fwd/bwd, dropout (Philox4x32-10), elementwise product
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -60,17 +62,26 @@ template <int TAPS>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          float* __restrict__ partial, int B, int IH, int IW, int Cs,
                                                          int Cin, int OH, int OW, int Cout, int stride, int pad, int up,
-                                                         int per_split) {
+                                                         int per_split, int n_ci, int n_co) {
   constexpr int KS = TAPS == 9 ? 3 : 1;
   __shared__ float red[TAPS * 1024];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = lane & 31, kk = lane >> 5;
-  const int co = blockIdx.z * 32 + m, ci = blockIdx.y * 32 + m;
+  // XCD-aware work order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs (one L2 each).  The
+  // (cout tile, cin tile) workgroups of one K-split read the same rows of x and dy, so they are made neighbours ON ONE XCD:
+  // work item w = (id % 8) * per_xcd + id / 8, split = w / tiles, tile = w % tiles.
+  const unsigned tiles = (unsigned)n_ci * n_co, total = gridDim.x;
+  const unsigned per_xcd = (total + 7) / 8;
+  unsigned wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((total & 7) != 0) wid = blockIdx.x;            // (grids that do not fill the 8 XCDs evenly keep the plain order)
+  const unsigned split_id = wid / tiles, tile_id = wid - split_id * tiles;
+  const int tz = (int)(tile_id / n_ci), ty = (int)(tile_id - (unsigned)tz * n_ci);
+  const int co = tz * 32 + m, ci = ty * 32 + m;
   const bool cov = co < Cout, civ = ci < Cin;
   // K runs over output rows r = b*OH + oy (a K-split is a run of rows; wave w takes rows w, w+4, ...) and, inside a row,
   // over pixel pairs: all addresses advance by constants, so a step costs ~60 VALU instructions next to 9 MFMAs.
   const unsigned nrows = (unsigned)B * OH;
-  const unsigned r_begin = blockIdx.x * (unsigned)per_split;
+  const unsigned r_begin = split_id * (unsigned)per_split;
   const unsigned r_end = r_begin + per_split < nrows ? r_begin + per_split : nrows;
   const int EH = IH << up, EW = IW << up;
   floatx16 acc[TAPS];
@@ -119,12 +130,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
         }
       }
       __builtin_amdgcn_sched_barrier(0);          // keep every load of the step ahead of its MFMAs
+      // masks first, then U*TAPS matrix instructions back to back (a v_cndmask in front of every MFMA held the pipe back)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const float av = va[u] ? a[u] : 0.f;
+        a[u] = va[u] ? a[u] : 0.f;
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, vb[u][t] ? bv[u][t] : 0.f, acc[t], 0, 0, 0);
+        for (int t = 0; t < TAPS; ++t) bv[u][t] = vb[u][t] ? bv[u][t] : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u][t], acc[t], 0, 0, 0);
       }
     }
   }
@@ -143,12 +160,159 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
     __syncthreads();
   }
   // partial[split][co][ci][tap]; accumulator r of lane holds D[row = (r&3) + 8*(r>>2) + 4*kk][col = m]
-  float* dst = partial + (size_t)blockIdx.x * Cout * Cin * TAPS;
+  float* dst = partial + (size_t)split_id * Cout * Cin * TAPS;
   for (int e = threadIdx.x; e < TAPS * 1024; e += 256) {
     const int l = e & 63, r = (e >> 6) & 15, t = e >> 10;
-    const int rco = blockIdx.z * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-    const int rci = blockIdx.y * 32 + (l & 31);
+    const int rco = tz * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    const int rci = ty * 32 + (l & 31);
     if (rco < Cout && rci < Cin) dst[((size_t)rco * Cin + rci) * TAPS + t] = red[e];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wide-load schedule of the weight gradient (Cin % 4 == 0).  The 32x32x9 kernel above turned out to be bound by the texture
+// addresser's instruction rate (40 dword wave-loads per 36 MFMAs, ~16 cycles each, 8 waves per CU), not by MFMA or bandwidth.
+// Here a lane loads a float4 = 4 consecutive input channels of one pixel: ONE 1 KiB wave-load feeds FOUR MFMAs (MFMA j takes
+// element j, so column n of tile j is input channel 4n + j), i.e. a wave covers 32 couts x 128 cins.  To keep the accumulators
+// in registers the taps are split over workgroups by kernel row ky: a wave holds KS x 4 tiles (192 accumulators for 3x3).
+// One wave per SIMD, software-pipelined: the 4 + 12 loads of the next step (U = 4 pixel pairs, 13 KiB) are in flight while
+// the 48 MFMAs (3072 cycles) of the current step run.
+// ---------------------------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void conv_wgrad4_kernel(const float* x, const float* dy,   // (not __restrict__: see the loop)
+                                                          float* partial, int B, int IH, int IW, int Cs,
+                                                          int Cin, int OH, int OW, int Cout, int stride, int pad, int up,
+                                                          int per_split, int n_ci, int n_co) {
+  constexpr int TAPS = KS * KS, U = 4;
+  __shared__ float red[KS * 4 * 1024];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = lane & 31, kk = lane >> 5;
+  // XCD-aware order (see conv_wgrad_kernel): the tiles of one K-split are neighbours on one XCD
+  const unsigned tiles = (unsigned)n_ci * n_co * KS, total = gridDim.x;
+  const unsigned per_xcd = (total + 7) / 8;
+  unsigned wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((total & 7) != 0) wid = blockIdx.x;
+  const unsigned split_id = wid / tiles;
+  unsigned tile_id = wid - split_id * tiles;
+  const int ky = (int)(tile_id % KS); tile_id /= KS;
+  const int ty = (int)(tile_id % n_ci), tz = (int)(tile_id / n_ci);
+  const int co = tz * 32 + m, ci = ty * 128 + 4 * m;
+  const bool cov = co < Cout, civ = ci < Cin;
+  const unsigned cio = civ ? ci : 0, coo = cov ? co : 0;
+  const unsigned nrows = (unsigned)B * OH;
+  const unsigned r_begin = split_id * (unsigned)per_split;
+  const unsigned r_end = r_begin + per_split < nrows ? r_begin + per_split : nrows;
+  const int EH = IH << up, EW = IW << up;
+  floatx16 acc[KS][4];
+#pragma unroll
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+
+  // operands of step (row r, pixel pairs ox0 .. ox0 + 2U): a[u] = dy of this lane's pixel, bq[u][kx] = 4 channels of x under tap
+  // (ky, kx); mask bit u*4 + kx (bit 3 of each nibble: the dy value) says whether the operand exists.  Loads are unconditional
+  // on clamped addresses.
+  auto fetch = [&](unsigned r, int ox0, float (&a)[U], float4 (&bq)[U][KS], unsigned& mask) {
+    const bool rv = r < r_end;
+    const unsigned rc = rv ? r : r_begin;
+    const unsigned b = rc / (unsigned)OH, oy = rc - b * (unsigned)OH;
+    const int iy = (int)oy * stride + ky - pad;
+    const bool rowok = rv && civ && iy >= 0 && iy < EH;
+    const unsigned rowoff = ((b * (unsigned)IH + (rowok ? (unsigned)(iy >> up) : 0u)) * (unsigned)IW) * (unsigned)Cs + cio;
+    const float* dyp = dy + (size_t)(rc * (unsigned)OW) * Cout + coo;
+    mask = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ox = ox0 + 2 * u + kk;
+      const bool v = rv && ox < OW;
+      a[u] = dyp[(unsigned)(v ? ox : 0) * (unsigned)Cout];
+      if (v && cov) mask |= 8u << (4 * u);
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const int ix = ox * stride + kx - pad;
+        const bool ok = v && rowok && ix >= 0 && ix < EW;
+        bq[u][kx] = *reinterpret_cast<const float4*>(x + (size_t)(rowoff + (ok ? (unsigned)(ix >> up) * (unsigned)Cs : 0u)));
+        if (ok) mask |= 1u << (4 * u + kx);
+      }
+    }
+  };
+  // the masks are applied when a step's operands are moved into place, so the MFMA block below is 48 back-to-back matrix
+  // instructions with no VALU between them (a v_cndmask in front of every MFMA held the pipe at ~40 %)
+  auto settle = [&](const float (&a)[U], const float4 (&bq)[U][KS], unsigned mask, float (&ao)[U], float4 (&bo)[U][KS]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ao[u] = ((mask >> (4 * u + 3)) & 1u) ? a[u] : 0.f;
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const bool ok = (mask >> (4 * u + kx)) & 1u;
+        bo[u][kx] = ok ? bq[u][kx] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  unsigned r = r_begin + wave;
+  int ox0 = 0;
+  float a_c[U];
+  float4 b_c[U][KS];
+  {
+    float a_n[U];
+    float4 b_n[U][KS];
+    unsigned m_n;
+    fetch(r, ox0, a_n, b_n, m_n);
+    settle(a_n, b_n, m_n, a_c, b_c);
+  }
+  while (r < r_end) {
+    unsigned rn = r;
+    int oxn = ox0 + 2 * U;
+    if (oxn >= OW) { oxn = 0; rn = r + 4; }
+    float a_n[U];
+    float4 b_n[U][KS];
+    unsigned m_n;
+    fetch(rn, oxn, a_n, b_n, m_n);                 // (masked to nothing past the last row)
+    // the loads of step i+1 must be ISSUED before the MFMAs of step i: a compiler-level memory fence (no instruction) keeps the
+    // optimiser from sinking them to the end of the iteration, the sched_barrier keeps the machine scheduler from doing it
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        acc[kx][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[u], b_c[u][kx].x, acc[kx][0], 0, 0, 0);
+        acc[kx][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[u], b_c[u][kx].y, acc[kx][1], 0, 0, 0);
+        acc[kx][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[u], b_c[u][kx].z, acc[kx][2], 0, 0, 0);
+        acc[kx][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[u], b_c[u][kx].w, acc[kx][3], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    settle(a_n, b_n, m_n, a_c, b_c);
+    r = rn;
+    ox0 = oxn;
+  }
+
+  // cross-wave reduction (fixed order: wave 0, 1, 2, 3)
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < KS; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            float* d = &red[((t * 4 + j) * 16 + q) * 64 + lane];
+            *d = (w == 0) ? acc[t][j][q] : *d + acc[t][j][q];
+          }
+    }
+    __syncthreads();
+  }
+  // partial[split][co][ci][tap]: accumulator q of lane l in tile (kx, j) is D[row (q&3) + 8*(q>>2) + 4*(l>>5)][channel 4*(l&31) + j]
+  float* dst = partial + (size_t)split_id * Cout * Cin * TAPS;
+  for (int e = threadIdx.x; e < KS * 4 * 1024; e += 256) {
+    const int l = e & 63, q = (e >> 6) & 15, j = (e >> 10) & 3, kx = e >> 12;
+    const int rco = tz * 32 + (q & 3) + 8 * (q >> 2) + 4 * (l >> 5);
+    const int rci = ty * 128 + 4 * (l & 31) + j;
+    if (rco < Cout && rci < Cin) dst[((size_t)rco * Cin + rci) * TAPS + ky * KS + kx] = red[e];
   }
 }
 
@@ -160,16 +324,23 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
   }
 }
 
-int wgrad_splits(int B, int OH, int OW, int Cin, int Cout, int* per_split) {
+inline bool wgrad_wide(int Cin) { return Cin % 4 == 0 && getenv("CSD_WGRAD_WIDE"); }   // A/B switch: the 32x32x9 schedule measures faster
+
+int wgrad_splits(int B, int OH, int OW, int Cin, int Cout, int ksize, int* per_split) {
   // K-splits are runs of output rows; ~1024 workgroups per launch, at least 4 rows (one per wave) and ~64 pixels each
   const long long nrows = (long long)B * OH;
-  const int tiles = cdiv(Cout, 32) * cdiv(Cin, 32);
+  const int tiles = wgrad_wide(Cin) ? cdiv(Cout, 32) * cdiv(Cin, 128) * ksize : cdiv(Cout, 32) * cdiv(Cin, 32);
   long long S = std::max(1, 1024 / tiles);
   const long long min_rows = std::max<long long>(4, cdiv(64, OW));
   const long long max_s = std::max<long long>(1, nrows / min_rows);
   if (S > max_s) S = max_s;
-  const long long per = (nrows + S - 1) / S;
+  long long per = (nrows + S - 1) / S;
   S = (nrows + per - 1) / per;
+  // prefer a split count that makes the grid a multiple of 8 (the XCD-aware order needs it): shrink `per` a little if that works
+  for (long long p2 = per; p2 >= std::max<long long>(min_rows, per - 8); --p2) {
+    const long long s2 = (nrows + p2 - 1) / p2;
+    if ((s2 * tiles) % 8 == 0) { per = p2; S = s2; break; }
+  }
   *per_split = (int)per;
   return (int)S;
 }
@@ -348,13 +519,19 @@ __global__ __launch_bounds__(256) void sum_inner_kernel(const float* __restrict_
   if (lane == 0) out[r] = (float)s;
 }
 
-// out[c] = sum_r x[r][c]  (fp64 accumulation, fixed order)
-__global__ void sum_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// out[c] = sum_r x[r][c]  (fp64 accumulation, fixed order): 64 columns x 4 row lanes per workgroup, rows r = lane, lane+4, ...
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C) {
+  __shared__ double sh[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
   double s = 0.0;
-  for (int r = 0; r < R; ++r) s += (double)x[(size_t)r * C + c];
-  out[c] = (float)s;
+  if (c < C) {
+#pragma unroll 4
+    for (int r = ty; r < R; r += 4) s += (double)x[(size_t)r * C + c];
+  }
+  sh[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < C) out[c] = (float)(sh[0][tx] + sh[1][tx] + sh[2][tx] + sh[3][tx]);
 }
 
 // dy == null: out = act(x);  else out = dy * act'(x)
@@ -411,7 +588,7 @@ inline unsigned ew_grid(size_t n) { return (unsigned)std::min<size_t>((n + 255) 
 extern "C" size_t csd_conv_wgrad_scratch_bytes(int B, int Cin, int Cout, int H, int W, int ksize, int stride, int up2) {
   const int OH = (H << (up2 ? 1 : 0)) / stride, OW = (W << (up2 ? 1 : 0)) / stride;
   int per;
-  const int S = wgrad_splits(B, OH, OW, Cin, Cout, &per);
+  const int S = wgrad_splits(B, OH, OW, Cin, Cout, ksize, &per);
   return (al64((size_t)B * H * W * Cin) + al64((size_t)B * OH * OW * Cout) +
           al64((size_t)S * Cout * Cin * ksize * ksize)) * sizeof(float) + 1024;
 }
@@ -436,7 +613,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin
   const int OH = (H << up) / stride, OW = (W << up) / stride;
   CSD_REQUIRE((double)B * H * W * Cin < 4.0e9 && (double)B * OH * OW * Cout < 4.0e9, "conv2d_wgrad: tensor exceeds 32-bit indexing");
   int per;
-  const int S = wgrad_splits(B, OH, OW, Cin, Cout, &per);
+  const int S = wgrad_splits(B, OH, OW, Cin, Cout, ksize, &per);
   float* f = static_cast<float*>(scratch);
   float* xh = f; f += al64((size_t)B * H * W * Cin);
   float* dyh = f; f += al64((size_t)B * OH * OW * Cout);
@@ -446,13 +623,29 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin
   else if ((rc = nchw_to_nhwc_launch(x, xh, B, Cin, H * W, Cin, Cin, s))) return rc;
   if (layout & 2) dyh = const_cast<float*>(dy);
   else if ((rc = nchw_to_nhwc_launch(dy, dyh, B, Cout, OH * OW, Cout, Cout, s))) return rc;
-  const dim3 grid(S, cdiv(Cin, 32), cdiv(Cout, 32));
+  if (wgrad_wide(Cin)) {
+    const int n_ci = cdiv(Cin, 128), n_co = cdiv(Cout, 32);
+    const dim3 grid((unsigned)S * n_ci * n_co * ksize);
+    if (ksize == 3)
+      hipLaunchKernelGGL(conv_wgrad4_kernel<3>, grid, dim3(256), 0, s, xh, dyh, partial, B, H, W, Cin, Cin, OH, OW, Cout, stride,
+                         pad, up, per, n_ci, n_co);
+    else
+      hipLaunchKernelGGL(conv_wgrad4_kernel<1>, grid, dim3(256), 0, s, xh, dyh, partial, B, H, W, Cin, Cin, OH, OW, Cout, stride,
+                         pad, up, per, n_ci, n_co);
+    CSD_LAUNCH_CHECK();
+    const size_t n = (size_t)Cout * Cin * ksize * ksize;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(n)), dim3(256), 0, s, partial, dw, n, S);
+    CSD_LAUNCH_CHECK();
+    return CSD_OK;
+  }
+  const int n_ci = cdiv(Cin, 32), n_co = cdiv(Cout, 32);
+  const dim3 grid((unsigned)S * n_ci * n_co);
   if (ksize == 3)
     hipLaunchKernelGGL(conv_wgrad_kernel<9>, grid, dim3(256), 0, s, xh, dyh, partial, B, H, W, Cin, Cin, OH, OW, Cout, stride,
-                       pad, up, per);
+                       pad, up, per, n_ci, n_co);
   else
     hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, s, xh, dyh, partial, B, H, W, Cin, Cin, OH, OW, Cout, stride,
-                       pad, up, per);
+                       pad, up, per, n_ci, n_co);
   CSD_LAUNCH_CHECK();
   const size_t n = (size_t)Cout * Cin * ksize * ksize;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(n)), dim3(256), 0, s, partial, dw, n, S);
@@ -556,7 +749,7 @@ extern "C" int csd_sum_inner(const float* x, float* out, int64_t rows, int64_t i
 
 extern "C" int csd_sum_rows(const float* x, float* out, int R, int C, void* stream) {
   CSD_REQUIRE(x && out && R > 0 && C > 0, "sum_rows: bad arguments");
-  hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, x, out, R, C);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, x, out, R, C);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }

@@ -1,0 +1,25 @@
+"""tuning aid: the weight gradient of one convolution shape, repeated (for rocprofv3 PMC / timing)
+usage: python tools/wgrad_probe.py B Cin Cout H [reps]"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from conditional_score_diffusion_amd import grad_ops_nhwc as G
+B, Cin, Cout, H = (int(v) for v in sys.argv[1:5])
+reps = int(sys.argv[5]) if len(sys.argv) > 5 else 10
+dev = torch.device('cuda:0')
+x = torch.randn(B, H, H, Cin, device=dev)
+w = (torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05).requires_grad_(True)
+dy = torch.randn(B, H, H, Cout, device=dev)
+from conditional_score_diffusion_amd import ops
+from conditional_score_diffusion_amd._lib import lib, ptr, check, current_stream
+dw = torch.empty_like(w)
+sc = ops._scratch(lib().csd_conv_wgrad_scratch_bytes(B, Cin, Cout, H, H, 3, 1, 0), dev)
+def run():
+    check(lib().csd_conv2d_wgrad_ex(ptr(x), ptr(dy), ptr(dw), B, Cin, Cout, H, H, 3, 1, 0, 0, 3, ptr(sc), current_stream(dev)), 'wgrad')
+run(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(reps): run()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / reps
+fl = 2.0 * B * H * H * Cin * Cout * 9
+print('wgrad B=%d %d->%d %dx%d: %.1f us  %.1f TFLOP/s' % (B, Cin, Cout, H, H, dt * 1e6, fl / dt / 1e12))
