@@ -593,7 +593,7 @@ extern "C" size_t csd_conv_wgrad_scratch_bytes(int B, int Cin, int Cout, int H, 
           al64((size_t)S * Cout * Cin * ksize * ksize)) * sizeof(float) + 1024;
 }
 
-// layout bit 0: x is NHWC [B,H,W,Cin]; bit 1: dy is NHWC [B,OH,OW,Cout]
+// layout bit 0: x is NHWC [B,H,W,Cin]; bit 1: dy is NHWC [B,OH,OW,Cout]; bit 2: split-bf16 arithmetic allowed (else exact fp32)
 static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin, int Cout, int H, int W, int ksize, int stride,
                       int pad_mode, int up2, int layout, void* scratch, void* stream) {
   CSD_REQUIRE(x && dy && dw && scratch, "conv2d_wgrad: null argument");
@@ -623,6 +623,14 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin
   else if ((rc = nchw_to_nhwc_launch(x, xh, B, Cin, H * W, Cin, Cin, s))) return rc;
   if (layout & 2) dyh = const_cast<float*>(dy);
   else if ((rc = nchw_to_nhwc_launch(dy, dyh, B, Cout, OH * OW, Cout, Cout, s))) return rc;
+  if ((layout & 4) && stride == 1 && !up && !wgrad_wide(Cin) && !getenv("CSD_WGRAD_FP32")) {
+    // split-bf16 operands on the bf16 matrix cores (wgrad_bf16.hip): the fp16 precision modes of the training step
+    if ((rc = wgrad_bf16_launch(xh, dyh, partial, B, H, W, Cin, Cout, ksize, S, per, s))) return rc;
+    const size_t n = (size_t)Cout * Cin * ksize * ksize;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(n)), dim3(256), 0, s, partial, dw, n, S);
+    CSD_LAUNCH_CHECK();
+    return CSD_OK;
+  }
   if (wgrad_wide(Cin)) {
     const int n_ci = cdiv(Cin, 128), n_co = cdiv(Cout, 32);
     const dim3 grid((unsigned)S * n_ci * n_co * ksize);

@@ -175,6 +175,10 @@ int nhwc_to_nchw_launch(const float* in, float* out, int B, int C, int HW, int C
 int avgpool2_launch(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 int nearest_up2_nhwc_launch(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 
+// wgrad_bf16.hip: weight gradient of a stride-1 3x3 / 1x1 convolution with split-bf16 operands (NHWC x, dy; partial [S][Cout][Cin][taps])
+int wgrad_bf16_launch(const float* xh, const float* dyh, float* partial, int B, int H, int W, int Cin, int Cout, int ksize, int S,
+                      int per_split, hipStream_t s);
+
 // sampler.hip
 // `net` may be the x-part of a wider network output: sample b starts at net + b*net_stride
 int sumsq_rows_launch(const float* net, int64_t net_stride, const float* z, double* partial, int B,

@@ -1,0 +1,217 @@
+// wgrad_bf16.hip - convolution weight gradient on the bf16 matrix cores with split operands (3x3 / 1x1, stride 1).
+//
+// dW[co][ci][tap] = sum over pixels of dY[p][co] * X[p + tap][ci]: the contraction index is the PIXEL, and
+// v_mfma_f32_32x32x16_bf16 wants 8 consecutive K values per lane - eight pixels of one channel.  Activations are NHWC
+// fp32 (a wave-load of one pixel is 32 consecutive channels = 128 B per half-wave), so a lane gathers its 8 pixels with
+// 8 dword loads (lanes 0-31: pixels 0..7 of the block, lanes 32-63: pixels 8..15) and converts on the fly:
+//     hi = x with the low 16 bits cleared (= a bf16), lo = bf16(x - hi)            (x - hi is exact in fp32)
+//     dY*X ~= hi*hi + hi*lo + lo*hi   -> 3 MFMAs, fp32 accumulate, ~2^-16 relative error per product
+// bf16 rather than fp16 halves: gradients span the whole fp32 exponent range.  The fp32 kernel (backward.hip) needs
+// 64 MFMA cycles per 2 pixels; this one 96 per 16: 5.3x fewer matrix-core cycles, and 38 instead of 80 wave-loads per 16
+// pixels because a row's 10 input pixels are loaded ONCE and serve the three kx taps (register windows q..q+7).
+//
+// Tile per wave: 32 couts x 32 cins x all taps (144 accumulators), K over output rows; 4 waves of a workgroup take
+// interleaved rows of one K-split and are reduced through LDS in fixed order; split partials are summed in fp64 in split
+// order by the caller (bit-reproducible).  Feature maps of width <= 8 put two ROWS into the two lane halves instead of
+// two 8-pixel segments of one row.
+#include "common.h"
+
+namespace csd {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_hi(float lo_elem, float hi_elem) {   // (bf16(hi_elem) << 16) | bf16(lo_elem), truncating
+  return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(float v) { return __uint_as_float(__float_as_uint(v) & 0xffff0000u); }
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float* x, const float* dy, float* partial, int B, int IH,
+                                                                 int IW, int Cin, int OH, int OW, int Cout, int per_split, int n_ci,
+                                                                 int n_co) {
+  constexpr int TAPS = KS * KS, PAD = KS / 2, NQ = 8 + KS - 1, NP = NQ / 2;
+  __shared__ float red[TAPS * 1024];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = lane & 31, kg = lane >> 5;
+  // XCD-aware order: the (cout tile, cin tile) workgroups of one K-split are neighbours on one XCD (they share x / dy rows)
+  const unsigned tiles = (unsigned)n_ci * n_co, total = gridDim.x;
+  const unsigned per_xcd = (total + 7) / 8;
+  unsigned wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((total & 7) != 0) wid = blockIdx.x;
+  const unsigned split_id = wid / tiles, tile_id = wid - split_id * tiles;
+  const int tz = (int)(tile_id / n_ci), ty = (int)(tile_id - (unsigned)tz * n_ci);
+  const int co = tz * 32 + m, ci = ty * 32 + m;
+  const bool cov = co < Cout, civ = ci < Cin;
+  const unsigned cio = civ ? ci : 0, coo = cov ? co : 0;
+  const unsigned nrows = (unsigned)B * OH;
+  const unsigned r_begin = split_id * (unsigned)per_split;
+  const unsigned r_end = r_begin + per_split < nrows ? r_begin + per_split : nrows;
+  const bool pair_rows = OW <= 8;          // lane halves = two rows (narrow maps) instead of two segments of one row
+  floatx16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // this lane's 8 output pixels of a step: row `row`, columns oxb .. oxb+7
+  auto lane_pos = [&](unsigned r, int ox0, unsigned& row, int& oxb) {
+    if (pair_rows) { row = r + kg; oxb = 0; }
+    else { row = r; oxb = ox0 + 8 * kg; }
+  };
+  // raw operands: a[j] = dy[row][oxb + j][co]; xin[ky][q] = x[b][oy + ky - PAD][oxb - PAD + q][ci]; loads are unconditional on
+  // clamped addresses, masks (bit j of am, bit q of xm[ky]) are applied when the values are converted
+  auto fetch = [&](unsigned r, int ox0, float (&a)[8], float (&xin)[KS][NQ], unsigned& am, unsigned (&xm)[KS]) {
+    unsigned row;
+    int oxb;
+    lane_pos(r, ox0, row, oxb);
+    const bool rv = row < r_end;
+    const unsigned rc = rv ? row : r_begin;
+    const unsigned b = rc / (unsigned)OH, oy = rc - b * (unsigned)OH;
+    const float* dyp = dy + (size_t)(rc * (unsigned)OW) * Cout + coo;
+    am = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ox = oxb + j;
+      const bool v = rv && cov && ox < OW;
+      a[j] = dyp[(unsigned)(v ? ox : 0) * (unsigned)Cout];
+      am |= (v ? 1u : 0u) << j;
+    }
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+      const int iy = (int)oy + ky - PAD;
+      const bool rowok = rv && civ && iy >= 0 && iy < IH;
+      const float* xp = x + (size_t)((b * (unsigned)IH + (rowok ? (unsigned)iy : 0u)) * (unsigned)IW) * Cin + cio;
+      xm[ky] = 0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int ix = oxb - PAD + q;
+        const bool ok = rowok && ix >= 0 && ix < IW;
+        xin[ky][q] = xp[(unsigned)(ok ? ix : 0) * (unsigned)Cin];
+        xm[ky] |= (ok ? 1u : 0u) << q;
+      }
+    }
+  };
+
+  unsigned r = r_begin + (pair_rows ? 2 * wave : wave);
+  const unsigned r_step = pair_rows ? 8 : 4;
+  int ox0 = 0;
+  float a_c[8], x_c[KS][NQ];
+  unsigned am_c, xm_c[KS];
+  fetch(r, ox0, a_c, x_c, am_c, xm_c);
+  while (r < r_end) {
+    unsigned rn = r;
+    int oxn = ox0 + 16;
+    if (pair_rows || oxn >= OW) { oxn = 0; rn = r + r_step; }
+    float a_n[8], x_n[KS][NQ];
+    unsigned am_n, xm_n[KS];
+    fetch(rn, oxn, a_n, x_n, am_n, xm_n);          // next step's 8 + KS*NQ loads in flight under this step's conversions + MFMAs
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // dY -> hi / lo bf16x8
+    uintx4 ah, al;
+    {
+      float v[8], lo[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] = ((am_c >> j) & 1u) ? a_c[j] : 0.f;
+        lo[j] = v[j] - trunc_bf16(v[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ah[j] = pack_hi(v[2 * j], v[2 * j + 1]);
+        al[j] = pack_hi(lo[2 * j], lo[2 * j + 1]);
+      }
+    }
+    const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Al = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+      float v[NQ], lo[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        v[q] = ((xm_c[ky] >> q) & 1u) ? x_c[ky][q] : 0.f;
+        lo[q] = v[q] - trunc_bf16(v[q]);
+      }
+      // even-aligned pairs P_i = (q = 2i, 2i+1) serve kx = 0 (P0..P3) and kx = 2 (P1..P4); odd-aligned Q_i = (2i+1, 2i+2) serve kx = 1
+      unsigned ph[NP], pl[NP], qh[4], ql[4];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        ph[i] = pack_hi(v[2 * i], v[2 * i + 1]);
+        pl[i] = pack_hi(lo[2 * i], lo[2 * i + 1]);
+      }
+      if (KS == 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          qh[i] = pack_hi(v[2 * i + 1], v[2 * i + 2]);
+          ql[i] = pack_hi(lo[2 * i + 1], lo[2 * i + 2]);
+        }
+      }
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        uintx4 bh, bl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          bh[i] = (kx == 1) ? qh[i] : ph[i + kx / 2];
+          bl[i] = (kx == 1) ? ql[i] : pl[i + kx / 2];
+        }
+        const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
+        const int t = ky * KS + kx;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a_c[j] = a_n[j];
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) x_c[ky][q] = x_n[ky][q];
+      xm_c[ky] = xm_n[ky];
+    }
+    am_c = am_n;
+    r = rn;
+    ox0 = oxn;
+  }
+
+  // cross-wave reduction (fixed order: wave 0, 1, 2, 3)
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          float* d = &red[(t * 16 + q) * 64 + lane];
+          *d = (w == 0) ? acc[t][q] : *d + acc[t][q];
+        }
+    }
+    __syncthreads();
+  }
+  float* dst = partial + (size_t)split_id * Cout * Cin * TAPS;
+  for (int e = threadIdx.x; e < TAPS * 1024; e += 256) {
+    const int l = e & 63, q = (e >> 6) & 15, t = e >> 10;
+    const int rco = tz * 32 + (q & 3) + 8 * (q >> 2) + 4 * (l >> 5);
+    const int rci = ty * 32 + (l & 31);
+    if (rco < Cout && rci < Cin) dst[((size_t)rco * Cin + rci) * TAPS + t] = red[e];
+  }
+}
+
+int wgrad_bf16_launch(const float* xh, const float* dyh, float* partial, int B, int H, int W, int Cin, int Cout, int ksize, int S,
+                      int per_split, hipStream_t s) {
+  const int n_ci = cdiv(Cin, 32), n_co = cdiv(Cout, 32);
+  const dim3 grid((unsigned)S * n_ci * n_co);
+  if (ksize == 3)
+    hipLaunchKernelGGL(conv_wgrad_bf16_kernel<3>, grid, dim3(256), 0, s, xh, dyh, partial, B, H, W, Cin, H, W, Cout, per_split, n_ci,
+                       n_co);
+  else
+    hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, grid, dim3(256), 0, s, xh, dyh, partial, B, H, W, Cin, H, W, Cout, per_split, n_ci,
+                       n_co);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+}  // namespace csd

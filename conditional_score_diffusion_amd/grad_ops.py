@@ -93,8 +93,8 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             sc = ops._scratch(lib().csd_conv_wgrad_scratch_bytes(B, Cin, Cout, H, W, k, stride, int(up2)), x.device)
-            check(lib().csd_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), B, Cin, Cout, H, W, k, stride, 1 if dpad else 0, int(up2),
-                                         ptr(sc), current_stream(x.device)), 'conv2d_wgrad')
+            check(lib().csd_conv2d_wgrad_ex(ptr(x), ptr(dy), ptr(dw), B, Cin, Cout, H, W, k, stride, 1 if dpad else 0, int(up2),
+                                            0 if precision == 'fp32' else 4, ptr(sc), current_stream(x.device)), 'conv2d_wgrad')
         if has_bias and ctx.needs_input_grad[2]:
             db = _sum_rows(_sum_inner(dy, B * Cout).view(B, Cout))
         return dx, dw, db, None, None, None, None

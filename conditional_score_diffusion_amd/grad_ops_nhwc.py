@@ -11,7 +11,7 @@ from . import _lib, ops
 from ._lib import check, current_stream, lib, ptr
 from .grad_ops import _sum_rows, axpby, dropout, linear  # noqa: F401  (layout-free operators are shared)
 
-IN_NHWC, OUT_NHWC = 1, 2
+IN_NHWC, OUT_NHWC, SPLIT_BF16 = 1, 2, 4
 
 
 def _conv_raw(x, weight, bias, stride, dpad, up2, precision, layout):
@@ -82,7 +82,8 @@ class _Conv2d(torch.autograd.Function):
             dw = torch.empty_like(weight)
             sc = ops._scratch(lib().csd_conv_wgrad_scratch_bytes(B, Cin, Cout, H, W, k, stride, int(up2)), x.device)
             check(lib().csd_conv2d_wgrad_ex(ptr(x), ptr(dy), ptr(dw), B, Cin, Cout, H, W, k, stride, 1 if dpad else 0, int(up2),
-                                            layout, ptr(sc), current_stream(x.device)), 'conv2d_wgrad_ex')
+                                            layout | (0 if precision == 'fp32' else SPLIT_BF16), ptr(sc),
+                                            current_stream(x.device)), 'conv2d_wgrad_ex')
         if has_bias and ctx.needs_input_grad[2]:
             if out_nhwc and Cout % 4 == 0:
                 db = _sum_rows(_sum_pixels(dy))

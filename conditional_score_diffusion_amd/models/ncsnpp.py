@@ -11,7 +11,8 @@ This first NCSN++ executor is *operator-granular* (one C-ABI call per layer, NCH
 per call): it establishes parity for the family the north star names; the planned NHWC graph executor that the
 DDPM family already has (csrc/unet.hip) is the next step for it.
 
-Covered options (the combination every NCSN++ config of the reference uses): ``resblock_type='biggan'``,
+Covered options (the combination the large-image NCSN++ configs of the reference use - ffhq/celebahq 256, bedroom, church, celebA-HQ;
+the CIFAR-10 configs add progressive_input=residual and the ddpmpp ones fir=False, which raise NotImplementedError): ``resblock_type='biggan'``,
 ``fir=True`` with any FIR kernel, ``progressive`` in {none, output_skip}, ``progressive_input`` in {none,
 input_skip}, ``progressive_combine='sum'``, ``embedding_type`` in {positional, fourier}, ``skip_rescale`` either
 way, attention at any resolutions.  Other values raise NotImplementedError (never a silent fallback).

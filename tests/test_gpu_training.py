@@ -374,3 +374,23 @@ def test_nhwc_operator_backward_vs_torch():
     g = rnd(rs, 3, 5, 5, 16)
     out.backward(g.to(dev()))
     assert rel(bd.grad, g.sum(dim=(1, 2))) < 1e-5 and rel(xd.grad, g) == 0
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,k', [(2, 32, 32, 16, 3), (3, 40, 72, 10, 3), (2, 64, 32, 8, 1), (4, 96, 96, 5, 3), (2, 128, 64, 20, 3),
+                                            (1, 32, 32, 37, 3)])
+def test_split_bf16_weight_gradient(B, Cin, Cout, H, k):
+    """the weight gradient of the fp16 precision modes: split-bf16 operands on the bf16 matrix cores (wgrad_bf16.hip), both
+    layouts, incl. maps narrower than a K block (two rows per wave-load) and widths that are not a multiple of 16"""
+    from conditional_score_diffusion_amd import grad_ops as G, grad_ops_nhwc as GN
+    rs = np.random.RandomState(21)
+    x, w = rnd(rs, B, Cin, H, H), rnd(rs, Cout, Cin, k, k) * 0.1
+    dy = rnd(rs, B, Cout, H, H) * 1e-4                      # small gradients: bf16 keeps the fp32 exponent range
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(x, wr, None, padding=k // 2).backward(dy)
+    wd = w.to(dev()).requires_grad_(True)
+    G.conv2d(x.to(dev()), wd, None, precision='fp16x3').backward(dy.to(dev()))
+    assert rel(wd.grad, wr.grad) < 5e-5
+    wn = w.to(dev()).requires_grad_(True)
+    GN.conv2d(x.permute(0, 2, 3, 1).contiguous().to(dev()), wn, None, precision='fp16x3').backward(dy.permute(0, 2, 3, 1).contiguous().to(dev()))
+    assert rel(wn.grad, wr.grad) < 5e-5
+    assert torch.equal(wn.grad, wd.grad)                     # same kernel, same reduction order
