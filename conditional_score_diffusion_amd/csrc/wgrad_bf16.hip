@@ -10,10 +10,20 @@
 // 64 MFMA cycles per 2 pixels; this one 96 per 16: 5.3x fewer matrix-core cycles, and 38 instead of 80 wave-loads per 16
 // pixels because a row's 10 input pixels are loaded ONCE and serve the three kx taps (register windows q..q+7).
 //
+// STAGED schedule (maps wider than 8, channels % 4 == 0): the gathers above are TA-bound - a 64-lane dword wave-load costs
+// ~16 cycles of the CU's texture addresser however well it coalesces, 38 of them per 16 pixels per wave.  Instead ONE
+// global_load_lds_dwordx4 wave-instruction brings 8 pixels x 32 channels (1 KiB, lane = pixel x channel quad) straight into a
+// wave-private LDS patch in memory order [pixel][32 channels] (11 per step: 2 for dY, 3 per input row), and each lane gathers its
+// 8 / 10 pixels of its channel from LDS with ds_read_b32 (bank = channel: conflict-free within a half wave).  No staging
+// registers, no workgroup barrier (the patch is private to the wave): wait vmcnt(0), read, wait lgkmcnt(0), issue the next step's
+// loads, then convert and run the MFMAs while they are in flight.
+//
 // Tile per wave: 32 couts x 32 cins x all taps (144 accumulators), K over output rows; 4 waves of a workgroup take
 // interleaved rows of one K-split and are reduced through LDS in fixed order; split partials are summed in fp64 in split
 // order by the caller (bit-reproducible).  Feature maps of width <= 8 put two ROWS into the two lane halves instead of
 // two 8-pixel segments of one row.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace csd {
@@ -27,12 +37,15 @@ __device__ __forceinline__ unsigned pack_hi(float lo_elem, float hi_elem) {   //
 }
 __device__ __forceinline__ float trunc_bf16(float v) { return __uint_as_float(__float_as_uint(v) & 0xffff0000u); }
 
-template <int KS>
+template <int KS, bool STAGED>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float* x, const float* dy, float* partial, int B, int IH,
                                                                  int IW, int Cin, int OH, int OW, int Cout, int per_split, int n_ci,
                                                                  int n_co) {
   constexpr int TAPS = KS * KS, PAD = KS / 2, NQ = 8 + KS - 1, NP = NQ / 2;
-  __shared__ float red[TAPS * 1024];
+  constexpr int BPIX = KS == 3 ? 24 : 16;                    // staged pixels per input row (16 + halo, rounded up to 8)
+  constexpr int WAVE_LDS = (16 + KS * BPIX) * 32;            // floats of one wave's patch: dY 16 pixels, KS rows of x
+  constexpr int SM = (STAGED && 4 * WAVE_LDS > TAPS * 1024) ? 4 * WAVE_LDS : TAPS * 1024;
+  __shared__ __attribute__((aligned(16))) float red[SM];     // the patches during the K loop, the cross-wave reduction after it
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = lane & 31, kg = lane >> 5;
   // XCD-aware order: the (cout tile, cin tile) workgroups of one K-split are neighbours on one XCD (they share x / dy rows)
@@ -94,19 +107,84 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float* x,
     }
   };
 
+  // ---- STAGED: global -> LDS (direct), LDS -> registers -------------------------------------------------------------
+  float* const patch = red + wave * WAVE_LDS;
+  const int sp = lane >> 3, sq = (lane & 7) * 4;             // this lane's pixel (within an 8-pixel group) and channel quad
+  auto glds16 = [&](const float* src, float* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto stage = [&](unsigned r, int ox0) {                    // (row r is wave-uniform here: no pair mode)
+    const unsigned rc = r < r_end ? r : r_begin;
+    const unsigned b = rc / (unsigned)OH, oy = rc - b * (unsigned)OH;
+    const unsigned coq = (unsigned)(tz * 32 + sq) < (unsigned)Cout ? (unsigned)(tz * 32 + sq) : 0u;
+    const unsigned ciq = (unsigned)(ty * 32 + sq) < (unsigned)Cin ? (unsigned)(ty * 32 + sq) : 0u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int ox = ox0 + sp + 8 * i;
+      ox = ox < OW ? ox : OW - 1;
+      glds16(dy + (size_t)((rc * (unsigned)OW + (unsigned)ox) * (unsigned)Cout + coq), patch + i * 256);
+    }
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+      int iy = (int)oy + ky - PAD;
+      iy = iy < 0 ? 0 : (iy >= IH ? IH - 1 : iy);
+#pragma unroll
+      for (int i = 0; i < BPIX / 8; ++i) {
+        int ix = ox0 - PAD + sp + 8 * i;
+        ix = ix < 0 ? 0 : (ix >= IW ? IW - 1 : ix);
+        glds16(x + (size_t)(((b * (unsigned)IH + (unsigned)iy) * (unsigned)IW + (unsigned)ix) * (unsigned)Cin + ciq),
+               patch + (16 + ky * BPIX) * 32 + i * 256);
+      }
+    }
+  };
+  // operands of this lane from the patch + the same masks as fetch()
+  auto gather = [&](unsigned r, int ox0, float (&a)[8], float (&xin)[KS][NQ], unsigned& am, unsigned (&xm)[KS]) {
+    const bool rv = r < r_end;
+    const unsigned rc = rv ? r : r_begin;
+    const unsigned b = rc / (unsigned)OH, oy = rc - b * (unsigned)OH;
+    const int oxb = ox0 + 8 * kg;
+    am = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a[j] = patch[(8 * kg + j) * 32 + m];
+      am |= ((rv && cov && oxb + j < OW) ? 1u : 0u) << j;
+    }
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+      const int iy = (int)oy + ky - PAD;
+      const bool rowok = rv && civ && iy >= 0 && iy < IH;
+      xm[ky] = 0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int ix = oxb - PAD + q;
+        xin[ky][q] = patch[(16 + ky * BPIX + 8 * kg + q) * 32 + m];
+        xm[ky] |= ((rowok && ix >= 0 && ix < IW) ? 1u : 0u) << q;
+      }
+    }
+  };
+
   unsigned r = r_begin + (pair_rows ? 2 * wave : wave);
   const unsigned r_step = pair_rows ? 8 : 4;
   int ox0 = 0;
   float a_c[8], x_c[KS][NQ];
   unsigned am_c, xm_c[KS];
-  fetch(r, ox0, a_c, x_c, am_c, xm_c);
+  float a_n[8], x_n[KS][NQ];
+  unsigned am_n, xm_n[KS];
+  if (STAGED) stage(r, ox0);
+  else fetch(r, ox0, a_c, x_c, am_c, xm_c);
   while (r < r_end) {
     unsigned rn = r;
     int oxn = ox0 + 16;
     if (pair_rows || oxn >= OW) { oxn = 0; rn = r + r_step; }
-    float a_n[8], x_n[KS][NQ];
-    unsigned am_n, xm_n[KS];
-    fetch(rn, oxn, a_n, x_n, am_n, xm_n);          // next step's 8 + KS*NQ loads in flight under this step's conversions + MFMAs
+    if (STAGED) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this step's patch has landed
+      gather(r, ox0, a_c, x_c, am_c, xm_c);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // ... and is in registers: the patch may be overwritten
+      stage(rn, oxn);                                           // next step's 11 loads fly under the conversions + MFMAs
+    } else {
+      fetch(rn, oxn, a_n, x_n, am_n, xm_n);        // next step's 8 + KS*NQ loads in flight under this step's conversions + MFMAs
+    }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
@@ -165,17 +243,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float* x,
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
+    if (!STAGED) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a_c[j] = a_n[j];
+      for (int j = 0; j < 8; ++j) a_c[j] = a_n[j];
 #pragma unroll
-    for (int ky = 0; ky < KS; ++ky) {
+      for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) x_c[ky][q] = x_n[ky][q];
-      xm_c[ky] = xm_n[ky];
+        for (int q = 0; q < NQ; ++q) x_c[ky][q] = x_n[ky][q];
+        xm_c[ky] = xm_n[ky];
+      }
+      am_c = am_n;
     }
-    am_c = am_n;
     r = rn;
     ox0 = oxn;
+  }
+  if (STAGED) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the last, unused prefetch must not land in the reduction buffer)
+    __syncthreads();                                            // every wave is done with its patch: red[] is reused below
   }
 
   // cross-wave reduction (fixed order: wave 0, 1, 2, 3)
@@ -204,12 +288,13 @@ int wgrad_bf16_launch(const float* xh, const float* dyh, float* partial, int B, 
                       int per_split, hipStream_t s) {
   const int n_ci = cdiv(Cin, 32), n_co = cdiv(Cout, 32);
   const dim3 grid((unsigned)S * n_ci * n_co);
-  if (ksize == 3)
-    hipLaunchKernelGGL(conv_wgrad_bf16_kernel<3>, grid, dim3(256), 0, s, xh, dyh, partial, B, H, W, Cin, H, W, Cout, per_split, n_ci,
-                       n_co);
-  else
-    hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, grid, dim3(256), 0, s, xh, dyh, partial, B, H, W, Cin, H, W, Cout, per_split, n_ci,
-                       n_co);
+  const bool staged = W > 8 && Cin % 4 == 0 && Cout % 4 == 0 && !getenv("CSD_WGRAD_GATHER");
+#define WG_LAUNCH(KS_, ST_)                                                                                                        \
+  hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS_, ST_>), grid, dim3(256), 0, s, xh, dyh, partial, B, H, W, Cin, H, W, Cout, per_split, \
+                     n_ci, n_co)
+  if (ksize == 3) { if (staged) WG_LAUNCH(3, true); else WG_LAUNCH(3, false); }
+  else { if (staged) WG_LAUNCH(1, true); else WG_LAUNCH(1, false); }
+#undef WG_LAUNCH
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
