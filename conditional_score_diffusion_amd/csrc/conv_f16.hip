@@ -123,7 +123,9 @@ __global__ void conv16_pack_kernel(const float* __restrict__ w, _Float16* __rest
   const int cout = nt * 32 + (lane & 31) - cout_off;
   const int cin = ck * C16_KC + (lane >> 5) * 8 + q;
   if (cout < 0 || cout >= cout_src || cin >= cin_src) return;     // padding stays zero
-  const float v = ((layout == 0) ? w[((size_t)cout * cin_src + cin) * taps + tap] : w[(size_t)cin * cout_src + cout]) *
+  const float v = ((layout == 0) ? w[((size_t)cout * cin_src + cin) * taps + tap]
+                   : (layout == 1) ? w[(size_t)cin * cout_src + cout]
+                                   : w[((size_t)cin * cout_src + cout) * taps + (taps - 1 - tap)]) *
                   C16_WSCALE;
   const size_t step = ((size_t)nt * nck + ck) * taps + tap;
   _Float16* dst = wpack + step * (size_t)ns * 512 + lane * 8 + q;

@@ -446,7 +446,11 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
   const int cin = ck * KC + kk * 8 + (lane >> 5) * 4 + q;
   // padding rows/columns stay zero: the buffer is cleared before the first tensor is packed
   if (cout >= 0 && cout < cout_src && cin < cin_src) {
-    const float v = (layout == 0) ? w[((size_t)cout * cin_src + cin) * taps + tap] : w[(size_t)cin * cout_src + cout];
+    // layout 0: OIHW; 1: NIN [Cin][Cout]; 2: the OIHW weight of the TRANSPOSED convolution ([Cin][Cout][taps]), spatially flipped
+    // (the data gradient of a convolution is a convolution with that weight)
+    const float v = (layout == 0) ? w[((size_t)cout * cin_src + cin) * taps + tap]
+                    : (layout == 1) ? w[(size_t)cin * cout_src + cout]
+                                    : w[((size_t)cin * cout_src + cout) * taps + (taps - 1 - tap)];
     wpack[(size_t)nt * per_tile + (idx % per_tile)] = v;
   }
 }

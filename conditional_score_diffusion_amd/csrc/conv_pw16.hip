@@ -233,7 +233,7 @@ __global__ void pw16_pack_kernel(const float* __restrict__ w, _Float16* __restri
   const int cin = (int)(idx % cin_tot);
   const int cout = cp - cout_off;
   if (cp >= cout_pad || cout < 0 || cout >= cout_src || cin >= cin_src) return;   // padding stays zero
-  const float v = ((layout == 0) ? w[(size_t)cout * cin_src + cin] : w[(size_t)cin * cout_src + cout]) * PW_WSCALE;
+  const float v = ((layout == 0) ? w[(size_t)cout * cin_src + cin] : w[(size_t)cin * cout_src + cout]) * PW_WSCALE;   // (layout 2 == 1 for 1x1)
   const int ng = cp / (PW_NTL * 16), nt = (cp % (PW_NTL * 16)) / 16, r = cp % 16;
   const int kk = cin / 32, kq = (cin % 32) / 8, q = cin % 8;
   const int lane = kq * 16 + r;

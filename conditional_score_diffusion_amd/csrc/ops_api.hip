@@ -87,7 +87,9 @@ extern "C" size_t csd_conv_scratch_bytes(int B, int Cin, int Cout, int H, int W,
           al64((size_t)B * p.OH * p.OW * Cout)) * sizeof(float) + 4096;
 }
 
-// layout bit 0: x is NHWC [B,H,W,Cin] (Cin must already be a multiple of the kernel's channel granule); bit 1: y is NHWC
+// layout bit 0: x is NHWC [B,H,W,Cin] (Cin must already be a multiple of the kernel's channel granule); bit 1: y is NHWC;
+// bit 2: `weight` is the OIHW weight [Cin][Cout][k][k] of the transposed convolution - it is used transposed and spatially flipped
+// (the data gradient of a convolution, without materialising the flipped weight)
 static int conv2d_impl(const float* x, const float* weight, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
                        int ksize, int stride, int pad_mode, int up2, int precision, int layout, void* scratch, void* stream) {
   CSD_REQUIRE(x && weight && y && scratch, "conv2d: null argument");
@@ -116,14 +118,17 @@ static int conv2d_impl(const float* x, const float* weight, const float* bias, f
   float* yh = f;
   if (in_nhwc) xh = const_cast<float*>(x);
   else if ((rc = nchw_to_nhwc_launch(x, xh, B, Cin, H * W, p.C0, p.C0, s))) return rc;
-  rc = pw ? pw16_pack_weight(p, ns, weight, 0, Cin, Cout, 0, wp, s)
-          : ns ? conv16_pack_weight(p, ns, weight, 0, Cin, Cout, 0, wp, s) : conv_pack_weight(p, weight, 0, Cin, Cout, 0, wp, s);
+  const int wl = (layout & 4) ? 2 : 0;
+  rc = pw ? pw16_pack_weight(p, ns, weight, wl ? 1 : 0, Cin, Cout, 0, wp, s)
+          : ns ? conv16_pack_weight(p, ns, weight, wl, Cin, Cout, 0, wp, s) : conv_pack_weight(p, weight, wl, Cin, Cout, 0, wp, s);
   if (rc) return rc;
-  CSD_CHECK_HIP(hipMemsetAsync(bp, 0, (size_t)p.CoutPad * sizeof(float), s));
-  if (bias) CSD_CHECK_HIP(hipMemcpyAsync(bp, bias, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (bias) {
+    CSD_CHECK_HIP(hipMemsetAsync(bp, 0, (size_t)p.CoutPad * sizeof(float), s));
+    CSD_CHECK_HIP(hipMemcpyAsync(bp, bias, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.src0 = xh; a.wpack = wp; a.bias = bp; a.out = out_nhwc ? y : yh;
+  a.src0 = xh; a.wpack = wp; a.bias = bias ? bp : nullptr; a.out = out_nhwc ? y : yh;
   a.out_stride = Cout; a.out_nchw = 0; a.out_scale = 1.f;
   if ((rc = pw ? pw16_launch(p, ns, a, s) : ns ? conv16_launch(p, ns, a, s) : conv_launch(p, a, s))) return rc;
   if (out_nhwc) return CSD_OK;

@@ -12,15 +12,20 @@ from ._lib import check, current_stream, lib, ptr
 from .grad_ops import _sum_rows, axpby, dropout, linear  # noqa: F401  (layout-free operators are shared)
 
 IN_NHWC, OUT_NHWC, SPLIT_BF16 = 1, 2, 4
+WEIGHT_T = 4            # csd_conv2d_ex: the weight is the transposed convolution's (data gradient)
 
 
 def _conv_raw(x, weight, bias, stride, dpad, up2, precision, layout):
-    """csd_conv2d_ex; x is [B,H,W,Cin] if layout & 1 else [B,Cin,H,W]; the result [B,OH,OW,Cout] if layout & 2 else NCHW."""
+    """csd_conv2d_ex; x is [B,H,W,Cin] if layout & 1 else [B,Cin,H,W]; the result [B,OH,OW,Cout] if layout & 2 else NCHW;
+    layout & 4: ``weight`` is [Cin, Cout, k, k] (the forward weight of the convolution whose data gradient this is)."""
     if layout & IN_NHWC:
         B, H, W, Cin = x.shape
     else:
         B, Cin, H, W = x.shape
-    Cout, cin_w, k, _ = weight.shape
+    if layout & WEIGHT_T:
+        cin_w, Cout, k, _ = weight.shape
+    else:
+        Cout, cin_w, k, _ = weight.shape
     if cin_w != Cin:
         raise RuntimeError('conv2d: weight %s does not match %d input channels' % (tuple(weight.shape), Cin))
     s = 2 if up2 else 1
@@ -63,8 +68,8 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if not in_nhwc:
                 raise RuntimeError('the data gradient of an NCHW-input convolution is not needed by the training graph')
-            wt = weight.flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, k, k]: data movement only
-            lay = (IN_NHWC if out_nhwc else 0) | OUT_NHWC
+            wt = weight                       # used transposed + flipped by the pack kernel (WEIGHT_T): nothing is materialised
+            lay = (IN_NHWC if out_nhwc else 0) | OUT_NHWC | WEIGHT_T
             if stride == 2:
                 if not out_nhwc:
                     raise RuntimeError('stride-2 convolutions live inside the NHWC graph')

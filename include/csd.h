@@ -302,7 +302,9 @@ int csd_ema_update(float* ema, const float* param, int64_t n, float decay, void*
  * the library's internal layout [B, H, W, C], so no layer pays an NCHW<->NHWC change.  Same kernels as above.
  * ---------------------------------------------------------------------------------------- */
 /* csd_conv2d / csd_conv2d_wgrad with layout flags: bit 0 = first tensor operand (x) is NHWC, bit 1 = second (y resp. dy) is
- * NHWC.  An NHWC x needs Cin % 8 == 0.  csd_conv2d_wgrad_ex bit 2: the stride-1 weight gradient may run with split-bf16
+ * NHWC.  An NHWC x needs Cin % 8 == 0.  csd_conv2d_ex bit 2: `weight` is the OIHW weight [Cin, Cout, k, k] of the TRANSPOSED
+ * convolution and is applied transposed + spatially flipped (the data gradient, without materialising that weight).
+ * csd_conv2d_wgrad_ex bit 2: the stride-1 weight gradient may run with split-bf16
  * operands on the bf16 matrix cores (hi*hi + hi*lo + lo*hi, ~2^-16 relative error per product) instead of exact fp32 MFMA. */
 int csd_conv2d_ex(const float* x, const float* weight, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
                   int ksize, int stride, int pad_mode, int up2, int precision, int layout, void* scratch, void* stream);
