@@ -2,8 +2,8 @@
 
 Mirrors ``get_sampling_fn`` (sampling/unconditional.py:13-75) and ``get_pc_sampler`` (:161-228):
 ``pc_sampler(model, show_evolution=False) -> (samples, {'times', 'steps'[, 'evolution']})``.
-The ODE sampler (:93-158) and the inpainter (:230-345) are not on any BASELINE config and are not
-provided (``sampling.method='ode'`` raises NotImplementedError).
+``sampling.method='ode'`` gives the probability-flow ODE sampler (:93-158): scipy's black-box RK45 on the host, every drift
+evaluation = one network evaluation + one HIP axpby.  The inpainter (:230-345) is not on any BASELINE config and is not provided.
 """
 import functools
 
@@ -29,12 +29,54 @@ def get_sampling_fn(config, sde, shape, eps, predictor='default', corrector='def
         denoise = config.sampling.noise_removal
     method = config.sampling.method.lower()
     if method == 'ode':
-        raise NotImplementedError('the probability-flow ODE sampler is not provided by the HIP path')
+        return get_ode_sampler(sde=sde, shape=shape, denoise=denoise, eps=eps)
     if method != 'pc':
         raise ValueError(f"Sampler name {config.sampling.method} unknown.")
     return get_pc_sampler(sde=sde, shape=shape, predictor=predictor, corrector=corrector, snr=snr,
                           p_steps=p_steps, c_steps=c_steps, probability_flow=config.sampling.probability_flow,
                           continuous=config.training.continuous, denoise=denoise, eps=eps)
+
+
+def get_ode_sampler(sde, shape, denoise=False, rtol=1e-5, atol=1e-5, method='RK45', eps=1e-3):
+    """Probability-flow ODE sampler with a black-box solver (sampling/unconditional.py:93-158):
+    ``ode_sampler(model, z=None) -> (samples, nfe)``.  The drift of the reverse-time ODE, f(x, t) - g(t)^2 score / 2
+    (sde_lib.py:123-133), is linear in x for every SDE of sde_lib, so an evaluation is the score network plus one
+    ``csd_axpby`` with host scalars; the state crosses to the host per evaluation exactly as in the reference."""
+    from scipy import integrate
+
+    from .. import ops
+    from .predictors import ReverseDiffusionPredictor, _linear_sde_coeffs
+
+    def denoise_update_fn(model, x):
+        score_fn = mutils.get_score_fn(sde, model, conditional=False, train=False, continuous=True)
+        predictor_obj = ReverseDiffusionPredictor(sde, score_fn, probability_flow=False)
+        vec_eps = torch.ones(x.shape[0], device=x.device) * eps
+        _, x = predictor_obj.update_fn(x, vec_eps)
+        return x
+
+    def drift_fn(model, x, t):
+        score_fn = mutils.get_score_fn(sde, model, conditional=False, train=False, continuous=True)
+        phi, g = _linear_sde_coeffs(sde, t)
+        return ops.axpby(x, score_fn(x, t), alpha=phi, beta=-0.5 * g * g)
+
+    def ode_sampler(model, z=None):
+        with torch.no_grad():
+            x = sde.prior_sampling(shape).to(model.device) if z is None else z
+
+            def ode_func(t, xf):
+                xt = mutils.from_flattened_numpy(xf, shape).to(model.device).type(torch.float32)
+                vec_t = torch.ones(shape[0], device=xt.device) * t
+                return mutils.to_flattened_numpy(drift_fn(model, xt, vec_t))
+
+            solution = integrate.solve_ivp(ode_func, (sde.T, eps), mutils.to_flattened_numpy(x), rtol=rtol, atol=atol,
+                                           method=method)
+            nfe = solution.nfev
+            x = torch.tensor(solution.y[:, -1]).reshape(shape).to(model.device).type(torch.float32)
+            if denoise:
+                x = denoise_update_fn(model, x)
+            return x, nfe
+
+    return ode_sampler
 
 
 def shared_predictor_update_fn(x, t, sde, model, predictor, probability_flow, continuous):

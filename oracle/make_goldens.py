@@ -335,6 +335,21 @@ def gen_grads(ref):
     np.savez_compressed(os.path.join(OUT, 'grads.npz'), **out)
 
 
+def gen_ode(ref):
+    """Probability-flow ODE sampler of the reference (sampling/unconditional.py:93-158: scipy RK45, rtol = atol = 1e-5, denoise) on
+    the tiny unconditional case from a fixed latent -> tests/golden/ode.npz (final sample, number of function evaluations)."""
+    cfg, B = cases.case_config('uncond_tiny')
+    model, _ = build_ref_model(ref, cfg)
+    model.embedding_type = 'positional'
+    sde = sdes_for(ref, cfg)
+    shape = (B,) + tuple(cfg.data.shape_x)
+    z = cases.tape([shape], 17)[0] * float(cfg.model.sigma_max_x)
+    sampler = ref['sampling.unconditional'].get_ode_sampler(sde, shape, denoise=True, eps=1e-5)
+    x, nfe = sampler(model, z=z.clone())
+    print('ode: nfe', nfe, 'max |x|', float(x.abs().max()))
+    np.savez_compressed(os.path.join(OUT, 'ode.npz'), x=x.numpy(), nfe=np.int64(nfe))
+
+
 def gen_ncsnpp(ref):
     """Reference NCSN++ forward (models/ncsnpp.py) on the seeded cases of cases.NCSNPP_CASES -> tests/golden/ncsnpp.npz:
     state_dict key order + shapes (as a string table) and the network output."""
@@ -367,6 +382,7 @@ def main():
             globals()['gen_' + name](ref)
         return
     gen_grads(ref)
+    gen_ode(ref)
     gen_sde_tables(ref)
     gen_modules(ref)
     gen_steps(ref)

@@ -618,3 +618,23 @@ def dsm_loss(p, cfg, name, ve_x, ve_y, x, y, t, z_x, z_y=None, reduce_mean=True,
     else:
         losses = red(torch.square(score * _b(std_x) + z_x).reshape(x.shape[0], -1))
     return losses.mean()
+
+
+def pf_ode_sample(score_fn, ve, shape, z, eps=1e-5, rtol=1e-5, atol=1e-5, denoise=True):
+    """Probability-flow ODE sampler (sampling/unconditional.py:93-158) for a VE SDE: scipy RK45 on dx/dt = -g(t)^2 score / 2
+    (sde_lib.py:123-133 with f = 0), then one noise-free reverse-diffusion step at t = eps (predictors.py:84-89).
+    ``score_fn(x, t) -> score``.  Returns (x, nfe)."""
+    from scipy import integrate
+
+    def ode_func(t, xf):
+        x = torch.from_numpy(xf.reshape(shape)).type(torch.float32)
+        vt = torch.ones(shape[0]) * t
+        drift = -_b(_g2(ve, vt)) * score_fn(x, vt) * 0.5
+        return drift.detach().numpy().reshape((-1,))
+
+    sol = integrate.solve_ivp(ode_func, (ve.T, eps), z.detach().numpy().reshape((-1,)), rtol=rtol, atol=atol, method='RK45')
+    x = torch.tensor(sol.y[:, -1]).reshape(shape).type(torch.float32)
+    if denoise:
+        vt = torch.ones(shape[0]) * eps
+        x = x + _b(ve.G(vt)) ** 2 * score_fn(x, vt)
+    return x, sol.nfev

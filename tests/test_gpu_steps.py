@@ -129,3 +129,22 @@ def test_global_norm_langevin_is_langevin_in_one_process():
     n = torch.randn(5, 7, 9, device=dev)
     from conditional_score_diffusion_amd import ops
     assert torch.allclose(ops.row_norms(n), torch.norm(n.reshape(5, -1), dim=-1), rtol=1e-6)
+
+
+def test_probability_flow_ode_sampler_vs_reference(golden_dir):
+    """sampling.method = 'ode' (sampling/unconditional.py:93-158): scipy RK45 over the HIP drift against the reference's sample."""
+    import cases
+    from conditional_score_diffusion_amd.sampling.unconditional import get_sampling_fn
+    from test_gpu_network import build, dev, sdes_for
+    g = np.load(os.path.join(golden_dir, 'ode.npz'))
+    cfg, nc, p, model = build('uncond_tiny')
+    sde = sdes_for(cfg)
+    cfg.sampling.method = 'ode'
+    B = cases.case_config('uncond_tiny')[1]
+    shape = (B,) + tuple(cfg.data.shape_x)
+    z = cases.tape([shape], 17)[0] * float(cfg.model.sigma_max_x)
+    sampler = get_sampling_fn(cfg, sde, shape, 1e-5)
+    x, nfe = sampler(model, z=z.to(dev()))
+    ref = g['x']
+    assert abs(nfe - int(g['nfe'])) <= 6
+    assert np.abs(x.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max()

@@ -187,3 +187,24 @@ def test_training_loss_and_grads(golden_dir, case):
     g = load(golden_dir, 'grads')
     loss, grads = oracle_loss_and_grads(case)
     check_grads_vs_fixture(g, case, loss, grads, 2e-4)
+
+
+def test_probability_flow_ode_sampler(golden_dir):
+    """a18 (sampling.method = 'ode'): the oracle's RK45 probability-flow sampler lands on the reference's sample with the same
+    number of function evaluations."""
+    g = load(golden_dir, 'ode')
+    cfg, B = cases.case_config('uncond_tiny')
+    nc = so.NetCfg.from_config(cfg)
+    p = so.synth_params(so.ddpm_param_shapes(nc), 0)
+    ve = so.VE(cfg.model.sigma_min_x, cfg.model.sigma_max_x, cfg.model.num_scales)
+    shape = (B,) + tuple(cfg.data.shape_x)
+    z = cases.tape([shape], 17)[0] * float(cfg.model.sigma_max_x)
+
+    def score_fn(x, t):
+        with torch.no_grad():
+            std = ve.std(t)
+            return so.ddpm_forward(p, nc, x, std) / std[:, None, None, None]
+
+    x, nfe = so.pf_ode_sample(score_fn, ve, shape, z)
+    assert abs(nfe - int(g['nfe'])) <= 6
+    assert rel(x.numpy(), g['x']) < 1e-3
