@@ -11,10 +11,10 @@ This first NCSN++ executor is *operator-granular* (one C-ABI call per layer, NCH
 per call): it establishes parity for the family the north star names; the planned NHWC graph executor that the
 DDPM family already has (csrc/unet.hip) is the next step for it.
 
-Covered options (the combination the large-image NCSN++ configs of the reference use - ffhq/celebahq 256, bedroom, church, celebA-HQ;
-the CIFAR-10 configs add progressive_input=residual and the ddpmpp ones fir=False, which raise NotImplementedError): ``resblock_type='biggan'``,
-``fir=True`` with any FIR kernel, ``progressive`` in {none, output_skip}, ``progressive_input`` in {none,
-input_skip}, ``progressive_combine='sum'``, ``embedding_type`` in {positional, fourier}, ``skip_rescale`` either
+Covered options - every NCSN++ / DDPM++ config of the reference (configs/{ve,vp,subvp}/*ncsnpp*, *ddpmpp*) falls in this set:
+``resblock_type='biggan'``, ``fir`` True (any FIR kernel) or False (naive nearest / 2x2-mean resampling), ``progressive`` in
+{none, output_skip}, ``progressive_input`` in {none, input_skip, residual}, ``progressive_combine='sum'``, ``embedding_type``
+in {positional, fourier}, ``skip_rescale`` either
 way, attention at any resolutions.  Other values raise NotImplementedError (never a silent fallback).
 """
 import math
@@ -72,10 +72,9 @@ class NCSNpp(nn.Module):
         assert self.embedding_type in ['fourier', 'positional']
         if self.resblock_type != 'biggan':
             raise NotImplementedError("ncsnpp on the HIP path: resblock_type 'biggan' only (got %r)" % self.resblock_type)
-        if not self.fir:
-            raise NotImplementedError('ncsnpp on the HIP path: fir=True only')
-        if self.progressive == 'residual' or self.progressive_input == 'residual':
-            raise NotImplementedError("ncsnpp on the HIP path: 'residual' progressive growing is not provided yet")
+        if self.progressive == 'residual':
+            # (its pyramid_upsample is up_or_down_sampling.Conv2d(up=True) = upsample_conv_2d, which fails upstream; no config uses it)
+            raise NotImplementedError("ncsnpp on the HIP path: progressive='residual' is not provided")
         if combine != 'sum':
             raise NotImplementedError("ncsnpp on the HIP path: progressive_combine 'sum' only (got %r)" % combine)
         channels = d.num_channels
@@ -108,6 +107,9 @@ class NCSNpp(nn.Module):
                 mods.append(('res', dict(cin=in_ch, cout=in_ch, up=False, down=True)))
                 if self.progressive_input == 'input_skip':
                     mods.append(('combine', dict(dim1=input_pyramid_ch, dim2=in_ch)))
+                elif self.progressive_input == 'residual':
+                    mods.append(('pyr_down', dict(cin=input_pyramid_ch, cout=in_ch)))     # ncsnpp.py:171-173
+                    input_pyramid_ch = in_ch
                 hs_c.append(in_ch)
         in_ch = hs_c[-1]
         mods.append(('res', dict(cin=in_ch, cout=in_ch, up=False, down=False)))
@@ -169,6 +171,8 @@ class NCSNpp(nn.Module):
             P('bias', torch.zeros(a['c']))
         elif kind == 'combine':
             conv('Conv_0', a['dim2'], a['dim1'], 1, 1.)                      # layerspp.py:49
+        elif kind == 'pyr_down':                                             # layerspp.Downsample(with_conv=True), :130-147
+            conv('Conv2d_0' if self.fir else 'Conv_0', a['cout'], a['cin'], 3, 1.)
         elif kind == 'attn':
             gn('GroupNorm_0', a['c'])
             for j in range(4):
@@ -208,15 +212,38 @@ class NCSNpp(nn.Module):
             self._fir_cache[key] = torch.tensor(k * gain, device=device)
         return self._fir_cache[key]
 
+    def _box(self, device, gain):
+        key = ('box', str(device), gain)
+        if key not in self._fir_cache:
+            self._fir_cache[key] = torch.full((2, 2), gain, dtype=torch.float32, device=device)
+        return self._fir_cache[key]
+
     def _upsample_2d(self, x, factor=2):
+        if not self.fir:       # naive_upsample_2d (up_or_down_sampling.py:59-63) = zero insertion + 2x2 box: nearest neighbour
+            return ops.upfirdn2d(x, self._box(x.device, 1.0), up=2, pad=(1, 0))
         k = self._fir(x.device, float(factor ** 2))
         p = k.shape[0] - factor
         return ops.upfirdn2d(x, k, up=factor, pad=((p + 1) // 2 + factor - 1, p // 2))
 
     def _downsample_2d(self, x, factor=2):
+        if not self.fir:       # naive_downsample_2d (:66-69): mean of 2x2 blocks
+            return ops.upfirdn2d(x, self._box(x.device, 0.25), down=2, pad=(0, 0))
         k = self._fir(x.device, 1.0)
         p = k.shape[0] - factor
         return ops.upfirdn2d(x, k, down=factor, pad=((p + 1) // 2, p // 2))
+
+    def _pyr_down(self, node, x):
+        """layerspp.Downsample(with_conv=True) of the 'residual' input pyramid (layerspp.py:130-165).  fir: conv_downsample_2d =
+        FIR, then a VALID stride-2 3x3 conv on the (H+1)-wide result; run as the library's stride-2 convolution (pad (0,1,0,1))
+        on an (H+2)-wide FIR output - its first H/2 rows/columns read exactly the valid window - and cropped."""
+        O = self._O
+        if not self.fir:
+            return O.conv2d(x, node.Conv_0.weight, node.Conv_0.bias, stride=2, downsample_pad=True, precision=self.precision)
+        k = self._fir(x.device, 1.0)
+        p = (k.shape[0] - 2) + 2
+        z = ops.upfirdn2d(x, k, pad=((p + 1) // 2, p // 2 + 1))
+        y = O.conv2d(z, node.Conv2d_0.weight, node.Conv2d_0.bias, stride=2, downsample_pad=True, precision=self.precision)
+        return y[:, :, :-1, :-1].contiguous()
 
     # ---- blocks ----
     @property
@@ -314,6 +341,11 @@ class NCSNpp(nn.Module):
                     # Combine 'sum' (models/layerspp.py:53-57): Conv_0(input_pyramid) + h
                     h = O.axpby(self._conv(nodes[i].Conv_0, input_pyramid, 1), h)
                     i += 1
+                elif self.progressive_input == 'residual':           # ncsnpp.py:302-309
+                    input_pyramid = self._pyr_down(nodes[i], input_pyramid)
+                    i += 1
+                    h = O.axpby(input_pyramid, h, post=(1.0 / math.sqrt(2.0)) if self.skip_rescale else 1.0)
+                    input_pyramid = h
                 hs.append(h)
         h = hs[-1]
         h = self._res(nodes[i], mods[i][1], h, temb)
@@ -377,10 +409,9 @@ class HipNCSNpp(HipUNet):
         m = config.model
         if m.resblock_type.lower() != 'biggan':
             raise NotImplementedError("ncsnpp on the HIP path: resblock_type 'biggan' only (got %r)" % m.resblock_type)
-        if not m.fir:
-            raise NotImplementedError('ncsnpp on the HIP path: fir=True only')
         if m.progressive.lower() == 'residual' or m.progressive_input.lower() == 'residual':
-            raise NotImplementedError("ncsnpp on the HIP path: 'residual' progressive growing is not provided yet")
+            raise NotImplementedError("the planned NCSN++ graph does not cover 'residual' progressive growing (the registry hands "
+                                      "out the operator-granular class for progressive_input='residual')")
         if m.progressive_combine.lower() != 'sum':
             raise NotImplementedError("ncsnpp on the HIP path: progressive_combine 'sum' only")
         if not m.conditional:
@@ -406,7 +437,9 @@ class HipNCSNpp(HipUNet):
         cfg.progressive = 1 if m.progressive.lower() == 'output_skip' else 0
         cfg.progressive_input = 1 if m.progressive_input.lower() == 'input_skip' else 0
         cfg.embedding_type = 1 if m.embedding_type.lower() == 'fourier' else 0
-        taps = list(m.fir_kernel)
+        # fir = False (naive nearest / 2x2-mean resampling, up_or_down_sampling.py:59-69) IS the 4-tap FIR (0, 1, 1, 0): the
+        # normalised kernel is a 2x2 box, with the same pads
+        taps = list(m.fir_kernel) if m.fir else [0., 1., 1., 0.]
         if len(taps) != 4:
             raise NotImplementedError('ncsnpp on the HIP path: 4-tap FIR kernels only (got %r)' % (taps,))
         cfg.n_fir = 4
@@ -471,7 +504,20 @@ class NCSNppPairedPlanned(HipNCSNpp):
         return {'x': out[:, :c], 'y': out[:, c:]}
 
 
-utils.register_model(NCSNppPlanned, name='ncsnpp')
-utils.register_model(NCSNppPairedPlanned, name='ncsnpp_paired')
+def _needs_operator_granular(config):
+    return config.model.progressive_input.lower() == 'residual'
+
+
+def create_ncsnpp(config, **kw):
+    """``ncsnpp``: the planned graph executor, or the operator-granular class for the options only it covers"""
+    return (NCSNpp if _needs_operator_granular(config) else NCSNppPlanned)(config, **kw)
+
+
+def create_ncsnpp_paired(config, **kw):
+    return (NCSNpp_paired if _needs_operator_granular(config) else NCSNppPairedPlanned)(config, **kw)
+
+
+utils.register_model(create_ncsnpp, name='ncsnpp')
+utils.register_model(create_ncsnpp_paired, name='ncsnpp_paired')
 utils.register_model(NCSNpp, name='ncsnpp_ops')
 utils.register_model(NCSNpp_paired, name='ncsnpp_paired_ops')

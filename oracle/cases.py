@@ -57,7 +57,7 @@ CASES = {
 
 def make_ncsnpp_config(name='ncsnpp', nf=16, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(8,), image_size=16,
                        channels=3, embedding_type='fourier', progressive='output_skip', progressive_input='input_skip',
-                       skip_rescale=True, fir_kernel=(1, 3, 3, 1), init_scale=0., centered=False):
+                       skip_rescale=True, fir_kernel=(1, 3, 3, 1), init_scale=0., centered=False, fir=True):
     """A reference-style NCSN++ config with the keys models/ncsnpp.py:44-236 reads
     (cf. configs/ve/ffhq_256_ncsnpp_continuous.py, configs/default_lsun_configs.py)."""
     c = ConfigDict()
@@ -67,7 +67,7 @@ def make_ncsnpp_config(name='ncsnpp', nf=16, ch_mult=(1, 2), num_res_blocks=1, a
     c.data = ConfigDict(image_size=image_size, effective_image_size=image_size, centered=centered, num_channels=channels)
     c.model = ConfigDict(name=name, nf=nf, ch_mult=tuple(ch_mult), num_res_blocks=num_res_blocks,
                          attn_resolutions=tuple(attn_resolutions), dropout=0.1, resamp_with_conv=True, conditional=True,
-                         nonlinearity='swish', num_scales=1000, sigma_min=0.01, sigma_max=50., fir=True,
+                         nonlinearity='swish', num_scales=1000, sigma_min=0.01, sigma_max=50., fir=fir,
                          fir_kernel=list(fir_kernel), skip_rescale=skip_rescale, resblock_type='biggan',
                          progressive=progressive, progressive_input=progressive_input, progressive_combine='sum',
                          attention_type='ddpm', init_scale=init_scale, embedding_type=embedding_type, fourier_scale=16,
@@ -82,6 +82,15 @@ NCSNPP_CASES = {
                                      progressive='none', progressive_input='none', skip_rescale=False, centered=True), 2),
     'ncsnpp_paired_skip': (dict(name='ncsnpp_paired', channels=6, nf=32, ch_mult=(1, 2), attn_resolutions=(16,),
                                 num_res_blocks=2), 2),
+    # the CIFAR-10 NCSN++ configs: progressive_input = 'residual' (configs/ve/cifar10_ncsnpp_continuous.py)
+    'ncsnpp_residual_input': (dict(nf=32, ch_mult=(1, 2, 2), attn_resolutions=(8,), progressive='none',
+                                   progressive_input='residual'), 2),
+    # the DDPM++ configs: fir = False (configs/vp/cifar10_ddpmpp_continuous.py), here with the input pyramid on (the OUTPUT pyramid
+    # with fir = False cannot run in the reference: layerspp.py:117 passes 'nearest' as F.interpolate's scale_factor)
+    'ncsnpp_nofir_skip': (dict(nf=32, ch_mult=(1, 2), attn_resolutions=(8,), fir=False, embedding_type='positional',
+                               progressive='none'), 2),
+    'ncsnpp_nofir_residual': (dict(nf=32, ch_mult=(1, 1, 2), attn_resolutions=(4,), fir=False, embedding_type='positional',
+                                   progressive='none', progressive_input='residual', skip_rescale=False), 2),
 }
 
 

@@ -351,13 +351,45 @@ def downsample_2d(x, k, factor=2):
     return upfirdn2d_ref(x, kern, down=factor, pad=((p + 1) // 2, p // 2))
 
 
+def naive_upsample_2d(x, factor=2):
+    """up_or_down_sampling.py:59-63 (fir = False): nearest-neighbour."""
+    N, C, H, W = x.shape
+    return x.reshape(N, C, H, 1, W, 1).repeat(1, 1, 1, factor, 1, factor).reshape(N, C, H * factor, W * factor)
+
+
+def naive_downsample_2d(x, factor=2):
+    """up_or_down_sampling.py:66-69 (fir = False): mean over factor x factor blocks."""
+    N, C, H, W = x.shape
+    return torch.mean(x.reshape(N, C, H // factor, factor, W // factor, factor), dim=(3, 5))
+
+
+def resample(x, fir_k, up):
+    """FIR resampling (fir_k a tap tuple) or, for fir_k None, the naive forms - as ResnetBlockBigGANpp (layerspp.py:246-259),
+    layerspp.Upsample / Downsample without conv (:110-123,149-163) select them by ``fir``."""
+    if fir_k is None:
+        return naive_upsample_2d(x) if up else naive_downsample_2d(x)
+    return upsample_2d(x, fir_k) if up else downsample_2d(x, fir_k)
+
+
+def pyramid_down_conv(p, pre, x, fir_k):
+    """layerspp.Downsample(with_conv=True) (layerspp.py:130-165): fir -> up_or_down_sampling.Conv2d(down=True) =
+    conv_downsample_2d (:155-178: FIR with pad ((p+1)//2, p//2), p = (taps - 2) + 2, then a VALID stride-2 3x3 conv) + bias;
+    no fir -> pad (0,1,0,1) + stride-2 conv3x3."""
+    if fir_k is None:
+        return F.conv2d(F.pad(x, (0, 1, 0, 1)), p[pre + 'Conv_0.weight'], p[pre + 'Conv_0.bias'], stride=2)
+    kern = fir_kernel_2d(fir_k, 1.0)
+    pp = (kern.shape[0] - 2) + 2
+    z = upfirdn2d_ref(x, kern, pad=((pp + 1) // 2, pp // 2))
+    return F.conv2d(z, p[pre + 'Conv2d_0.weight'], stride=2) + p[pre + 'Conv2d_0.bias'].reshape(1, -1, 1, 1)
+
+
 def biggan_block(p, pre, x, temb, act, cin, cout, up, down, fir_k, skip_rescale):
-    """ResnetBlockBigGANpp.forward in eval mode (layerspp.py:242-274)."""
+    """ResnetBlockBigGANpp.forward in eval mode (layerspp.py:242-274); fir_k None = fir False."""
     h = act(F.group_norm(x, _ncsnpp_groups(cin), p[pre + 'GroupNorm_0.weight'], p[pre + 'GroupNorm_0.bias'], eps=1e-6))
     if up:
-        h, x = upsample_2d(h, fir_k), upsample_2d(x, fir_k)
+        h, x = resample(h, fir_k, True), resample(x, fir_k, True)
     elif down:
-        h, x = downsample_2d(h, fir_k), downsample_2d(x, fir_k)
+        h, x = resample(h, fir_k, False), resample(x, fir_k, False)
     h = F.conv2d(h, p[pre + 'Conv_0.weight'], p[pre + 'Conv_0.bias'], padding=1)
     if temb is not None:
         h = h + F.linear(act(temb), p[pre + 'Dense_0.weight'], p[pre + 'Dense_0.bias'])[:, :, None, None]
@@ -376,14 +408,14 @@ def attn_block_pp(p, pre, x, skip_rescale):
 
 
 def ncsnpp_forward(p, config, x, time_cond):
-    """NCSNpp.forward (models/ncsnpp.py:238-388) for the option set the HIP adapter covers: biggan blocks, FIR
-    resampling, progressive in {none, output_skip}, progressive_input in {none, input_skip}, combine 'sum'."""
+    """NCSNpp.forward (models/ncsnpp.py:238-388) for the option set the HIP adapter covers: biggan blocks, FIR or naive
+    resampling, progressive in {none, output_skip}, progressive_input in {none, input_skip, residual}, combine 'sum'."""
     m, d = config.model, config.data
     act = _act(m.nonlinearity.lower())
     nf, ch_mult = m.nf, tuple(m.ch_mult)
     L = len(ch_mult)
     res = [d.effective_image_size // (2 ** i) for i in range(L)]
-    fir_k, skip = tuple(m.fir_kernel), bool(m.skip_rescale)
+    fir_k, skip = (tuple(m.fir_kernel) if m.fir else None), bool(m.skip_rescale)
     prog, prog_in = m.progressive.lower(), m.progressive_input.lower()
     i = 0
 
@@ -425,9 +457,14 @@ def ncsnpp_forward(p, config, x, time_cond):
             h = biggan_block(p, pre(), hs[-1], temb, act, in_ch, in_ch, False, True, fir_k, skip)
             i += 1
             if prog_in == 'input_skip':
-                input_pyramid = downsample_2d(input_pyramid, fir_k)
+                input_pyramid = resample(input_pyramid, fir_k, False)
                 h = F.conv2d(input_pyramid, p[pre() + 'Conv_0.weight'], p[pre() + 'Conv_0.bias']) + h   # Combine 'sum'
                 i += 1
+            elif prog_in == 'residual':                                        # ncsnpp.py:302-309
+                input_pyramid = pyramid_down_conv(p, pre(), input_pyramid, fir_k)
+                i += 1
+                input_pyramid = (input_pyramid + h) / np.sqrt(2.) if skip else input_pyramid + h
+                h = input_pyramid
             hs.append(h)
             hs_c.append(in_ch)
     h = hs[-1]
@@ -453,7 +490,7 @@ def ncsnpp_forward(p, config, x, time_cond):
             i += 1
             ph = F.conv2d(ph, p[pre() + 'weight'], p[pre() + 'bias'], padding=1)
             i += 1
-            pyramid = ph if pyramid is None else upsample_2d(pyramid, fir_k) + ph
+            pyramid = ph if pyramid is None else resample(pyramid, fir_k, True) + ph
         if lv != 0:
             h = biggan_block(p, pre(), h, temb, act, in_ch, in_ch, True, False, fir_k, skip)
             i += 1
