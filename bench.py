@@ -281,6 +281,17 @@ def main():
                 except Exception as e:      # a side measurement must never break the bench line
                     alt[mode] = {'error': str(e)[:200]}
             res['other_precision_modes'] = alt
+            # SURVEY 8(d) "config 4": one data-parallel training step (loss + HIP backward + gradient all-reduce + fused
+            # clip/Adam/EMA) of the VS-CMDE edges2shoes-64 shape, measured by tools/bench_train.py - a side figure, not the headline
+            try:
+                tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'bench_train.py')
+                r = subprocess.run([sys.executable, tool, '--precision', 'fp16x3', '--steps', '10', '--warmup', '3'],
+                                   capture_output=True, text=True, timeout=600)
+                j = json.loads(r.stdout.strip().splitlines()[-1])
+                res['training_side_bench'] = {k: j[k] for k in ('metric', 'value', 'unit', 'images_per_sec', 'global_batch', 'ms_per_step',
+                                                                'precision', 'params', 'achieved_TFLOPs_3x_fwd')}
+            except Exception as e:
+                res['training_side_bench'] = {'error': str(e)[:200]}
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()

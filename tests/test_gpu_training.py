@@ -394,3 +394,25 @@ def test_split_bf16_weight_gradient(B, Cin, Cout, H, k):
     GN.conv2d(x.permute(0, 2, 3, 1).contiguous().to(dev()), wn, None, precision='fp16x3').backward(dy.permute(0, 2, 3, 1).contiguous().to(dev()))
     assert rel(wn.grad, wr.grad) < 5e-5
     assert torch.equal(wn.grad, wd.grad)                     # same kernel, same reduction order
+
+
+def test_weight_gradient_ab_schedules_agree(monkeypatch):
+    """the A/B schedules kept behind environment switches (wide-load fp32 kernel, gather-only bf16 kernel) give the same weight
+    gradient as the default ones"""
+    from conditional_score_diffusion_amd import grad_ops_nhwc as GN
+    rs = np.random.RandomState(31)
+    x, w, dy = rnd(rs, 2, 20, 20, 64), rnd(rs, 96, 64, 3, 3) * 0.1, rnd(rs, 2, 20, 20, 96)
+
+    def wgrad(precision):
+        wd = w.to(dev()).requires_grad_(True)
+        GN.conv2d(x.to(dev()), wd, None, precision=precision).backward(dy.to(dev()))
+        return wd.grad.clone()
+
+    base32, base16 = wgrad('fp32'), wgrad('fp16x3')
+    monkeypatch.setenv('CSD_WGRAD_WIDE', '1')
+    assert rel(wgrad('fp32'), base32) < 1e-5
+    monkeypatch.delenv('CSD_WGRAD_WIDE')
+    monkeypatch.setenv('CSD_WGRAD_GATHER', '1')
+    assert rel(wgrad('fp16x3'), base16) < 1e-6          # same arithmetic, different data path
+    monkeypatch.setenv('CSD_WGRAD_FP32', '1')
+    assert torch.equal(wgrad('fp16x3'), base32)          # forced back to the exact fp32 kernel
