@@ -46,7 +46,8 @@ __device__ __forceinline__ double dpp_row16_sum(double v) {
 
 // S: stride.  S = 2 is the reference Downsample (pad (0,1,0,1), models/layers.py:619-625): the patch of a TH x TW output
 // tile is (2*TH+1) x (2*TW+1) input pixels and a lane's tap (0,0) sits at (2*ty, 2*tx).
-template <int MQ, int NS, bool MASK, int PWC, int S>
+// NTQ: 16-cout tiles per N half - 3 (Cout % 96 == 0: the nf = 96 nets) or 4 (Cout % 128 == 0: the nf = 128 nets)
+template <int MQ, int NS, bool MASK, int PWC, int S, int NTQ>
 __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void* __restrict__ g_hi,
                                                                     const void* __restrict__ g_lo,
                                                                     const char* __restrict__ g_wpack,
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
   constexpr int SPP = 2 * NS * KCS;          // 16-byte slots per patch pixel per stage
   constexpr int NU = (S == 2) ? ((NS == 2) ? 10 : 5) : ((NS == 2) ? 7 : 4);      // staging slots per thread (host: patch * SPP <= NU * 256)
   constexpr int rstride = PWC * PSB;
-  constexpr int WSTEP = 3 * NS * 1024;       // weight bytes per K step per wave
+  constexpr int WSTEP = NTQ * NS * 1024;     // weight bytes per K step per wave
+  constexpr int GC = 32 * NTQ, HC = 16 * NTQ; // couts per workgroup / per N half
   extern __shared__ __attribute__((aligned(16))) char smem16[];
 
   const int tid = threadIdx.x;
@@ -169,20 +171,20 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
   constexpr int BR = 3;
   const int nk32 = Cin / 32;
   const char* wstep = g_wpack + ((size_t)(ng * 2 + ni) * nk32 * TAPS) * WSTEP + lane * 16;
-  half8 wreg[BR][3][NS];
+  half8 wreg[BR][NTQ][NS];
 #pragma unroll
   for (int q = 0; q < BR - 1; ++q)
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NTQ; ++t)
 #pragma unroll
       for (int p = 0; p < NS; ++p) wreg[q][t][p] = gload_h8(wstep + (size_t)q * WSTEP + (t * NS + p) * 1024);
   wstep += (size_t)(BR - 2) * WSTEP;
 
-  floatx4q acc[MQ][3];
+  floatx4q acc[MQ][NTQ];
 #pragma unroll
   for (int j = 0; j < MQ; ++j)
 #pragma unroll
-    for (int t = 0; t < 3; ++t) acc[j][t] = floatx4q{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NTQ; ++t) acc[j][t] = floatx4q{0.f, 0.f, 0.f, 0.f};
 
   // first stage: one burst
   {
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
       const int r = tap / KS, sx = tap % KS;
       wstep += WSTEP;
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < NTQ; ++t)
 #pragma unroll
         for (int p = 0; p < NS; ++p) wreg[bn][t][p] = gload_h8(wstep + (t * NS + p) * 1024);
 #pragma unroll
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
           }
         }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < NTQ; ++t) {
           if (NS == 2) {
             acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[bc][t][1], b[0], acc[j][t], 0, 0, 0);
             acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[bc][t][0], b[1], acc[j][t], 0, 0, 0);
@@ -273,23 +275,23 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
       __builtin_amdgcn_make_buffer_rsrc(k.a.out + o_base * k.a.out_stride + k.a.out_coff, 0, OOB, RSRC_FLAGS);
   const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(has_res ? k.a.res + o_base * k.Cout : k.a.out), 0, OOB, RSRC_FLAGS);
-  const int c_base = ng * 96 + ni * 48 + kq * 4;            // this lane's first cout of 16-cout tile 0
+  const int c_base = ng * GC + ni * HC + kq * 4;            // this lane's first cout of 16-cout tile 0
   int oidx[MQ];
 #pragma unroll
   for (int j = 0; j < MQ; ++j) oidx[j] = otab[(mi * MQ + j) * 16 + l16];
   // every read before the first store
-  float4 bias4[3], tvu4[3];
+  float4 bias4[NTQ], tvu4[NTQ];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
+  for (int t = 0; t < NTQ; ++t) {
     const int c0 = c_base + t * 16;
     bias4[t] = k.a.bias ? gload4f(k.a.bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
     tvu4[t] = (!MASK && has_temb) ? gload4f(k.a.temb + (size_t)b0 * k.a.temb_stride + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  float4 addv[MQ][3];
+  float4 addv[MQ][NTQ];
 #pragma unroll
   for (int j = 0; j < MQ; ++j)
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < NTQ; ++t) {
       float4 a = tvu4[t];
       if (has_res) {
         const unsigned off = oidx[j] >= 0 ? (unsigned)(oidx[j] * k.Cout + c_base + t * 16) * 4u : OOB;
@@ -305,21 +307,21 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
     for (int j = 0; j < MQ; ++j) {
       const int b = btab[(mi * MQ + j) * 16 + l16];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
+      for (int t = 0; t < NTQ; ++t) {
         const float4 tv = gload4f(k.a.temb + (size_t)b * k.a.temb_stride + c_base + t * 16);
         addv[j][t] = make_float4(addv[j][t].x + tv.x, addv[j][t].y + tv.y, addv[j][t].z + tv.z, addv[j][t].w + tv.w);
       }
     }
   }
-  double st_s[3][4], st_q[3][4];              // GroupNorm partials of this lane's 12 columns over its MQ pixels
+  double st_s[NTQ][4], st_q[NTQ][4];              // GroupNorm partials of this lane's 12 columns over its MQ pixels
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < NTQ; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) { st_s[t][i] = 0.0; st_q[t][i] = 0.0; }
 #pragma unroll
   for (int j = 0; j < MQ; ++j)
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < NTQ; ++t) {
       const float b4[4] = {bias4[t].x, bias4[t].y, bias4[t].z, bias4[t].w};
       const float a4[4] = {addv[j][t].x, addv[j][t].y, addv[j][t].z, addv[j][t].w};
       float o4[4];
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
   // `stats` only when a tile lies inside one sample.  Fixed-order DPP reduction over the 16 pixel lanes.
   if (k.a.stats) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NTQ; ++t)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const double s = dpp_row16_sum(st_s[t][i]), q = dpp_row16_sum(st_q[t][i]);
@@ -359,15 +361,19 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
 // ---------------------------------------------------------------------------------------------
 bool conv16q_supported(const ConvPlan& p, int ns) {
   return (ns == 1 || ns == 2) && p.taps == 9 && ((p.stride == 1 && (p.up == 0 || p.up == 1)) || (p.stride == 2 && p.up == 0)) &&
-         p.C1 == 0 && p.C0 % 32 == 0 && p.Cout % 96 == 0;
+         p.C1 == 0 && p.C0 % 32 == 0 && (p.Cout % 96 == 0 || p.Cout % 128 == 0);
 }
 
+// 16-cout tiles per N half: groups of 96 couts where that divides (the layout the nf = 96 nets have always had), else of 128
+static inline int q_ntq(int cout) { return cout % 96 == 0 ? 3 : 4; }
+
 size_t conv16q_packed_bytes(const ConvPlan& p, int ns) {
-  return (size_t)(p.Cout / 96) * 2 * (p.C0 / 32) * 9 * 3 * ns * 1024 + (size_t)4 * 3 * ns * 1024;   // + prefetch slack
+  const int ntq = q_ntq(p.Cout);
+  return (size_t)(p.Cout / (32 * ntq)) * 2 * (p.C0 / 32) * 9 * ntq * ns * 1024 + (size_t)4 * ntq * ns * 1024;   // + prefetch slack
 }
 
 __global__ void conv16q_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ wpack, int layout, int cin_src,
-                                    int cout_src, int cout_off, int Cin, int Cout, int ns) {
+                                    int cout_src, int cout_off, int Cin, int Cout, int ns, int ntq) {
   // one thread per (cout in [cout_off, cout_off + cout_src), cin, tap)
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)cout_src * Cin * 9;
@@ -377,12 +383,16 @@ __global__ void conv16q_pack_kernel(const float* __restrict__ w, _Float16* __res
   const int co = (int)(idx / ((size_t)9 * Cin));
   const int cout = cout_off + co;
   if (cin >= cin_src || cout >= Cout) return;          // padding stays zero
-  const float v = ((layout == 0) ? w[((size_t)co * cin_src + cin) * 9 + tap] : w[(size_t)cin * cout_src + co]) * C16_WSCALE;
-  const int ng = cout / 96, ni = (cout % 96) / 48, t = (cout % 48) / 16, r = cout % 16;
+  // layout 0: OIHW; 1: NIN [Cin][Cout]; 2: the transposed convolution's OIHW weight [Cin][Cout][9], spatially flipped (data gradient)
+  const float v = ((layout == 0) ? w[((size_t)co * cin_src + cin) * 9 + tap]
+                   : (layout == 1) ? w[(size_t)cin * cout_src + co]
+                                   : w[((size_t)cin * cout_src + co) * 9 + (8 - tap)]) * C16_WSCALE;
+  const int gc = 32 * ntq, hc = 16 * ntq;
+  const int ng = cout / gc, ni = (cout % gc) / hc, t = (cout % hc) / 16, r = cout % 16;
   const int kb = cin / 32, kq = (cin % 32) / 8, q = cin % 8;
   const int lane = kq * 16 + r;
   const size_t step = ((size_t)(ng * 2 + ni) * (Cin / 32) + kb) * 9 + tap;
-  _Float16* dst = wpack + (step * 3 + t) * (size_t)ns * 512 + lane * 8 + q;
+  _Float16* dst = wpack + (step * ntq + t) * (size_t)ns * 512 + lane * 8 + q;
   const _Float16 hi = (_Float16)v;
   dst[0] = hi;
   if (ns == 2) dst[512] = (_Float16)(v - (float)hi);
@@ -402,7 +412,7 @@ int conv16q_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, i
   }
   const size_t total = (size_t)cout_src * p.C0 * 9;
   hipLaunchKernelGGL(conv16q_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w, (_Float16*)wpack, layout,
-                     cin_src, cout_src, cout_off, p.C0, p.Cout, ns);
+                     cin_src, cout_src, cout_off, p.C0, p.Cout, ns, q_ntq(p.Cout));
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
@@ -413,8 +423,8 @@ int conv16q_plan_tiles(ConvPlan* p, int ns) {
   CSD_REQUIRE(conv16q_supported(*p, ns), "conv16q: unsupported shape (Cin=%d Cout=%d)", p->C0, p->Cout);
   p->KC = C16_KC;
   p->CoutPad = p->Cout;
-  p->NT = 3;
-  p->n_groups = p->Cout / 96;
+  p->NT = q_ntq(p->Cout);
+  p->n_groups = p->Cout / (32 * p->NT);
   p->KCS = 2;
   p->LC = 0;
   const int psb = 32 * 2 * ns + 16;
@@ -461,9 +471,9 @@ int conv16q_plan_tiles(ConvPlan* p, int ns) {
   return CSD_OK;
 }
 
-template <int MQ, int NS, bool MASK, int PWC, int S>
+template <int MQ, int NS, bool MASK, int PWC, int S, int NTQ>
 static int launch_q(const Conv16KArgs& k, size_t lds, hipStream_t s) {
-  auto kern = conv_f16_q_kernel<MQ, NS, MASK, PWC, S>;
+  auto kern = conv_f16_q_kernel<MQ, NS, MASK, PWC, S, NTQ>;
   static bool attr_set = false;
   if (!attr_set) {
     CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -505,26 +515,27 @@ int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) 
   k.nw = 4;
   k.ntiles_n = p.Cout / 32;
   const bool mask = (p.OH % p.TH) != 0;
-#define CSD_Q_CASE(MQ_, NS_)                                                  \
-  if (p.MT == MQ_ && ns == NS_ && p.stride == 1) {                            \
-    if (p.PW <= 24) {                                                         \
-      if (mask) return launch_q<MQ_, NS_, true, 24, 1>(k, p.lds_bytes, s);    \
-      return launch_q<MQ_, NS_, false, 24, 1>(k, p.lds_bytes, s);             \
-    }                                                                         \
-    if (mask) return launch_q<MQ_, NS_, true, 34, 1>(k, p.lds_bytes, s);      \
-    return launch_q<MQ_, NS_, false, 34, 1>(k, p.lds_bytes, s);               \
-  }                                                                           \
-  if (p.MT == MQ_ && ns == NS_ && p.stride == 2) {                            \
-    if (p.PW <= 24) {                                                         \
-      if (mask) return launch_q<MQ_, NS_, true, 24, 2>(k, p.lds_bytes, s);    \
-      return launch_q<MQ_, NS_, false, 24, 2>(k, p.lds_bytes, s);             \
-    }                                                                         \
-    if (mask) return launch_q<MQ_, NS_, true, 34, 2>(k, p.lds_bytes, s);      \
-    return launch_q<MQ_, NS_, false, 34, 2>(k, p.lds_bytes, s);               \
+#define CSD_Q_CASE(MQ_, NS_, NTQ_)                                                  \
+  if (p.MT == MQ_ && ns == NS_ && p.NT == NTQ_ && p.stride == 1) {                  \
+    if (p.PW <= 24) {                                                               \
+      if (mask) return launch_q<MQ_, NS_, true, 24, 1, NTQ_>(k, p.lds_bytes, s);    \
+      return launch_q<MQ_, NS_, false, 24, 1, NTQ_>(k, p.lds_bytes, s);             \
+    }                                                                               \
+    if (mask) return launch_q<MQ_, NS_, true, 34, 1, NTQ_>(k, p.lds_bytes, s);      \
+    return launch_q<MQ_, NS_, false, 34, 1, NTQ_>(k, p.lds_bytes, s);               \
+  }                                                                                 \
+  if (p.MT == MQ_ && ns == NS_ && p.NT == NTQ_ && p.stride == 2) {                  \
+    if (p.PW <= 24) {                                                               \
+      if (mask) return launch_q<MQ_, NS_, true, 24, 2, NTQ_>(k, p.lds_bytes, s);    \
+      return launch_q<MQ_, NS_, false, 24, 2, NTQ_>(k, p.lds_bytes, s);             \
+    }                                                                               \
+    if (mask) return launch_q<MQ_, NS_, true, 34, 2, NTQ_>(k, p.lds_bytes, s);      \
+    return launch_q<MQ_, NS_, false, 34, 2, NTQ_>(k, p.lds_bytes, s);               \
   }
-  CSD_Q_CASE(4, 2) CSD_Q_CASE(2, 2) CSD_Q_CASE(4, 1) CSD_Q_CASE(2, 1)
+  CSD_Q_CASE(4, 2, 3) CSD_Q_CASE(2, 2, 3) CSD_Q_CASE(4, 1, 3) CSD_Q_CASE(2, 1, 3)
+  CSD_Q_CASE(4, 2, 4) CSD_Q_CASE(2, 2, 4) CSD_Q_CASE(4, 1, 4) CSD_Q_CASE(2, 1, 4)
 #undef CSD_Q_CASE
-  set_error("conv16q: no kernel for MQ=%d ns=%d", p.MT, ns);
+  set_error("conv16q: no kernel for MQ=%d ns=%d NT=%d", p.MT, ns, p.NT);
   return CSD_ERR_INVALID;
 }
 

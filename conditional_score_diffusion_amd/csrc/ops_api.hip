@@ -3,6 +3,7 @@
 // runs the same kernels the network executor uses, and writes NCHW.  These exist for per-op parity
 // tests and for callers that use the reference's functional ops directly; the network path never
 // pays these layout changes.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -70,6 +71,14 @@ static int conv_api_plan(ConvPlan* p, int B, int Cin, int Cout, int H, int W, in
 static int ceil32(int c) { return (c + 31) / 32 * 32; }
 static size_t api_packed_floats(const ConvPlan& p, int Cin) {
   size_t n = al64(conv_packed_floats(p)) * 2;
+  {
+    ConvPlan q = p;
+    q.C0 = Cin; q.C1 = 0;
+    if (Cin % 32 == 0 && conv16q_supported(q, 2)) {
+      const size_t m = al64(conv16q_packed_bytes(q, 2) / sizeof(float) + 1);
+      if (m > n) n = m;
+    }
+  }
   if (p.taps == 1) {
     ConvPlan q = p;
     q.C0 = ceil32(Cin);
@@ -100,9 +109,18 @@ static int conv2d_impl(const float* x, const float* weight, const float* bias, f
   int rc = conv_api_plan(&p, B, Cin, Cout, H, W, ksize, stride, pad_mode, up2);
   if (rc) return rc;
   CSD_REQUIRE(!in_nhwc || Cin % 8 == 0, "conv2d: an NHWC input needs Cin %% 8 == 0 (got %d)", Cin);
+  const size_t packed_fl = api_packed_floats(p, Cin);      // (sized from the fp32 plan, exactly as csd_conv_scratch_bytes does)
+  const size_t bias_fl = al64((size_t)p.CoutPad);
   int ns = precision_ns(precision);
-  bool pw = false;
-  if (ns) {   // fp16 MFMA kernel where it applies (3x3 stride 1, Cin padded to 16), else fp32 kernel
+  bool pw = false, quad = false;
+  if (ns && in_nhwc && Cin % 32 == 0 && !getenv("CSD_NO_Q")) {
+    // NHWC source (the training graph): the quad schedule of the sampling path - one split pass writes the fp16 planes into the
+    // scratch region an NCHW source would be transposed into, then conv_f16_q_kernel
+    ConvPlan q = p;
+    q.C0 = Cin; q.C1 = 0;
+    if (conv16q_supported(q, ns) && conv16q_plan_tiles(&q, ns) == CSD_OK) { p = q; quad = true; }
+  }
+  if (ns && !quad) {   // fp16 MFMA kernel where it applies (3x3 stride 1, Cin padded to 16), else fp32 kernel
     ConvPlan q = p;
     q.C0 = ceil16(Cin);
     ConvPlan q1 = p;
@@ -113,12 +131,31 @@ static int conv2d_impl(const float* x, const float* weight, const float* bias, f
   }
   float* f = static_cast<float*>(scratch);
   float* xh = f; f += al64((size_t)B * H * W * ceil32(Cin));
-  float* wp = f; f += api_packed_floats(p, Cin);
-  float* bp = f; f += al64((size_t)p.CoutPad);
+  float* const xh_scratch = xh;
+  float* wp = f; f += packed_fl;
+  float* bp = f; f += bias_fl;
   float* yh = f;
   if (in_nhwc) xh = const_cast<float*>(x);
   else if ((rc = nchw_to_nhwc_launch(x, xh, B, Cin, H * W, p.C0, p.C0, s))) return rc;
   const int wl = (layout & 4) ? 2 : 0;
+  if (quad) {
+    void* hi = xh_scratch;
+    void* lo = ns == 2 ? static_cast<void*>(static_cast<char*>(hi) + (size_t)B * H * W * Cin * 2) : nullptr;
+    if ((rc = gn_apply16_launch(x, nullptr, Cin, 0, nullptr, nullptr, hi, lo, B, H * W, CSD_ACT_NONE, s))) return rc;
+    if ((rc = conv16q_pack_weight(p, ns, weight, wl, Cin, Cout, 0, wp, s))) return rc;
+    if (bias) {
+      CSD_CHECK_HIP(hipMemsetAsync(bp, 0, (size_t)p.CoutPad * sizeof(float), s));
+      CSD_CHECK_HIP(hipMemcpyAsync(bp, bias, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src0 = static_cast<const float*>(hi); a.src1 = static_cast<const float*>(lo); a.wpack = wp; a.bias = bias ? bp : nullptr;
+    a.out = out_nhwc ? y : yh;
+    a.out_stride = Cout; a.out_nchw = 0; a.out_scale = 1.f;
+    if ((rc = conv16q_launch(p, ns, a, s))) return rc;
+    if (out_nhwc) return CSD_OK;
+    return nhwc_to_nchw_launch(yh, y, B, Cout, p.OH * p.OW, Cout, s);
+  }
   rc = pw ? pw16_pack_weight(p, ns, weight, wl ? 1 : 0, Cin, Cout, 0, wp, s)
           : ns ? conv16_pack_weight(p, ns, weight, wl, Cin, Cout, 0, wp, s) : conv_pack_weight(p, weight, wl, Cin, Cout, 0, wp, s);
   if (rc) return rc;

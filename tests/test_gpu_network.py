@@ -288,3 +288,22 @@ def test_use_path_sampler_vs_golden(golden_dir):
     assert rel(info['evolution']['y'].numpy(), g['evo_y']) < 1e-5
     assert np.abs(info['evolution']['x'].numpy() - g['evo_x']).max() / smax < 2e-4
     assert np.abs(out.cpu().numpy() - g['out']).max() / smax < 2e-4
+
+
+@pytest.mark.parametrize('precision,tol', [('fp16x3', 3e-5), ('fp16', 5e-3), ('fp32', 3e-5)])
+def test_nf128_network_vs_oracle(precision, tol):
+    """nf = 128 (the VS-CMDE edges2shoes and NCSN++-256 widths): Cout = 128 / 256 run the quad schedule with four 16-cout
+    tiles per N half (groups of 128 couts) instead of three; odd batch, tiles that straddle samples."""
+    cfg = cases.make_config(name='ddpm_paired', nf=128, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(8,), image_size=16)
+    cfg, nc, p, model = build(cfg, precision)
+    B = 3
+    rs = np.random.RandomState(77)
+    x = torch.from_numpy(rs.uniform(-1, 2, size=(B, 3, 16, 16)).astype(np.float32))
+    y = torch.from_numpy(rs.uniform(0, 1, size=(B, 3, 16, 16)).astype(np.float32))
+    labels = torch.tensor([3.0, 420.5, 998.0])
+    with torch.no_grad():
+        r = model({'x': x.to(dev()), 'y': y.to(dev())}, labels.to(dev()))
+        got = torch.cat([r['x'], r['y']], dim=1).cpu()
+        o = so.paired_forward(p, nc, x, y, labels, sr3=False)
+        ref = torch.cat([o['x'], o['y']], dim=1)
+    assert (got - ref).abs().max().item() <= tol * ref.abs().max().item()

@@ -416,3 +416,29 @@ def test_weight_gradient_ab_schedules_agree(monkeypatch):
     assert rel(wgrad('fp16x3'), base16) < 1e-6          # same arithmetic, different data path
     monkeypatch.setenv('CSD_WGRAD_FP32', '1')
     assert torch.equal(wgrad('fp16x3'), base32)          # forced back to the exact fp32 kernel
+
+
+@pytest.mark.parametrize('precision,tol', [('fp16x3', 1e-5), ('fp16', 3e-3)])
+@pytest.mark.parametrize('B,Cin,Cout,H,stride,up2', [(2, 64, 96, 12, 1, False), (3, 128, 128, 16, 1, False), (2, 32, 128, 8, 2, False),
+                                                     (2, 96, 256, 8, 1, True), (1, 256, 192, 5, 1, False)])
+def test_nhwc_conv_on_the_quad_schedule(B, Cin, Cout, H, stride, up2, precision, tol):
+    """NHWC convolutions with Cin % 32 == 0 and Cout % 96 == 0 or % 128 == 0 in the fp16 modes run the sampling path's quad-wave
+    schedule (split pass + conv_f16_q_kernel, three or four 16-cout tiles per N half) - forward, and the data gradient through
+    the transposed/flipped weight packing of that kernel"""
+    from conditional_score_diffusion_amd import grad_ops_nhwc as G
+    rs = np.random.RandomState(41)
+    to_nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    to_nchw = lambda t: t.permute(0, 3, 1, 2).contiguous()
+    x, w, b = rnd(rs, B, Cin, H, H), rnd(rs, Cout, Cin, 3, 3) * 0.05, rnd(rs, Cout)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    u = F.interpolate(xr, scale_factor=2, mode='nearest') if up2 else xr
+    ref = F.conv2d(F.pad(u, (0, 1, 0, 1)), wr, br, stride=2) if stride == 2 else F.conv2d(u, wr, br, padding=1)
+    dy = rnd(rs, *ref.shape)
+    ref.backward(dy)
+    xd, wd, bd = to_nhwc(x).to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    out = G.conv2d(xd, wd, bd, stride=stride, downsample_pad=stride == 2, up2=up2, precision=precision)
+    assert rel(to_nchw(out), ref) < tol
+    out.backward(to_nhwc(dy).to(dev()))
+    assert rel(to_nchw(xd.grad), xr.grad) < tol
+    assert rel(wd.grad, wr.grad) < max(tol, 5e-5)
+    assert rel(bd.grad, br.grad) < 1e-5
