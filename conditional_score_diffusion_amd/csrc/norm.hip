@@ -123,10 +123,21 @@ __global__ void gn_finalize_tiles_kernel(const double* __restrict__ p0, int tpi0
     const bool s1 = c >= C0;
     const double* p = s1 ? p1 : p0;
     const int Cs = s1 ? C1 : C0, cs = s1 ? c - C0 : c, tpi = s1 ? tpi1 : tpi0;
-    const double* e = p + ((size_t)b * tpi * Cs + cs) * 2;
-    for (int i = ti; i < tpi; i += TL) {
-      s += e[(size_t)i * Cs * 2];
-      q += e[(size_t)i * Cs * 2 + 1];
+    // (sum, sumsq) pairs as one 16-byte load; unrolled so that 8 loads are in flight - the adds keep their order (the kernel was
+    // latency-bound: ~17 us per launch whatever the size, one dependent load per add)
+    const double2* e = reinterpret_cast<const double2*>(p + ((size_t)b * tpi * Cs + cs) * 2);
+    int i = ti;
+    for (; i + 7 * TL < tpi; i += 8 * TL) {
+      double2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = e[(size_t)(i + u * TL) * Cs];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s += v[u].x; q += v[u].y; }
+    }
+    for (; i < tpi; i += TL) {
+      const double2 v = e[(size_t)i * Cs];
+      s += v.x;
+      q += v.y;
     }
   }
   red[0][t] = s;
