@@ -1,5 +1,7 @@
+import os
 import sys
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/oracle')
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'oracle'))
 import torch, cases
 from conditional_score_diffusion_amd import _lib
 from conditional_score_diffusion_amd.models import utils as mutils
