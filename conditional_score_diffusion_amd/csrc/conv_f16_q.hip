@@ -224,8 +224,16 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
       const int bc = tap % BR, bn = (tap + BR - 1) % BR;
       const int r = tap / KS, sx = tap % KS;
       wstep += WSTEP;
+      // The weight stream through L1 / the texture addresser is the binding resource of this loop: a tuning build with a third
+      // of these loads (CSD_Q_ABLATE=1, wrong results) runs the 3x3 class 20 % faster (36.3 -> 28.9 ms per PC step).  Each
+      // fragment is pulled by BOTH waves of an N half.  Tried: 256-pixel tiles (MQ = 8) halve the bytes per MFMA but need 316
+      // registers in the split mode (60 spilled: 66.4 vs 62.1 ms per step); sharing through an LDS ring needs a pair barrier per
+      // tap or 36 KB more LDS per workgroup.
+#ifndef CSD_Q_ABLATE
+#define CSD_Q_ABLATE 0
+#endif
 #pragma unroll
-      for (int t = 0; t < NTQ; ++t)
+      for (int t = 0; t < ((CSD_Q_ABLATE & 1) ? 1 : NTQ); ++t)
 #pragma unroll
         for (int p = 0; p < NS; ++p) wreg[bn][t][p] = gload_h8(wstep + (t * NS + p) * 1024);
 #pragma unroll
