@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 
 import cases
+import score_oracle as so
 from test_gpu_network import build, dev, sdes_for
 from test_oracle_golden import check_grads_vs_fixture, oracle_loss_and_grads
 
@@ -442,3 +443,56 @@ def test_nhwc_conv_on_the_quad_schedule(B, Cin, Cout, H, stride, up2, precision,
     assert rel(to_nchw(xd.grad), xr.grad) < tol
     assert rel(wd.grad, wr.grad) < max(tol, 5e-5)
     assert rel(bd.grad, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize('precision', ['fp16x3', 'fp32'])
+def test_config4_shape_gradients_vs_oracle(precision):
+    """BASELINE configs[3] shape (VS-CMDE edges2shoes: `ddpm_paired`, nf = 128, ch_mult (1,1,2,2), attention at 16 / 8, 64 x 64) at
+    batch 2: the training loss and EVERY parameter gradient of the 28.75 M-parameter network against autograd over the oracle -
+    the path the training bench times (NHWC graph, quad-schedule convolutions with four cout tiles, staged split-bf16 weight
+    gradient on 64 / 32 / 16-wide maps and the two-rows-per-wave form on the 8-wide ones)."""
+    from conditional_score_diffusion_amd import losses
+    cfg = cases.make_config(name='ddpm_paired', nf=128, ch_mult=(1, 1, 2, 2), num_res_blocks=2, attn_resolutions=(16, 8), image_size=64,
+                            sigma_max_y=float(np.sqrt(3 * 64 * 64)))
+    cfg.model.dropout = 0.0
+    cfg, nc, p, model = build(cfg, precision)
+    assert sum(q.numel() for q in model.parameters()) == 28752902
+    sde = sdes_for(cfg)
+    B = 2
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.uniform(0, 1, size=(B, 3, 64, 64)).astype(np.float32))
+    y = torch.from_numpy(rs.uniform(0, 1, size=(B, 3, 64, 64)).astype(np.float32))
+    u = torch.tensor([0.71, 0.18])
+    tape = cases.tape([(B, 3, 64, 64)] * 2, 9)
+    fn = losses.get_general_sde_loss_fn(sde, True, True, True, True, True)
+    it = iter(tape)
+    o_rand, o_like = torch.rand, torch.randn_like
+    torch.rand = lambda *a, **k: u.clone()
+    torch.randn_like = lambda t, **k: next(it).to(t.device)
+    try:
+        loss = fn(model, (y.to(dev()), x.to(dev())))
+    finally:
+        torch.rand, torch.randn_like = o_rand, o_like
+    loss.backward()
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ve_x = so.VE(cfg.model.sigma_min_x, cfg.model.sigma_max_x, cfg.model.num_scales)
+    ve_y = so.VE(cfg.model.sigma_min_y, cfg.model.sigma_max_y, cfg.model.num_scales)
+    t = u * (1 - 1e-5) + 1e-5
+    ref = so.dsm_loss(pr, nc, 'ddpm_paired', ve_x, ve_y, x, y, t, tape[1], tape[0])
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-4 * abs(float(ref.detach()))
+    total = float(np.sqrt(sum(float((v.grad.double() ** 2).sum()) for v in pr.values())))
+    worst = 0.0
+    rows = []
+    for k, q in model.named_parameters():
+        g, r = q.grad.cpu().double(), pr[k].grad.double()
+        scale = max(float(r.abs().max()), float(r.norm()) / np.sqrt(r.numel()))
+        err = float((g - r).abs().max())
+        assert err <= 1e-3 * scale + 1e-6 * total / np.sqrt(r.numel()), (k, err, scale)
+        worst = max(worst, err / max(scale, 1e-30))
+        rows.append((err / max(scale, 1e-30), k, err, scale))
+    # (tensors whose gradient is mathematically zero - the attention key bias NIN_1.b: softmax is invariant to a per-query shift -
+    # hold rounding noise ~1e-11 of the norm; the bound above covers them through its absolute floor)
+    big = [r_ for r_ in rows if r_[3] > 1e-6 * total]
+    assert len(big) > 200 and max(r_[0] for r_ in big) < 1e-3
+    print('config-4 shape, %s: worst relative gradient error over %d tensors %.2e' % (precision, len(big), max(r_[0] for r_ in big)))
