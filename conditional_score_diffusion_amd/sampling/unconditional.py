@@ -3,7 +3,8 @@
 Mirrors ``get_sampling_fn`` (sampling/unconditional.py:13-75) and ``get_pc_sampler`` (:161-228):
 ``pc_sampler(model, show_evolution=False) -> (samples, {'times', 'steps'[, 'evolution']})``.
 ``sampling.method='ode'`` gives the probability-flow ODE sampler (:93-158): scipy's black-box RK45 on the host, every drift
-evaluation = one network evaluation + one HIP axpby.  The inpainter (:230-345) is not on any BASELINE config and is not provided.
+evaluation = one network evaluation + one HIP axpby.  ``get_inpainting_fn`` / ``get_pc_inpainter`` (:78-91, :230-345): the PC loop
+with the known pixels re-imposed after every update (masked blend on csd_axpby / csd_mul).
 """
 import functools
 
@@ -77,6 +78,60 @@ def get_ode_sampler(sde, shape, denoise=False, rtol=1e-5, atol=1e-5, method='RK4
             return x, nfe
 
     return ode_sampler
+
+
+def get_inpainting_fn(config, sde, eps, n_steps_each=1):
+    """sampling/unconditional.py:78-91."""
+    return get_pc_inpainter(sde=sde, predictor=get_predictor(config.sampling.predictor.lower()),
+                            corrector=get_corrector(config.sampling.corrector.lower()), snr=config.sampling.snr,
+                            n_steps=n_steps_each, probability_flow=config.sampling.probability_flow,
+                            continuous=config.training.continuous, denoise=config.sampling.noise_removal, eps=eps)
+
+
+def get_pc_inpainter(sde, predictor, corrector, snr, n_steps=1, probability_flow=False, continuous=False, denoise=True, eps=1e-5):
+    """Image inpainting with an unconditional model (sampling/unconditional.py:230-345):
+    ``pc_inpainter(model, data, mask, show_evolution=False) -> (x, info)``; ``mask`` is 1 on known pixels.  After every
+    corrector / predictor update the known region is replaced by the data perturbed to the current noise level."""
+    from .. import ops
+    from ..losses import _bstd
+
+    pred_fn = functools.partial(shared_predictor_update_fn, sde=sde, predictor=predictor, probability_flow=probability_flow,
+                                continuous=continuous)
+    corr_fn = functools.partial(shared_corrector_update_fn, sde=sde, corrector=corrector, continuous=continuous, snr=snr,
+                                n_steps=n_steps)
+
+    def blend(a, b, mask):
+        """a*(1 - mask) + b*mask = a + (b - a)*mask on the device"""
+        from ..grad_ops import _mul
+        return ops.axpby(a, _mul(ops.axpby(b, a, 1.0, -1.0), mask))
+
+    def inpaint_update(update_fn, model, data, mask, x, t):
+        vec_t = torch.ones(data.shape[0], device=data.device) * t
+        x, x_mean = update_fn(x, vec_t, model=model)
+        m, std = _bstd(sde, data, vec_t)                       # mean scale / std of p_t(x | data): [B] host scalars
+        mean = data if bool(torch.all(m == 1)) else ops.scale_rows(data, m.to(data.device))
+        masked = ops.axpby(mean, ops.scale_rows(torch.randn_like(x), std.to(data.device)))
+        x = blend(x, masked, mask)
+        x_mean = blend(x, mean, mask)
+        return x, x_mean
+
+    def pc_inpainter(model, data, mask, show_evolution=False):
+        with torch.no_grad():
+            data, mask = data.contiguous().float(), mask.contiguous().float()
+            x = blend(sde.prior_sampling(data.shape).to(data.device), data, mask)
+            evolution = [x.cpu()] if show_evolution else None
+            timesteps = torch.linspace(sde.T, eps, sde.N)
+            x_mean = x
+            for i in range(sde.N):
+                t = timesteps[i]
+                x, x_mean = inpaint_update(corr_fn, model, data, mask, x, t)
+                x, x_mean = inpaint_update(pred_fn, model, data, mask, x, t)
+                if show_evolution:
+                    evolution.append(x.cpu())
+            info = {'evolution': torch.stack(evolution)} if show_evolution else {}
+            return (x_mean if denoise else x), info
+
+    return pc_inpainter
 
 
 def shared_predictor_update_fn(x, t, sde, model, predictor, probability_flow, continuous):

@@ -177,3 +177,15 @@ def grad_sample_index(name, numel, n=48):
     import zlib
     rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7fffffff)
     return np.sort(rs.choice(numel, size=min(n, numel), replace=False))
+
+
+def inpaint_case():
+    """inputs of the inpainting fixture: tiny unconditional net, VESDE with N = 12 steps, a half-image mask"""
+    cfg, B = case_config('uncond_tiny')
+    S = cfg.data.image_size
+    rs = np.random.RandomState(77)
+    data = torch.from_numpy(rs.uniform(0, 1, size=(B, 3, S, S)).astype(np.float32))
+    mask = torch.zeros(B, 3, S, S)
+    mask[:, :, :, : S // 2] = 1.
+    shape = (B, 3, S, S)
+    return cfg, B, data, mask, tape([shape] * (1 + 4 * 12), 23)

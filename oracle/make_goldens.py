@@ -350,6 +350,21 @@ def gen_ode(ref):
     np.savez_compressed(os.path.join(OUT, 'ode.npz'), x=x.numpy(), nfe=np.int64(nfe))
 
 
+def gen_inpaint(ref):
+    """get_pc_inpainter of the reference (sampling/unconditional.py:230-345) on the tiny unconditional case -> tests/golden/inpaint.npz"""
+    cfg, B, data, mask, tape = cases.inpaint_case()
+    model, _ = build_ref_model(ref, cfg)
+    model.embedding_type = 'positional'
+    sde = ref['sde_lib'].VESDE(cfg.model.sigma_min_x, cfg.model.sigma_max_x, 12)
+    P, C = ref['sampling.predictors'], ref['sampling.correctors']
+    fn = ref['sampling.unconditional'].get_pc_inpainter(sde, P.get_predictor('reverse_diffusion'), C.get_corrector('langevin'), snr=0.15,
+                                                      n_steps=1, probability_flow=False, continuous=True, denoise=True, eps=1e-5)
+    with ref_import.TapeRandn(tape):
+        x, _ = fn(model, data, mask)
+    print('inpaint: max |x|', float(x.abs().max()), 'known region err', float(((x - data) * mask).abs().max()))
+    np.savez_compressed(os.path.join(OUT, 'inpaint.npz'), x=x.numpy())
+
+
 def gen_ncsnpp(ref):
     """Reference NCSN++ forward (models/ncsnpp.py) on the seeded cases of cases.NCSNPP_CASES -> tests/golden/ncsnpp.npz:
     state_dict key order + shapes (as a string table) and the network output."""
@@ -383,6 +398,7 @@ def main():
         return
     gen_grads(ref)
     gen_ode(ref)
+    gen_inpaint(ref)
     gen_sde_tables(ref)
     gen_modules(ref)
     gen_steps(ref)

@@ -675,3 +675,24 @@ def pf_ode_sample(score_fn, ve, shape, z, eps=1e-5, rtol=1e-5, atol=1e-5, denois
         vt = torch.ones(shape[0]) * eps
         x = x + _b(ve.G(vt)) ** 2 * score_fn(x, vt)
     return x, sol.nfev
+
+
+def pc_inpaint_unconditional(score_fn, data, mask, noise, ve, snr=0.15, eps=1e-5, denoise=True):
+    """get_pc_inpainter (sampling/unconditional.py:230-345) for a VE SDE with the (reverse diffusion, Langevin) pair: N = ve.N steps;
+    after each update x = x(1 - mask) + (data + sigma(t) z) mask, x_mean = x(1 - mask) + data mask.  ``noise(like)`` serves the
+    draws in the reference's order: prior; per step corrector z, blend z, predictor z, blend z."""
+    x = data * mask + noise(data) * ve.sigma_max * (1. - mask)
+    timesteps = torch.linspace(ve.T, eps, ve.N)
+    x_mean = x
+    for i in range(ve.N):
+        vec_t = torch.ones(data.shape[0]) * timesteps[i]
+        for upd in ('c', 'p'):
+            s = score_fn(x, vec_t)
+            if upd == 'c':
+                x, x_mean = langevin_update(s, x, noise(x), snr)
+            else:
+                x, x_mean = reverse_diffusion_update(s, x, noise(x), ve.G(vec_t))
+            masked = data + noise(x) * _b(ve.std(vec_t))
+            x = x * (1. - mask) + masked * mask
+            x_mean = x * (1. - mask) + data * mask
+    return x_mean if denoise else x

@@ -148,3 +148,30 @@ def test_probability_flow_ode_sampler_vs_reference(golden_dir):
     ref = g['x']
     assert abs(nfe - int(g['nfe'])) <= 6
     assert np.abs(x.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max()
+
+
+def test_pc_inpainter_vs_reference(golden_dir):
+    """get_pc_inpainter (sampling/unconditional.py:230-345) on the HIP kernels against the reference's 12-step run with a noise tape:
+    the known half of the image is returned exactly, the inpainted half within the trajectory tolerance."""
+    import cases
+    from conditional_score_diffusion_amd import sde_lib
+    from conditional_score_diffusion_amd.sampling import correctors, predictors, unconditional
+    from test_gpu_network import build, dev
+    g = np.load(os.path.join(golden_dir, 'inpaint.npz'))
+    cfg, B, data, mask, tape = cases.inpaint_case()
+    cfg, nc, p, model = build(cfg)
+    sde = sde_lib.VESDE(cfg.model.sigma_min_x, cfg.model.sigma_max_x, 12)
+    fn = unconditional.get_pc_inpainter(sde, predictors.get_predictor('reverse_diffusion'), correctors.get_corrector('langevin'),
+                                        snr=0.15, n_steps=1, probability_flow=False, continuous=True, denoise=True, eps=1e-5)
+    it = iter(tape)
+    o_randn, o_like = torch.randn, torch.randn_like
+    torch.randn = lambda *s, **k: next(it)
+    torch.randn_like = lambda t, **k: next(it).to(t.device)
+    try:
+        x, info = fn(model, data.to(dev()), mask.to(dev()))
+    finally:
+        torch.randn, torch.randn_like = o_randn, o_like
+    ref = g['x']
+    x = x.cpu()
+    assert float(((x - data) * mask).abs().max()) == 0.0
+    assert np.abs(x.numpy() - ref).max() <= 2e-4 * float(cfg.model.sigma_max_x)

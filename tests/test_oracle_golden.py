@@ -208,3 +208,21 @@ def test_probability_flow_ode_sampler(golden_dir):
     x, nfe = so.pf_ode_sample(score_fn, ve, shape, z)
     assert abs(nfe - int(g['nfe'])) <= 6
     assert rel(x.numpy(), g['x']) < 1e-3
+
+
+def test_pc_inpainter(golden_dir):
+    """sampling/unconditional.py:230-345: the oracle's inpainting loop reproduces the reference's 12-step run (noise tape)."""
+    g = load(golden_dir, 'inpaint')
+    cfg, B, data, mask, tape = cases.inpaint_case()
+    nc = so.NetCfg.from_config(cfg)
+    p = so.synth_params(so.ddpm_param_shapes(nc), 0)
+    ve = so.VE(cfg.model.sigma_min_x, cfg.model.sigma_max_x, 12)
+
+    def score_fn(x, t):
+        with torch.no_grad():
+            std = ve.std(t)
+            return so.ddpm_forward(p, nc, x, std) / std[:, None, None, None]
+
+    x = so.pc_inpaint_unconditional(score_fn, data, mask, so.NoiseTape(tape), ve, snr=0.15, eps=1e-5, denoise=True)
+    assert rel(x.numpy(), g['x']) < 2e-4
+    assert float(((x - data) * mask).abs().max()) == 0.0
