@@ -16,6 +16,7 @@ import torch
 
 from . import grad_ops, ops, sde_lib
 from .models import utils as mutils
+from .optim import get_optimizer, optimization_manager  # noqa: F401  (losses.py:26-53: same names, same module as the reference)
 
 
 def _bstd(sde, ref, t):
@@ -117,3 +118,117 @@ def get_general_sde_loss_fn(sde, train, conditional=False, reduce_mean=True, con
         return losses.mean().float()
 
     return loss_fn
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# discrete-time ("legacy") objectives and the one-step function - losses.py:236-407
+# ------------------------------------------------------------------------------------------------------------------
+def _diff_sumsq(a, b):
+    """per-sample sum of squares of (a - b): differentiable in ``a`` when it carries a graph"""
+    if a.requires_grad:
+        return grad_ops.sumsq_rows(grad_ops.axpby(a, b, 1.0, -1.0))
+    n = ops.row_norms(ops.axpby(a, b, 1.0, -1.0)).cpu().double()
+    return n * n
+
+
+def get_smld_loss_fn(vesde, train, reduce_mean=False, likelihood_weighting=False):
+    """losses.py:236-265 (SMLD / NCSN objective on the discrete sigma ladder).  (score + z/sigma)^2 sigma^2 = (score sigma + z)^2:
+    both weightings of the reference reduce to the same per-sample value."""
+    assert isinstance(vesde, sde_lib.VESDE), "SMLD training only works for VESDEs."
+
+    def loss_fn(model, batch):
+        score_fn = mutils.get_score_fn(vesde, model, train=train)
+        labels = torch.randint(0, vesde.N, (batch.shape[0],))
+        sigmas = vesde.discrete_sigmas[labels].float()
+        z = torch.randn_like(batch)
+        perturbed = ops.axpby(batch, ops.scale_rows(z, sigmas.to(batch.device)))
+        score = score_fn(perturbed, (labels / (vesde.N - 1)).to(batch.device))
+        losses = _reduce(_residual_sumsq(score, z, sigmas, False), batch[0].numel(), reduce_mean)
+        return losses.mean().float()
+
+    return loss_fn
+
+
+def get_inverse_problem_smld_loss_fn(sde, train, reduce_mean=False, likelihood_weighting=True):
+    """losses.py:267-318: SMLD objective for the {'x', 'y'} pair of VE SDEs on a shared label."""
+    def loss_fn(model, batch):
+        y, x = batch
+        score_fn = mutils.get_score_fn(sde, model, train=train)
+        labels = torch.randint(0, sde['x'].N, (x.shape[0],))
+        sig_y, sig_x = sde['y'].discrete_sigmas[labels].float(), sde['x'].discrete_sigmas[labels].float()
+        z_y = torch.randn_like(y)
+        z_x = torch.randn_like(x)
+        pert = {'x': ops.axpby(x, ops.scale_rows(z_x, sig_x.to(x.device))), 'y': ops.axpby(y, ops.scale_rows(z_y, sig_y.to(y.device)))}
+        score = score_fn(pert, (labels / (sde['x'].N - 1)).to(x.device))
+        numel = x[0].numel() + y[0].numel()
+        if likelihood_weighting:      # (s + z/sigma)^2 sigma^2 per domain, concatenated, reduced
+            sx = _residual_sumsq(score['x'].contiguous(), z_x, sig_x, False)
+            sy = _residual_sumsq(score['y'].contiguous(), z_y, sig_y, False)
+            return _reduce(sx + sy, numel, reduce_mean).mean().float()
+        sx = _residual_sumsq(score['x'].contiguous(), z_x, sig_x, True)      # (s + z/sigma)^2
+        sy = _residual_sumsq(score['y'].contiguous(), z_y, sig_y, True)
+        w = (sig_x.double() ** 2 * sig_y.double() ** 2) / (sig_x.double() ** 2 + sig_y.double() ** 2)
+        tot = sx + sy
+        return (_reduce(tot, numel, reduce_mean) * w.to(tot)).mean().float()
+
+    return loss_fn
+
+
+def get_ddpm_loss_fn(vpsde, train, reduce_mean=True):
+    """losses.py:320-340 (DDPM noise-prediction objective)."""
+    assert isinstance(vpsde, sde_lib.VPSDE), "DDPM training only works for VPSDEs."
+
+    def loss_fn(model, batch):
+        model_fn = mutils.get_model_fn(model, train=train)
+        labels = torch.randint(0, vpsde.N, (batch.shape[0],))
+        a = vpsde.sqrt_alphas_cumprod[labels].float()
+        b = vpsde.sqrt_1m_alphas_cumprod[labels].float()
+        z = torch.randn_like(batch)
+        perturbed = ops.axpby(ops.scale_rows(batch, a.to(batch.device)), ops.scale_rows(z, b.to(batch.device)))
+        out = model_fn(perturbed, labels.to(batch.device))
+        return _reduce(_diff_sumsq(out, z), batch[0].numel(), reduce_mean).mean().float()
+
+    return loss_fn
+
+
+def get_inverse_problem_ddpm_loss_fn(vpsdes, train, reduce_mean=True):
+    """losses.py:342-343: not implemented upstream either (the reference returns the NotImplementedError class)."""
+    raise NotImplementedError('discrete DDPM training of inverse problems is not implemented in the reference')
+
+
+def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True, likelihood_weighting=False):
+    """losses.py:345-407: ``step_fn(state, batch) -> loss`` with state = {'model', 'optimizer', 'ema', 'step'}."""
+    if continuous:
+        loss_fn = get_sde_loss_fn(sde, train, reduce_mean=reduce_mean, continuous=True, likelihood_weighting=likelihood_weighting)
+    elif isinstance(sde, dict):
+        if isinstance(sde['y'], sde_lib.VESDE) and isinstance(sde['x'], sde_lib.cVESDE) and len(sde) == 2:
+            loss_fn = get_inverse_problem_smld_loss_fn(sde, train, reduce_mean=reduce_mean, likelihood_weighting=likelihood_weighting)
+        else:
+            raise NotImplementedError('This combination of sdes is not supported for discrete training yet.')
+    elif isinstance(sde, sde_lib.VESDE):
+        loss_fn = get_smld_loss_fn(sde, train, reduce_mean=reduce_mean)
+    elif isinstance(sde, sde_lib.VPSDE):
+        loss_fn = get_ddpm_loss_fn(sde, train, reduce_mean=reduce_mean)
+    else:
+        raise ValueError(f"Discrete training for {sde.__class__.__name__} is not recommended.")
+
+    def step_fn(state, batch):
+        model = state['model']
+        if train:
+            optimizer = state['optimizer']
+            optimizer.zero_grad()
+            loss = loss_fn(model, batch)
+            loss.backward()
+            optimize_fn(optimizer, model.parameters(), step=state['step'])
+            state['step'] += 1
+            state['ema'].update(model.parameters())
+        else:
+            with torch.no_grad():
+                ema = state['ema']
+                ema.store(model.parameters())
+                ema.copy_to(model.parameters())
+                loss = loss_fn(model, batch)
+                ema.restore(model.parameters())
+        return loss
+
+    return step_fn

@@ -365,6 +365,35 @@ def gen_inpaint(ref):
     np.savez_compressed(os.path.join(OUT, 'inpaint.npz'), x=x.numpy())
 
 
+def gen_legacy_losses(ref):
+    """The discrete-time objectives (losses.py:236-265 SMLD, :320-340 DDPM) of the reference on the tiny unconditional net with fixed
+    labels and noise -> tests/golden/legacy_losses.npz"""
+    L, S = ref['losses'], ref['sde_lib']
+    cfg, B = cases.case_config('uncond_tiny')
+    model, _ = build_ref_model(ref, cfg)
+    model.embedding_type = 'positional'
+    rs = np.random.RandomState(11)
+    xs = (B,) + tuple(cfg.data.shape_x)
+    x = torch.from_numpy(rs.uniform(0, 1, size=xs).astype(np.float32))
+    labels = torch.tensor([700, 123][:B])
+    out = {}
+    orig = torch.randint
+    torch.randint = lambda *a, **k: labels.clone()
+    try:
+        for rm in (True, False):
+            for lw in (True, False):
+                fn = L.get_smld_loss_fn(S.VESDE(cfg.model.sigma_min_x, cfg.model.sigma_max_x, cfg.model.num_scales), False, rm, lw)
+                with ref_import.TapeRandn(cases.tape([xs], 3)), torch.no_grad():
+                    out['smld_rm%d_lw%d' % (rm, lw)] = np.float64(fn(model, x).item())
+            fn = L.get_ddpm_loss_fn(S.VPSDE(0.1, 20., cfg.model.num_scales), False, rm)
+            with ref_import.TapeRandn(cases.tape([xs], 3)), torch.no_grad():
+                out['ddpm_rm%d' % rm] = np.float64(fn(model, x).item())
+    finally:
+        torch.randint = orig
+    print(out)
+    np.savez_compressed(os.path.join(OUT, 'legacy_losses.npz'), **out)
+
+
 def gen_ncsnpp(ref):
     """Reference NCSN++ forward (models/ncsnpp.py) on the seeded cases of cases.NCSNPP_CASES -> tests/golden/ncsnpp.npz:
     state_dict key order + shapes (as a string table) and the network output."""
@@ -399,6 +428,7 @@ def main():
     gen_grads(ref)
     gen_ode(ref)
     gen_inpaint(ref)
+    gen_legacy_losses(ref)
     gen_sde_tables(ref)
     gen_modules(ref)
     gen_steps(ref)
