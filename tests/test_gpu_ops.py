@@ -218,3 +218,39 @@ def test_upfirdn2d_backward_matches_autograd_of_native(up, down, pad, hw):
     v = rnd(*x.shape, seed=7)
     gg, = torch.autograd.grad(gi, go_d, v.to(dev()))
     assert rel(gg, _upfirdn2d_native(v, kern, up, down, pad)) < 1e-6
+
+
+@pytest.mark.gpu
+def test_op_package_fused_leaky_relu_forward_backward_double_backward():
+    """conditional_score_diffusion_amd.op (the reference's op/ package: upfirdn2d, fused_leaky_relu, FusedLeakyReLU): forward, the
+    gradients w.r.t. input and bias, and the double backward, against torch autograd of lrelu(x + b) * scale."""
+    from conditional_score_diffusion_amd import op
+    dev = torch.device('cuda:0')
+    rs = np.random.RandomState(19)
+    x = torch.from_numpy(rs.standard_normal((3, 8, 5, 6)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(8).astype(np.float32))
+    g = torch.from_numpy(rs.standard_normal((3, 8, 5, 6)).astype(np.float32))
+    xr, br = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.leaky_relu(xr + br.view(1, -1, 1, 1), 0.1) * 1.7
+    gx, gb = torch.autograd.grad(ref, (xr, br), g, create_graph=True)
+    (gx * g).sum().backward()                                   # d/d(g)... second-order path w.r.t. nothing here; checks create_graph works
+    xd, bd = x.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    out = op.fused_leaky_relu(xd, bd, negative_slope=0.1, scale=1.7)
+    assert (out.cpu() - ref.detach()).abs().max() < 1e-6
+    gd = g.to(dev).requires_grad_(True)
+    hx, hb = torch.autograd.grad(out, (xd, bd), gd, create_graph=True)
+    assert (hx.cpu() - gx.detach()).abs().max() < 1e-6
+    assert (hb.cpu() - gb.detach()).abs().max() < 1e-4
+    # double backward: the input gradient is linear in grad_output, its derivative w.r.t. grad_output applied to a vector v
+    v = torch.from_numpy(rs.standard_normal((3, 8, 5, 6)).astype(np.float32))
+    (hx * v.to(dev)).sum().backward()
+    gr = g.clone().requires_grad_(True)
+    xr2 = x.clone()
+    ref_gx = torch.autograd.grad(torch.nn.functional.leaky_relu(xr2.requires_grad_(True) + b.view(1, -1, 1, 1), 0.1) * 1.7, xr2, gr,
+                                 create_graph=True)[0]
+    (ref_gx * v).sum().backward()
+    assert (gd.grad.cpu() - gr.grad).abs().max() < 1e-6
+    mod = op.FusedLeakyReLU(8).to(dev)
+    assert mod(xd.detach()).shape == x.shape
+    k = torch.tensor([[1., 3., 3., 1.]]).T @ torch.tensor([[1., 3., 3., 1.]]) / 64
+    assert op.upfirdn2d(xd.detach(), k.to(dev), up=2, pad=(2, 1)).shape == (3, 8, 10, 12)
