@@ -110,7 +110,7 @@ def optimization_manager(config):
                     ema=None):
         if warmup > 0:
             for g in optimizer.param_groups:
-                g['lr'] = lr * np.minimum(step / warmup, 1.0)
+                g['lr'] = float(lr * np.minimum(step / warmup, 1.0))
         optimizer.max_norm = float(grad_clip)
         optimizer.step(ema=ema)
 

@@ -43,6 +43,27 @@ class Trainer:
         self.step += 1
         return loss.detach()
 
+    # -- checkpoint / resume (Lightning keeps the same pieces in its .ckpt: state_dict, optimizer_states, the EMA callback state) --
+    def state_dict(self):
+        return {'model': {k: v.detach().clone() for k, v in self.model.state_dict().items()},
+                'optimizer': {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.optimizer.state_dict().items()},
+                'ema': {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.ema.state_dict().items()},
+                'step': self.step, 'train_calls': getattr(self.model, '_train_calls', 0)}
+
+    def load_state_dict(self, sd):
+        """Resume: parameters, Adam moments, EMA shadow, step counter and the dropout stream position - the next train_step is
+        bit-identical to the one the saved run would have taken."""
+        from . import _lib
+        with torch.no_grad():
+            for k, v in self.model.state_dict().items():
+                v.copy_(sd['model'][k])                       # (in place: the parameters stay views of the flat buffer)
+        _lib.WEIGHT_EPOCH[0] += 1
+        self.optimizer.load_state_dict(sd['optimizer'])
+        self.ema.load_state_dict(sd['ema'])
+        self.step = int(sd['step'])
+        if hasattr(self.model, '_train_calls'):
+            self.model._train_calls = int(sd['train_calls'])
+
     @torch.no_grad()
     def eval_loss(self, batch, use_ema=False):
         if use_ema:

@@ -496,3 +496,34 @@ def test_config4_shape_gradients_vs_oracle(precision):
     big = [r_ for r_ in rows if r_[3] > 1e-6 * total]
     assert len(big) > 200 and max(r_[0] for r_ in big) < 1e-3
     print('config-4 shape, %s: worst relative gradient error over %d tensors %.2e' % (precision, len(big), max(r_[0] for r_ in big)))
+
+
+def test_trainer_checkpoint_resume_is_bit_exact(tmp_path):
+    """train 2 steps, save (torch.save of Trainer.state_dict()), train 2 more; a fresh model + Trainer restored from the file takes
+    the same 2 steps: identical losses and identical parameters / EMA (dropout 0.1 on: the Philox stream position is part of the state)."""
+    from conditional_score_diffusion_amd import train
+    cfg, B, x, y, u, tape = cases.grad_case('sr3_tiny')
+    cfg.model.dropout = 0.1
+    cfg.optim.warmup = 2
+    batch = (y.to(dev()), x.to(dev()))
+
+    def steps(tr, n):
+        out = []
+        for _ in range(n):
+            torch.manual_seed(len(out) + tr.step)          # (t and the noise of the loss come from torch's generator)
+            out.append(float(tr.train_step(batch)))
+        return out
+
+    _, _, _, model = build(cfg)
+    tr = train.Trainer(cfg, model, sdes_for(cfg))
+    steps(tr, 2)
+    path = os.path.join(str(tmp_path), 'trainer.pt')
+    torch.save(tr.state_dict(), path)
+    cont = steps(tr, 2)
+    _, _, _, model2 = build(cfg)
+    tr2 = train.Trainer(cfg, model2, sdes_for(cfg))
+    tr2.load_state_dict(torch.load(path))
+    res = steps(tr2, 2)
+    assert res == cont
+    assert torch.equal(tr2.flat.data, tr.flat.data) and torch.equal(tr2.ema.shadow, tr.ema.shadow)
+    assert tr2.step == tr.step == 4 and tr2.optimizer.num_steps == 4
