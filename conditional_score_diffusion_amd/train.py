@@ -15,15 +15,27 @@ from . import losses, optim
 from .distributed import GradSync
 
 
+def get_reduction_fn(y0, xk, yk):
+    """lightning_callbacks/callbacks.py:81-86: starts at y0 and reaches yk after xk steps at an inverse multiplicative rate."""
+    def f(x):
+        return xk * yk * y0 / (x * (y0 - yk) + xk * yk)
+    return f
+
+
 class Trainer:
     def __init__(self, config, model, sde, group=None, bucket_bytes=32 << 20):
         self.config, self.model, self.sde = config, model, sde
-        t = config.training
-        conditional = isinstance(sde, dict) or model.__class__.__name__ != 'DDPM' and getattr(model, 'y_channels', 0) > 0
-        self.loss_fn = losses.get_general_sde_loss_fn(sde, True, conditional=conditional, reduce_mean=t.reduce_mean,
-                                                      continuous=t.continuous, likelihood_weighting=t.likelihood_weighting)
-        self.eval_loss_fn = losses.get_general_sde_loss_fn(sde, False, conditional=conditional, reduce_mean=t.reduce_mean,
-                                                           continuous=t.continuous, likelihood_weighting=t.likelihood_weighting)
+        # VS-CMDE (DecreasingVarianceConfigurationSetterCallback, lightning_callbacks/callbacks.py:23-78): the conditioning SDE's
+        # sigma_max_y / sigma_min_y shrink with the global step; the SDE object of 'y' is rebuilt before every training batch
+        m = config.model
+        has = (lambda k: k in m) if hasattr(m, '__contains__') else (lambda k: hasattr(m, k))
+        self._vs = None
+        if isinstance(sde, dict) and has('reach_target_steps') and has('sigma_max_y_target'):
+            self._vs = (get_reduction_fn(m.sigma_max_y, m.reach_target_steps, m.sigma_max_y_target),
+                        get_reduction_fn(m.sigma_min_y, m.reach_target_steps, m.sigma_min_y_target if has('sigma_min_y_target') else m.sigma_min_y))
+        self.sigma_max_y = float(m.sigma_max_y) if has('sigma_max_y') else None
+        self.sigma_min_y = float(m.sigma_min_y) if has('sigma_min_y') else None
+        self._build_loss_fns()
         self.flat = optim.FlatParams(model.parameters())
         self.optimizer = optim.get_optimizer(config, self.flat)
         self.optimize_fn = optim.optimization_manager(config)
@@ -31,8 +43,26 @@ class Trainer:
         self.sync = GradSync(self.flat, group, bucket_bytes)
         self.step = 0                     # completed optimizer steps (the warm-up factor of step k is k / warmup)
 
+    def _build_loss_fns(self):
+        config, model, sde = self.config, self.model, self.sde
+        t = config.training
+        conditional = isinstance(sde, dict) or model.__class__.__name__ != 'DDPM' and getattr(model, 'y_channels', 0) > 0
+        self.loss_fn = losses.get_general_sde_loss_fn(sde, True, conditional=conditional, reduce_mean=t.reduce_mean,
+                                                      continuous=t.continuous, likelihood_weighting=t.likelihood_weighting)
+        self.eval_loss_fn = losses.get_general_sde_loss_fn(sde, False, conditional=conditional, reduce_mean=t.reduce_mean,
+                                                           continuous=t.continuous, likelihood_weighting=t.likelihood_weighting)
+
+    def reconfigure_conditioning_sde(self):
+        """callbacks.py:44-56 + ConditionalSdeGenerativeModel.reconfigure_conditioning_sde (:179-195): sde['y'] at the current step"""
+        from . import sde_lib
+        self.sigma_max_y, self.sigma_min_y = float(self._vs[0](self.step)), float(self._vs[1](self.step))
+        self.sde['y'] = sde_lib.VESDE(sigma_min=self.sigma_min_y, sigma_max=self.sigma_max_y, N=self.config.model.num_scales)
+        self._build_loss_fns()
+
     def train_step(self, batch):
         """-> detached loss of this rank's shard.  ``batch`` is the loss_fn's: ``x`` or ``(y, x)``."""
+        if self._vs is not None:
+            self.reconfigure_conditioning_sde()
         self.optimizer.zero_grad()
         loss = self.loss_fn(self.model, batch)
         self.sync.scale_loss(loss).backward()
@@ -48,7 +78,8 @@ class Trainer:
         return {'model': {k: v.detach().clone() for k, v in self.model.state_dict().items()},
                 'optimizer': {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.optimizer.state_dict().items()},
                 'ema': {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.ema.state_dict().items()},
-                'step': self.step, 'train_calls': getattr(self.model, '_train_calls', 0)}
+                'step': self.step, 'train_calls': getattr(self.model, '_train_calls', 0),
+                'sigma_max_y': self.sigma_max_y, 'sigma_min_y': self.sigma_min_y}     # (the buffers the Lightning module registers)
 
     def load_state_dict(self, sd):
         """Resume: parameters, Adam moments, EMA shadow, step counter and the dropout stream position - the next train_step is

@@ -527,3 +527,25 @@ def test_trainer_checkpoint_resume_is_bit_exact(tmp_path):
     assert res == cont
     assert torch.equal(tr2.flat.data, tr.flat.data) and torch.equal(tr2.ema.shadow, tr.ema.shadow)
     assert tr2.step == tr.step == 4 and tr2.optimizer.num_steps == 4
+
+
+def test_vs_cmde_trainer_shrinks_the_conditioning_sde():
+    """VS-CMDE: with `reach_target_steps` / `sigma_max_y_target` in the config the Trainer rebuilds sde['y'] before every batch with the
+    scheduled sigma_max_y (DecreasingVarianceConfigurationSetterCallback, lightning_callbacks/callbacks.py:23-78)."""
+    from conditional_score_diffusion_amd import train
+    cfg, B, x, y, u, tape = cases.grad_case('cmde_tiny')
+    cfg.model.sigma_max_y = float(np.sqrt(3 * 20 * 20))
+    cfg.model.reach_target_steps = 4
+    cfg.model.sigma_max_y_target = 1.0
+    cfg.model.sigma_min_y_target = cfg.model.sigma_min_y
+    cfg, nc, p, model = build(cfg)
+    tr = train.Trainer(cfg, model, sdes_for(cfg))
+    batch = (y.to(dev()), x.to(dev()))
+    seen = []
+    for _ in range(5):
+        loss = tr.train_step(batch)
+        assert torch.isfinite(loss)
+        seen.append(tr.sde['y'].sigma_max)
+    f = train.get_reduction_fn(cfg.model.sigma_max_y, 4, 1.0)
+    assert np.allclose(seen, [f(k) for k in range(5)]) and abs(seen[-1] - 1.0) < 1e-9
+    assert tr.state_dict()['sigma_max_y'] == seen[-1]

@@ -211,3 +211,14 @@ def test_lightning_checkpoint_reader(tmp_path):
         assert torch.equal(a + 0.01, b), k
     with pytest.raises(KeyError):
         checkpoint.split_lightning_state_dict({'state_dict': {'other.weight': torch.zeros(1)}})
+
+
+def test_vs_cmde_variance_schedule():
+    """get_reduction_fn (lightning_callbacks/callbacks.py:81-86): starts at y0, reaches yk at xk steps, inverse multiplicative in between -
+    the edges2shoes values (configs/.../edges2shoes_ours_DV.py:101-104)."""
+    from conditional_score_diffusion_amd.train import get_reduction_fn
+    y0, xk, yk = float(np.sqrt(3 * 64 * 64)), 300000, 1.0
+    f = get_reduction_fn(y0, xk, yk)
+    assert abs(f(0) - y0) < 1e-9 and abs(f(xk) - yk) < 1e-9
+    assert f(1000) > f(2000) > f(100000) > yk
+    assert abs(f(150000) - xk * yk * y0 / (150000 * (y0 - yk) + xk * yk)) < 1e-12

@@ -34,6 +34,7 @@ def make_config(precision):
                          dropout=0.1, resamp_with_conv=True, conditional=True, nonlinearity='swish', num_scales=1000,
                          sigma_min_x=5e-3, sigma_max_x=smax, sigma_min_y=5e-3, sigma_max_y=smax, input_channels=6,
                          output_channels=6, embedding_type='positional', scale_by_sigma=True, ema_rate=0.999,
+                         reach_target_steps=300000, sigma_max_y_target=1.0, sigma_min_y_target=5e-3,     # VS-CMDE schedule (edges2shoes_ours_DV.py:101-107)
                          csd_precision=precision)
     c.optim = ConfigDict(weight_decay=0, optimizer='Adam', lr=2e-4, beta1=0.9, eps=1e-8, warmup=2500, grad_clip=1)
     c.seed = 42
