@@ -39,11 +39,53 @@ ALG_WEIGHT_BYTES_PER_NFE = 173.9e6
 def sr3_160_config():
     """The values of configs/ve/inverse_problems/super_resolution/celebA_SR3_160.py that the hot
     path reads (SURVEY.md section 5 'Config / flags')."""
-    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import cases
-    return cases.make_config(name='ddpm_paired_SR3', nf=96, ch_mult=(1, 1, 2, 2, 3, 3), num_res_blocks=2,
-                             attn_resolutions=(20, 10, 5), image_size=160, x_ch=3, y_ch=3, num_scales=1000,
-                             sigma_min_x=5e-3, sigma_max_x=float(np.sqrt(3 * 160 * 160)), snr=0.15)
+    from conditional_score_diffusion_amd.config_dict import ConfigDict
+    S = 160
+    c = ConfigDict()
+    c.training = ConfigDict(continuous=True, sde='vesde', likelihood_weighting=True, reduce_mean=True, conditioning_approach='sr3')
+    c.sampling = ConfigDict(method='pc', predictor='conditional_reverse_diffusion', corrector='conditional_langevin',
+                            n_steps_each=1, noise_removal=True, probability_flow=False, snr=0.15)
+    c.data = ConfigDict(image_size=S, effective_image_size=S, centered=False, shape_x=[3, S, S], shape_y=[3, S, S], num_channels=6)
+    smax = float(np.sqrt(3 * S * S))
+    c.model = ConfigDict(name='ddpm_paired_SR3', nf=96, ch_mult=(1, 1, 2, 2, 3, 3), num_res_blocks=2, attn_resolutions=(20, 10, 5),
+                         dropout=0.1, resamp_with_conv=True, conditional=True, nonlinearity='swish', num_scales=1000,
+                         sigma_min_x=5e-3, sigma_max_x=smax, sigma_min_y=5e-3, sigma_max_y=1.0, sigma_min=5e-3, sigma_max=smax,
+                         input_channels=6, output_channels=3, embedding_type='positional', scale_by_sigma=True, ema_rate=0.999)
+    c.optim = ConfigDict(weight_decay=0, optimizer='Adam', lr=2e-4, beta1=0.9, eps=1e-8, warmup=2500, grad_clip=1)
+    c.seed = 42
+    return c
+
+
+def _stable_hash(s):
+    h = 2166136261
+    for ch in s.encode():
+        h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+    return h
+
+
+def synth_weights(shapes, seed=0):
+    """Random-init weights for the bench, generated HERE (the GPU leg imports nothing from oracle/): every >= 2-D tensor is
+    U(+-sqrt(3 / fan_avg)) - the reference's ``default_init(1.0)`` (models/layers.py:54-91), also for its init_scale = 0 layers so
+    that the sampler is not numerically degenerate (with the 1e-10 output layer the score is ~0 and the Langevin step
+    size (snr |z| / |score|)^2 overflows; same FLOPs either way) - biases and GroupNorm affine parameters perturbed around 0 / 1."""
+    out = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        rs = np.random.RandomState((seed * 1000003 + _stable_hash(k)) % (2 ** 31 - 1))
+        if len(shp) >= 2:
+            if k.endswith('.W'):
+                fan_in, fan_out = shp[0], shp[1]
+            else:
+                rf = int(np.prod(shp[2:])) if len(shp) > 2 else 1
+                fan_in, fan_out = shp[1] * rf, shp[0] * rf
+            lim = float(np.sqrt(3.0 / ((fan_in + fan_out) / 2.0)))
+            v = rs.uniform(-lim, lim, size=shp)
+        elif 'GroupNorm' in k and k.endswith('weight') or (k.count('.') == 2 and k.endswith('weight')):
+            v = 1.0 + 0.1 * rs.standard_normal(shp)
+        else:
+            v = 0.05 * rs.standard_normal(shp)
+        out[k] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return out
 
 
 def synth_y(B, seed=123):
@@ -54,11 +96,11 @@ def synth_y(B, seed=123):
 
 def cpu_baseline(cfg, steps=4, B=4):
     """The CPU oracle (oracle/score_oracle.py, a validated port of the reference's PyTorch CPU path)
-    on a bounded sample of the same workload: B images, `steps` PC iterations at 160x160."""
-    import cases  # noqa: F401
+    on a bounded sample of the same workload: B images, `steps` PC iterations at 160x160.  The ONLY place this file touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import score_oracle as so
     nc = so.NetCfg.from_config(cfg)
-    p = so.synth_params(so.ddpm_param_shapes(nc), 0)
+    p = synth_weights(so.ddpm_param_shapes(nc), 0)
     y = synth_y(B)
     shapes = [(B, 3, 160, 160)] * (1 + 2 * steps)
     rs = np.random.RandomState(1)
@@ -115,9 +157,7 @@ def main():
     model = mutils.create_model(cfg)
     # random-init weights of that architecture; the reference's init_scale=0 layers are re-drawn at
     # scale 1 so the sampler is not numerically degenerate - same FLOPs either way
-    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import score_oracle as so
-    model.load_state_dict(so.synth_params(so.ddpm_param_shapes(so.NetCfg.from_config(cfg)), 0))
+    model.load_state_dict(synth_weights({k: tuple(v.shape) for k, v in model.state_dict().items()}, 0))
     model = model.to(dev).eval()
     sde = sde_lib.cVESDE(cfg.model.sigma_min_x, cfg.model.sigma_max_x, cfg.model.num_scales)
     y = synth_y(B, seed=123 + rank).to(dev)
