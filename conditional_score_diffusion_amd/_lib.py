@@ -114,7 +114,7 @@ SIGNATURES = {
     'csd_conv2d_wgrad_ex': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'csd_groupnorm_nhwc_scratch_bytes': (_sz, [_i, _i, _i]),
     'csd_groupnorm_act_nhwc': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
-    'csd_groupnorm_act_backward_nhwc': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'csd_groupnorm_act_backward_nhwc': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'csd_bias_add_nhwc': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'csd_sum_pixels_scratch_bytes': (_sz, [_i, _i, _i]),
     'csd_sum_pixels_nhwc': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

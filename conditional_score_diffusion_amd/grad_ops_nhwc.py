@@ -5,6 +5,8 @@ no NCHW<->NHWC change on either side of a convolution (12-16 % of the operator-g
 C ABI family (include/csd.h: csd_conv2d_ex / csd_conv2d_wgrad_ex layout flags, csd_*_nhwc); the network input and output keep
 the reference's NCHW (``layout`` arguments of conv2d).  No CPU fallback.
 """
+import ctypes
+
 import torch
 
 from . import _lib, ops
@@ -128,13 +130,14 @@ class _GroupNormAct(torch.autograd.Function):
         dy = dy.contiguous()
         B, H, W, C = x.shape
         dx = torch.empty_like(x)
-        dg = torch.empty(B, C, dtype=torch.float32, device=x.device)
-        db = torch.empty(B, C, dtype=torch.float32, device=x.device)
+        rows = torch.empty(B, 2 * C, dtype=torch.float32, device=x.device)       # [dgamma row | dbeta row] per sample: ONE batch reduction
         sc = ops._scratch(lib().csd_groupnorm_nhwc_scratch_bytes(B, C, H * W), x.device)
-        check(lib().csd_groupnorm_act_backward_nhwc(ptr(x), ptr(gamma), ptr(beta), ptr(rs), ptr(ms), ptr(dy), ptr(dx), ptr(dg),
-                                                    ptr(db), B, C, H * W, groups, _lib.ACT_IDS[act], ptr(sc),
-                                                    current_stream(x.device)), 'groupnorm_act_backward_nhwc')
-        return dx, _sum_rows(dg), _sum_rows(db), None, None, None
+        check(lib().csd_groupnorm_act_backward_nhwc(ptr(x), ptr(gamma), ptr(beta), ptr(rs), ptr(ms), ptr(dy), ptr(dx), ptr(rows),
+                                                    ctypes.c_void_p(rows.data_ptr() + 4 * C), 2 * C, B, C, H * W, groups,
+                                                    _lib.ACT_IDS[act], ptr(sc), current_stream(x.device)),
+              'groupnorm_act_backward_nhwc')
+        both = _sum_rows(rows)
+        return dx, both[:C], both[C:], None, None, None
 
 
 def groupnorm_act(x, gamma, beta, groups=32, eps=1e-6, act='none'):

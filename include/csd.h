@@ -315,9 +315,11 @@ size_t csd_groupnorm_nhwc_scratch_bytes(int B, int C, int HW);
 int csd_groupnorm_act_nhwc(const float* x, const float* gamma, const float* beta, float* y, float* rs, float* ms, int B,
                            int C, int HW, int groups, float eps, int act, void* scratch, void* stream);
 int csd_groupnorm_act_backward_nhwc(const float* x, const float* gamma, const float* beta, const float* rs, const float* ms,
-                                    const float* dy, float* dx, float* dgamma_rows, float* dbeta_rows, int B, int C, int HW,
-                                    int groups, int act, void* scratch, void* stream);
-/* out[b,p,c] = x[b,p,c] + bias[b,c];  out[b,c] = sum_p x[b,p,c] (its gradient, and a conv bias gradient after csd_sum_rows) */
+                                    const float* dy, float* dx, float* dgamma_rows, float* dbeta_rows, int row_stride, int B, int C,
+                                    int HW, int groups, int act, void* scratch, void* stream);
+/* out[b,p,c] = x[b,p,c] + bias[b,c];  csd_sum_pixels_nhwc: out[b,c] = sum_p x[b,p,c] (the gradient of that add; a conv bias gradient after
+ * csd_sum_rows).  csd_groupnorm_act_backward_nhwc writes row b of dgamma / dbeta at b*row_stride, so both
+ * can live in one [B, 2C] buffer that a single csd_sum_rows reduces. */
 int csd_bias_add_nhwc(const float* x, const float* bias, float* out, int B, int HW, int C, void* stream);
 size_t csd_sum_pixels_scratch_bytes(int B, int HW, int C);
 int csd_sum_pixels_nhwc(const float* x, float* out, int B, int HW, int C, void* scratch, void* stream);
