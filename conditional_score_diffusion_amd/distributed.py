@@ -28,7 +28,7 @@ def rank_seed(seed, rank):
     return (int(seed) * 1000003 + 7919 * int(rank)) & 0x7FFFFFFFFFFFFFFF
 
 
-def sample_sharded(sampler, model, y_global=None, n_total=None, seed=0, group=None, **sampler_kw):
+def sample_sharded(sampler, model, y_global=None, n_total=None, seed=None, group=None, **sampler_kw):
     """Run ``sampler`` on this rank's shard and all-gather the samples.
 
     sampler : ``fn(model, y_shard, seed=..., **kw) -> (x, info)`` for conditional sampling (as returned
@@ -38,6 +38,8 @@ def sample_sharded(sampler, model, y_global=None, n_total=None, seed=0, group=No
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if seed is None:        # a fresh base key per call from torch's generator (rank_seed keeps the ranks' streams distinct)
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
     if y_global is not None:
         lo, hi = shard_bounds(y_global.shape[0], rank, world)
         x_local, info = sampler(model, y_global[lo:hi].contiguous(), seed=rank_seed(seed, rank), **sampler_kw)

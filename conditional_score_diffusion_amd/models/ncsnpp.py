@@ -463,6 +463,9 @@ class HipNCSNpp(HipUNet):
             self.__dict__['_twin'] = twin            # (not a registered submodule: the state_dict stays the reference's)
         twin.train()
         twin.dropout_seed = self.dropout_seed
+        # THIS model owns the dropout stream position (Trainer.state_dict saves it): the twin's forward increments its own copy
+        twin._train_calls = self._train_calls
+        self._train_calls += 1
         inp = torch.cat([x, y], dim=1) if self.y_channels else x
         return twin(inp, labels)
 

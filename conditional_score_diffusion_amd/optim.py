@@ -7,6 +7,8 @@ decay min(decay, (1+n)/(10+n))), re-designed for the MI355X: all parameters live
 all-reduce per bucket, one norm kernel), and ``step()`` is a single HBM-bound pass - csd_adam_step: clip + Adam + EMA,
 5 reads + 4 writes per element - instead of ~10 elementwise launches per parameter tensor.
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -14,13 +16,41 @@ from . import _lib
 from ._lib import check, current_stream, lib, ptr
 
 
+def _owner(p):
+    """the live FlatParams that holds this Parameter's storage (kept as a weak reference on the Parameter), or None"""
+    r = getattr(p, '_csd_flat', None)
+    return r() if r is not None else None
+
+
 class FlatParams:
-    """Moves ``params`` into one contiguous fp32 buffer (each parameter becomes a view) with a matching gradient buffer."""
+    """Moves ``params`` into one contiguous fp32 buffer (each parameter becomes a view) with a matching gradient buffer.
+
+    A parameter can live in ONE flat buffer only.  ``FlatParams.of(params)`` is what the optimizer and the EMA call: it hands
+    back the existing FlatParams when exactly these parameters were flattened before - so ``get_optimizer(config,
+    model.parameters())`` and ``ExponentialMovingAverage(model.parameters(), decay)``, the two calls the reference makes
+    (lightning_modules/BaseSdeGenerativeModel.py:75-96), share one buffer - and raises when the sets only overlap."""
+
+    @classmethod
+    def of(cls, params):
+        if isinstance(params, FlatParams):
+            return params
+        plist = [p for p in params if p.requires_grad]
+        owners = {id(o): o for o in map(_owner, plist) if o is not None}
+        if not owners:
+            return cls(plist)
+        if len(owners) == 1:
+            flat = next(iter(owners.values()))
+            if len(flat.params) == len(plist) and all(a is b for a, b in zip(flat.params, plist)):
+                return flat
+        raise RuntimeError('FlatParams: some of these parameters already live in another flat buffer (a different parameter '
+                           'list was flattened before); build the optimizer and the EMA from the same parameter list')
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('no trainable parameters')
+        if any(_owner(p) is not None for p in self.params):
+            raise RuntimeError('FlatParams: parameters are already flattened - use FlatParams.of(params)')
         dev = self.params[0].device
         if any(p.dtype != torch.float32 or p.device != dev for p in self.params):
             raise RuntimeError('FlatParams: parameters must be float32 on one device')
@@ -33,6 +63,7 @@ class FlatParams:
             self.data[o:o + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.data[o:o + p.numel()].view_as(p)
             p.grad = self.grad[o:o + p.numel()].view_as(p)      # autograd accumulates in place into the flat buffer
+            p._csd_flat = weakref.ref(self)
         _lib.WEIGHT_EPOCH[0] += 1
 
     def zero_grad(self):
@@ -42,13 +73,16 @@ class FlatParams:
                 p.grad = self.grad[int(o):int(o) + p.numel()].view_as(p)
 
 
-class FusedAdam:
-    """``torch.optim.Adam`` semantics (losses.py:12-23) on a FlatParams; ``step()`` = csd_global_norm + csd_adam_step."""
+class FusedAdam(torch.optim.Optimizer):
+    """``torch.optim.Adam`` semantics (losses.py:12-23) on a FlatParams; ``step()`` = csd_global_norm + csd_adam_step.
+    A ``torch.optim.Optimizer`` (one parameter group), so the reference's ``LambdaLR`` warm-up scheduler
+    (BaseSdeGenerativeModel.py:86-96) accepts it.  One difference from torch.optim.Adam: a parameter that received no
+    gradient in a step is updated with a zero gradient (moments decay) instead of being skipped."""
 
     def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        self.flat = params if isinstance(params, FlatParams) else FlatParams(list(params))
+        self.flat = FlatParams.of(params if isinstance(params, FlatParams) else list(params))
         _lib.require_gpu_tensor(self.flat.data, 'parameters')          # the update is a HIP kernel: no CPU fallback
-        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, params=self.flat.params)]
+        super().__init__(self.flat.params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.exp_avg = torch.zeros_like(self.flat.data)
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
         self.num_steps = 0
@@ -67,8 +101,10 @@ class FusedAdam:
                                     current_stream(out.device)), 'global_norm')
         return out
 
-    def step(self, ema=None):
+    def step(self, closure=None, ema=None):
         """One update; ``ema`` (an ExponentialMovingAverage over the same FlatParams) is folded into the same pass."""
+        if closure is not None:
+            raise NotImplementedError('FusedAdam.step: closures are not supported')
         g = self.param_groups[0]
         self.num_steps += 1
         norm = self.grad_norm() if self.max_norm >= 0 else None
@@ -125,7 +161,7 @@ class ExponentialMovingAverage:
             raise ValueError('Decay must be between 0 and 1')
         self.decay = decay
         self.num_updates = 0 if use_num_updates else None
-        self.flat = parameters if isinstance(parameters, FlatParams) else FlatParams(list(parameters))
+        self.flat = FlatParams.of(parameters if isinstance(parameters, FlatParams) else list(parameters))
         _lib.require_gpu_tensor(self.flat.data, 'parameters')
         self.shadow = self.flat.data.clone()
         self._stored = None

@@ -123,7 +123,7 @@ def get_pc_conditional_sampler(sde, shape, predictor, corrector, snr, p_steps, c
     if use_path:
         return path_sampler
 
-    def pc_conditional_sampler(model, y, show_evolution=False, noise_tape=None, seed=0):
+    def pc_conditional_sampler(model, y, show_evolution=False, noise_tape=None, seed=None):
         if fused.fusable(model, sde, predictor, corrector, c_steps, probability_flow, continuous):
             x, rec, _ = fused.run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=noise_tape,
                                   seed=seed, record=show_evolution)

@@ -47,9 +47,17 @@ def _fp(t):
     return t.data_ptr() and ctypes.cast(t.data_ptr(), ctypes.POINTER(ctypes.c_float))
 
 
-def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=0, record=False,
+def fresh_seed():
+    """A Philox key drawn from torch's global CPU generator: successive calls get different noise (as the reference's
+    torch.randn calls do, sampling/conditional.py:198) and torch.manual_seed still makes a run reproducible."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=None, record=False,
         unconditional_label=None):
-    """Run the fused loop; returns (samples, record_or_None)."""
+    """Run the fused loop; returns (samples, record_or_None, timesteps).  ``seed=None``: a fresh key per call (fresh_seed)."""
+    if seed is None:
+        seed = fresh_seed()
     c_sde = sde['x'] if isinstance(sde, dict) else sde
     dev = model.device
     if dev.type != 'cuda':

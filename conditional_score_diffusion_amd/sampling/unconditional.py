@@ -153,7 +153,7 @@ def get_pc_sampler(sde, shape, predictor, corrector, snr, p_steps, c_steps, prob
     corr_fn = functools.partial(shared_corrector_update_fn, sde=sde, corrector=corrector, continuous=continuous,
                                 snr=snr, n_steps=c_steps)
 
-    def pc_sampler(model, show_evolution=False, noise_tape=None, seed=0):
+    def pc_sampler(model, show_evolution=False, noise_tape=None, seed=None):
         steps = p_steps * (c_steps + 1)
         if fused.fusable(model, sde, predictor, corrector, c_steps, probability_flow, continuous):
             label = 'fourier' if getattr(model, 'embedding_type', 'positional') == 'fourier' else 'sigma'

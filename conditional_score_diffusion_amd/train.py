@@ -36,7 +36,7 @@ class Trainer:
         self.sigma_max_y = float(m.sigma_max_y) if has('sigma_max_y') else None
         self.sigma_min_y = float(m.sigma_min_y) if has('sigma_min_y') else None
         self._build_loss_fns()
-        self.flat = optim.FlatParams(model.parameters())
+        self.flat = optim.FlatParams.of(model.parameters())
         self.optimizer = optim.get_optimizer(config, self.flat)
         self.optimize_fn = optim.optimization_manager(config)
         self.ema = optim.ExponentialMovingAverage(self.flat, decay=config.model.ema_rate)

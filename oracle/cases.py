@@ -189,3 +189,20 @@ def inpaint_case():
     mask[:, :, :, : S // 2] = 1.
     shape = (B, 3, S, S)
     return cfg, B, data, mask, tape([shape] * (1 + 4 * 12), 23)
+
+
+# ---- full-size SR3-160 (BASELINE configs[1] network), the long-schedule fixture tests/golden/sr3_160_long.npz ----
+SR3_160 = dict(name='ddpm_paired_SR3', nf=96, ch_mult=(1, 1, 2, 2, 3, 3), attn_resolutions=(20, 10, 5), image_size=160)
+LONG_P, LONG_B, LONG_EVERY, LONG_STRIDE = 1000, 2, 50, 4
+
+
+def sr3_160_y(B, seed=123):
+    """synthetic LR condition: U[0,1) 20x20 -> nearest x8 (mirrors lightning_data_modules/SRFLOWDataset.py:141-146, scale 8)"""
+    rs = np.random.RandomState(seed)
+    lr = rs.uniform(0, 1, size=(B, 3, 20, 20)).astype(np.float32)
+    return torch.from_numpy(np.repeat(np.repeat(lr, 8, axis=2), 8, axis=3))
+
+
+def long_tape(P=LONG_P, B=LONG_B, seed=2024):
+    """prior + 2 draws per PC step, [B,3,160,160] each, regenerated from the seed on either side"""
+    return tape([(B, 3, 160, 160)] * (1 + 2 * P), seed)

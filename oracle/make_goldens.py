@@ -417,6 +417,45 @@ def gen_ncsnpp(ref):
     np.savez_compressed(os.path.join(OUT, 'ncsnpp.npz'), **out)
 
 
+def gen_sr3_160_long(ref):
+    """Full-size SR3-160 (BASELINE configs[1] network: nf = 96, ch_mult (1,1,2,2,3,3), attention at 20/10/5, 160 x 160), the REAL
+    1000-step PC schedule (sampling/conditional.py:180-226), B = 2, noise from a seeded tape, run by the imported reference
+    on the CPU -> tests/golden/sr3_160_long.npz: x after every 50th PC step on a stride-4 pixel grid, the full final x_mean,
+    and one B = 1 network evaluation.  ~35 min on 8 cores."""
+    import time
+    cfg = cases.make_config(**cases.SR3_160)
+    model, _ = build_ref_model(ref, cfg)
+    sde = sdes_for(ref, cfg)
+    P, B, every, st = cases.LONG_P, cases.LONG_B, cases.LONG_EVERY, cases.LONG_STRIDE
+    y = cases.sr3_160_y(B)
+    xs = (B, 3, 160, 160)
+    out = {}
+    with torch.no_grad():
+        rs = np.random.RandomState(5)
+        x1 = torch.from_numpy((rs.standard_normal((1, 3, 160, 160)) * 3.0 + 0.5).astype(np.float32))
+        lab = torch.tensor([412.0])
+        out['fwd_x'], out['fwd_label'] = x1.numpy(), lab.numpy()
+        out['fwd_net'] = model({'x': x1, 'y': y[:1]}, lab).numpy()
+    tp = cases.long_tape()
+    co = ref['sampling.conditional']
+    sampler = co.get_pc_conditional_sampler(sde, xs, ref['sampling.predictors'].get_predictor('conditional_reverse_diffusion'),
+                                            ref['sampling.correctors'].get_corrector('conditional_langevin'),
+                                            snr=cfg.sampling.snr, p_steps=P, c_steps=1, probability_flow=False, continuous=True,
+                                            denoise=True, use_path=False, eps=1e-5)
+    t0 = time.time()
+    with ref_import.TapeRandn(tp) as tr:
+        res, info = sampler(model, y, show_evolution=True)
+        assert tr.i == len(tp), (tr.i, len(tp))
+    ev = info['evolution']['x']                              # [P, B, 3, 160, 160]: x after every PC step
+    out['steps'] = np.arange(every - 1, P, every)
+    out['evo'] = ev[every - 1::every, :, :, ::st, ::st].contiguous().numpy()
+    out['evo_absmax'] = ev[every - 1::every].abs().amax(dim=(1, 2, 3, 4)).numpy()
+    out['evo_rms'] = ev[every - 1::every].double().pow(2).mean(dim=(1, 2, 3, 4)).sqrt().numpy()
+    out['final'] = res.numpy()
+    print('sr3_160_long: %.0f s; |x| max per snapshot' % (time.time() - t0), out['evo_absmax'], 'final absmax', float(res.abs().max()))
+    np.savez_compressed(os.path.join(OUT, 'sr3_160_long.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)

@@ -498,14 +498,40 @@ def test_config4_shape_gradients_vs_oracle(precision):
     print('config-4 shape, %s: worst relative gradient error over %d tensors %.2e' % (precision, len(big), max(r_[0] for r_ in big)))
 
 
-def test_trainer_checkpoint_resume_is_bit_exact(tmp_path):
+def _ncsnpp_train_case():
+    cfg, B, x, labels = cases.ncsnpp_case('ncsnpp_paired_skip')
+    cfg.optim = cases.make_config().optim
+    cfg.model.ema_rate = 0.999
+    cfg.seed = 42
+    cfg.model.sigma_min_x, cfg.model.sigma_max_x, cfg.model.sigma_min_y, cfg.model.sigma_max_y = 0.01, 50., 0.01, 1.0
+    return cfg, x
+
+
+@pytest.mark.parametrize('family', ['ddpm', 'ncsnpp'])
+def test_trainer_checkpoint_resume_is_bit_exact(tmp_path, family):
     """train 2 steps, save (torch.save of Trainer.state_dict()), train 2 more; a fresh model + Trainer restored from the file takes
-    the same 2 steps: identical losses and identical parameters / EMA (dropout 0.1 on: the Philox stream position is part of the state)."""
-    from conditional_score_diffusion_amd import train
-    cfg, B, x, y, u, tape = cases.grad_case('sr3_tiny')
-    cfg.model.dropout = 0.1
-    cfg.optim.warmup = 2
-    batch = (y.to(dev()), x.to(dev()))
+    the same 2 steps: identical losses and identical parameters / EMA (dropout 0.1 on: the Philox stream position is part of the
+    state - for the planned NCSN++ class too, whose training forward runs on a parameter-sharing twin)."""
+    from conditional_score_diffusion_amd import sde_lib, train
+    from conditional_score_diffusion_amd.models import utils as mutils
+    if family == 'ncsnpp':
+        cfg, xx = _ncsnpp_train_case()
+        cfg.model.dropout = 0.1
+        cfg.optim.warmup = 2
+        batch = (xx[:, 3:].contiguous().to(dev()), xx[:, :3].contiguous().to(dev()))
+
+        def build(cfg):
+            torch.manual_seed(5)
+            return None, None, None, mutils.create_model(cfg).to(dev())
+
+        def sdes_for(cfg):
+            return {'x': sde_lib.cVESDE(0.01, 50., 1000), 'y': sde_lib.VESDE(0.01, 1.0, 1000)}
+    else:
+        build, sdes_for = globals()['build'], globals()['sdes_for']
+        cfg, B, x, y, u, tape = cases.grad_case('sr3_tiny')
+        cfg.model.dropout = 0.1
+        cfg.optim.warmup = 2
+        batch = (y.to(dev()), x.to(dev()))
 
     def steps(tr, n):
         out = []

@@ -168,6 +168,24 @@ def test_no_cpu_fallback():
         ops.groupnorm_act(torch.zeros(1, 32, 4, 4), torch.ones(32), torch.zeros(32))
 
 
+def test_flat_params_are_shared_not_reflattened():
+    """get_optimizer(config, model.parameters()) and ExponentialMovingAverage(model.parameters(), decay) - the reference's two
+    calls (BaseSdeGenerativeModel.py:75-96) - must land on ONE flat buffer; a second, different flattening must raise
+    (silently re-pointing p.data at a second buffer left the optimizer updating storage no Parameter views)."""
+    from conditional_score_diffusion_amd import optim
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    a = optim.FlatParams.of(net.parameters())
+    b = optim.FlatParams.of(net.parameters())
+    assert a is b
+    for p_, o in zip(a.params, a.offsets[:-1]):
+        assert p_.data_ptr() == a.data.data_ptr() + 4 * int(o) and p_.grad.data_ptr() == a.grad.data_ptr() + 4 * int(o)
+    with pytest.raises(RuntimeError):
+        optim.FlatParams.of(list(net.parameters())[:2])         # a subset of an already flattened list
+    with pytest.raises(RuntimeError):
+        optim.FlatParams(net.parameters())                      # explicit re-flattening
+    assert issubclass(optim.FusedAdam, torch.optim.Optimizer)   # LambdaLR (configure_optimizers) accepts it
+
+
 def test_product_code_never_imports_the_oracle():
     pkg = os.path.join(ROOT, 'conditional_score_diffusion_amd')
     for dirpath, _, files in os.walk(pkg):
