@@ -110,6 +110,8 @@ SIGNATURES = {
     'csd_sum_rows': (_i, [_vp, _vp, _i, _i, _vp]),
     'csd_act': (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
     'csd_mul': (_i, [_vp, _vp, _vp, _i64, _vp]),
+    'csd_conv3x3_block_scratch_bytes': (_sz, [_i, _i]),
+    'csd_conv3x3_block': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'csd_conv2d_ex': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'csd_conv2d_wgrad_ex': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'csd_groupnorm_nhwc_scratch_bytes': (_sz, [_i, _i, _i]),

@@ -113,6 +113,14 @@ int conv16q_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, i
                         void* wpack, hipStream_t s);
 int conv16q_plan_tiles(ConvPlan* p, int ns);
 int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s);
+// fused-prologue schedule (conv_ff.hip): 3x3 stride-1 layers on 16 x 16 tiles that lie inside one sample, fp32 NHWC sources
+// (two-source virtual concat), GroupNorm affine + activation + fp16 split applied while staging (no gn_apply16 pass)
+bool convff_supported(const ConvPlan& p, int ns);
+size_t convff_packed_bytes(const ConvPlan& p, int ns);
+int convff_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int cin_src, int cout_src, int cout_off,
+                       void* wpack, hipStream_t s);
+int convff_plan_tiles(ConvPlan* p, int ns);
+int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s);
 // pointwise (1x1) layers on the fp16 MFMA path (conv_pw16.hip): fp32 NHWC in / out, optional GroupNorm affine on the
 // input, bias + residual epilogue; no LDS staging of activations - a pure HBM stream
 bool pw16_supported(const ConvPlan& p, int ns);

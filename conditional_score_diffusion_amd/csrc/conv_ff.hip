@@ -1,0 +1,634 @@
+// conv_ff.hip - "fused-prologue" 3x3 stride-1 convolution of the ResnetBlock convs (reference models/layers.py:632-675:
+// h = Conv(act(GroupNorm(x))) [+ Dense(temb)] / x + Conv(...); models/layerspp.py:212-274) at the resolutions where a
+// 16 x 16 pixel tile lies inside one sample (H % 16 == 0 and W % 16 == 0: the 160^2 / 80^2 levels of SR3-160, every level
+// >= 16^2 of the 128^2 / 64^2 / 256^2 nets).
+//
+// What it fuses: the GroupNorm affine + activation + fp16 (hi|lo) split of the conv OPERAND.  The other fp16 schedules
+// read fp16 planes that gn_apply16_kernel wrote (fp32 in, 2*NS bytes out per element, then 2*NS bytes back in) - a pure
+// HBM pass that cost 17-22 % of a PC step.  Here the fp32 residual stream (two-source virtual concat allowed) is the
+// kernel's input: every element is converted ONCE per workgroup while it is staged, by three of the four waves.
+//
+// Schedule (one workgroup = 4 waves = 256 output pixels (16 x 16) x NT*32 couts, 2 workgroups per CU):
+//   * MFMA: v_mfma_f32_32x32x16_f16, operands swapped (A = weights, B = pixels) so a lane's 16 results are 4 x 4
+//     consecutive couts of ONE pixel: the epilogue moves 16 bytes per lane.  Wave w owns pixel rows 4w..4w+3 as two
+//     4 x 8 M tiles (that lane->pixel map + a 1168-byte LDS row pitch makes every ds_read_b128 of a tap conflict-free)
+//     and ALL NT cout tiles: 2*NT accumulators, 2 + NT fragment reads per K step.
+//   * weights: through LDS, shared by the four waves (each wave pulling its own fragments from L2 saturates the
+//     64 B/clk L1 path - the binding resource of the quad / loader-consumer schedules).  Wave 0 streams them with
+//     global_load_lds_dwordx4 (no registers, fragment order = linear) into a ring of R groups, a few hundred cycles
+//     ahead; it issues no other VMEM load inside the loop, so its in-order vmcnt queue holds L2-latency DMAs only.
+//   * activations: waves 1-3 fetch the NEXT stage's patch (18 x 18 pixels x KC channels, fp32) into registers at the
+//     top of a stage, convert + write it into the other LDS patch buffer at the end of the stage: a full stage
+//     (>= 1.4 us of MFMAs) of latency cover, and their vmcnt queue holds nothing but that burst.
+//   * one LDS-only barrier per ring group (18 MFMAs per wave between barriers in both arithmetic modes).
+//   NS = 1 (fp16): KC = 32 channels per stage (2 K steps per tap), ring group = 3 steps.
+//   NS = 2 (fp16x3: hi|lo operands, 3 MFMAs per product): KC = 16, ring group = 1 step.
+// Epilogue: acc starts at (bias + temb) * 2^8, residual added, out_scale, 16-byte stores, and the GroupNorm partials
+// (sum, sum of squares per (tile, cout)) of the written tensor for the NEXT GroupNorm - fp32 tree over the tile's 256
+// pixels in a fixed order, folded in fp64 by gn_finalize_tiles_kernel.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "conv_f16_kernel.h"
+
+namespace csd {
+
+typedef unsigned int uint4f __attribute__((ext_vector_type(4)));
+
+#define FF_THREADS 256
+#define FF_TILE 16
+#define FF_PW 18                                   // patch width / height in pixels
+#define FF_NPATCH (FF_PW * FF_PW)
+#define FF_PSB 64                                  // bytes per staged pixel: NS = 1: 32 channels fp16; NS = 2: 16 ch hi | 16 ch lo
+#define FF_RS (FF_PW * FF_PSB + 16)                // LDS row pitch (conflict-free ds_read_b128 for 4 x 8 M tiles)
+#define FF_PATCH_BYTES (FF_PW * FF_RS)
+
+struct ConvFFArgs {
+  ConvArgs a;
+  int B, H, W, C0, C1, Cout;
+  int tiles_x, tpi, n_groups, nblocks;
+  int nstage;
+  int abl;                   // tuning aid (CSD_FF_ABL): 1 no weight refills, 2 no patch conversion, 4 no patch prefetch, 8 no epilogue IO
+};
+
+// LDS hand-over: this wave's ds_writes / ds_reads have completed (lgkmcnt), then the workgroup barrier.  NOT a fence: with an
+// LDS-DMA in flight a workgroup release fence makes hipcc drain vmcnt(0) in every wave at every barrier - which would expose
+// the patch prefetch and the weight stream once per ring group.  LDS-DMA data is ordered by wave 0's counted vmcnt before
+// its barrier arrival instead.
+__device__ __forceinline__ void ff_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0) only (a builtin, so hipcc's own wait bookkeeping sees it)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void ff_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int NS, int NT>
+struct FFCfg {
+  static constexpr int KC = NS == 1 ? 32 : 16;                // channels per stage
+  static constexpr int KSUB = NS == 1 ? 2 : 1;                // MFMA K steps per tap per stage
+  static constexpr int STEPS = KSUB * 9;                      // K steps per stage
+  static constexpr int TG = NS == 1 ? 2 : 1;                  // steps per ring group (6 KiB at NT = 3)
+  static constexpr int GPS = STEPS / TG;                      // ring groups per stage
+  static constexpr int SB = NT * NS * 1024;                   // weight bytes per step
+  static constexpr int GB = TG * SB;                          // bytes per ring group
+  static constexpr int GL = GB / 1024;                        // LDS-DMA instructions per group
+  static constexpr int R = 5;                                 // ring depth (groups): current, next (landed), two in flight, one being refilled
+  static constexpr int G4 = KC / 4;                           // 4-channel groups per pixel per stage
+  // waves 0..NDMA-1 stream the weights (an LDS-DMA costs its wave 60-180 cycles of issue: six per ring group on ONE wave made
+  // that wave the pace of the workgroup), the others prefetch + convert the patch
+  static constexpr int NDMA = 1;      // (2 measured slower in the split mode: 11 conversion slots on two waves outweigh the DMA relief)
+  static constexpr int GLW = GL / NDMA;                       // LDS-DMA instructions per group per DMA wave
+  static constexpr int LOADERS = (4 - NDMA) * 64;             // threads of the patch waves
+  static constexpr int NSLOT = (FF_NPATCH * G4 + LOADERS - 1) / LOADERS;
+  static constexpr int PPJ = LOADERS / G4;                    // patch pixels between a thread's consecutive slots
+  static constexpr size_t LDS = 2 * (size_t)FF_PATCH_BYTES + (size_t)R * GB + 2 * FF_NPATCH * sizeof(int);
+};
+
+template <int NS, int NT>
+__global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __restrict__ g_wpack, const ConvFFArgs k) {
+  using C = FFCfg<NS, NT>;
+  constexpr int KC = C::KC, STEPS = C::STEPS, TG = C::TG, GPS = C::GPS, SB = C::SB, GB = C::GB, GL = C::GL, R = C::R;
+  constexpr int G4 = C::G4, NSLOT = C::NSLOT, PPJ = C::PPJ, NDMA = C::NDMA, GLW = C::GLW;
+  static_assert(GL % NDMA == 0, "weight DMA split");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const patch = smem;                                         // 2 buffers
+  char* const ring = smem + 2 * FF_PATCH_BYTES;                     // R groups of weights in fragment order
+  int* const stab = reinterpret_cast<int*>(ring + R * GB);          // [324] source pixel index inside the sample, or -1
+  int* const dtab = stab + FF_NPATCH;                               // [324] LDS byte offset of the patch pixel
+
+  // (local copies: a lambda that captures the by-value kernel argument struct by reference forces it into scratch)
+  const float* const a_src0 = k.a.src0;
+  const float* const a_src1 = k.a.src1;
+  const float* const a_bias = k.a.bias;
+  const float* const a_temb = k.a.temb;
+  const float* const a_res = k.a.res;
+  const float* const a_nscale = k.a.nscale;
+  const float* const a_nshift = k.a.nshift;
+  float* const a_out = k.a.out;
+  double* const a_stats = k.a.stats;
+  long long* const a_dbg = k.a.dbg;
+  const int a_temb_stride = k.a.temb_stride, a_out_stride = k.a.out_stride, a_out_coff = k.a.out_coff, a_act = k.a.act;
+  const float a_out_scale = k.a.out_scale;
+  const int kH = k.H, kW = k.W, kC0 = k.C0, kC1 = k.C1, kCout = k.Cout, k_tiles_x = k.tiles_x, k_tpi = k.tpi,
+            k_n_groups = k.n_groups, k_nblocks = k.nblocks, k_nstage = k.nstage, k_abl = k.abl;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kh = lane >> 5, p32 = lane & 31;
+#ifdef CSD_FF_TUNE
+#ifdef CSD_FF_CONST_ABL
+#define FF_ABL(bit) ((CSD_FF_CONST_ABL) & (bit))      // compile-time ablation: the tested code is really gone
+#else
+#define FF_ABL(bit) (k_abl & (bit))
+#endif
+  int ts_n = 0;
+#define FF_TS() do { if (a_dbg && (tid == 0 || tid == 64) && blockIdx.x < 4096 && ts_n < 16) a_dbg[(blockIdx.x * 2 + (tid >> 6)) * 16 + ts_n++] = clock64(); } while (0)
+#define FF_WALL(i) do { if (a_dbg && (tid == 0 || tid == 64) && blockIdx.x < 4096) a_dbg[(blockIdx.x * 2 + (tid >> 6)) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define FF_WALL(i) do { } while (0)
+#define FF_ABL(bit) false
+#define FF_TS() do { } while (0)
+#endif
+  FF_TS();
+  FF_WALL(14);
+
+  int w;
+  {
+    const int bid = blockIdx.x, nb = k_nblocks;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int ng = w % k_n_groups;
+  const int tile = w / k_n_groups;
+  const int b = tile / k_tpi;
+  const int tin = tile - b * k_tpi;
+  const int ty0 = (tin / k_tiles_x) * FF_TILE, tx0 = (tin - (tin / k_tiles_x) * k_tiles_x) * FF_TILE;
+  const int Cin = kC0 + kC1;
+  const bool norm = a_nscale != nullptr;
+
+  // ---- loader state (waves 1-3): slot j of thread t = 4-channel group (t % G4) of patch pixel j*PPJ + t/G4 ----
+  const int lt = tid - 64 * NDMA;
+  const int lg = (lt >= 0 ? lt : 0) % G4, lp0 = (lt >= 0 ? lt : 0) / G4;
+  float4 pf[NSLOT];
+  float4 n_sc = make_float4(1.f, 1.f, 1.f, 1.f), n_sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  const size_t img0 = (size_t)b * kH * kW;
+  auto issue_patch = [&](int stage, auto from_table) __attribute__((always_inline)) {      // (waves 1-3 only)
+    const int cb = stage * KC;
+    const bool s1 = cb >= kC0;
+    const float* src = (s1 ? a_src1 : a_src0) + img0 * (s1 ? kC1 : kC0) + (s1 ? cb - kC0 : cb) + lg * 4;
+    const int Cs = s1 ? kC1 : kC0;
+    // straight-line: slots past the patch and out-of-image pixels read pixel 0 of the sample (their values are replaced
+    // by zeros / dumped when stored) - a per-slot branch would put every load into its own basic block behind a vmcnt(0)
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+      const int pix = min(j * PPJ + lp0, FF_NPATCH - 1);
+      int sp;
+      if constexpr (decltype(from_table)::value) {
+        sp = stab[pix];
+      } else {                                       // (the first stage is requested before the tables exist)
+        const int pr = pix / FF_PW, pc = pix - pr * FF_PW;
+        const int y = ty0 - 1 + pr, x = tx0 - 1 + pc;
+        sp = (y >= 0 && y < kH && x >= 0 && x < kW) ? y * kW + x : -1;
+      }
+      pf[j] = gload4f(src + (size_t)(sp >= 0 ? sp : 0) * Cs);
+    }
+    if (norm) {
+      n_sc = gload4f(a_nscale + (size_t)b * Cin + cb + lg * 4);
+      n_sh = gload4f(a_nshift + (size_t)b * Cin + cb + lg * 4);
+    }
+  };
+  // convert + write the prefetched stage: the arithmetic of gn_apply16_kernel with the SiLU inline (the host routes
+  // other activations - none of the reference's configs uses one - to the older schedules)
+  auto store_patch = [&](char* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+      const int pixr = j * PPJ + lp0;
+      const int pix = min(pixr, FF_NPATCH - 1);
+      const bool in = stab[pix] >= 0;
+      float h[4] = {pf[j].x, pf[j].y, pf[j].z, pf[j].w};
+      if (norm) {
+        h[0] = h[0] * n_sc.x + n_sh.x; h[1] = h[1] * n_sc.y + n_sh.y;
+        h[2] = h[2] * n_sc.z + n_sh.z; h[3] = h[3] * n_sc.w + n_sh.w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = h[q] * __builtin_amdgcn_rcpf(1.0f + __expf(-h[q]));      // (v_rcp_f32: 1 ulp)
+      }
+      half4 hi, lo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v = in ? h[q] : 0.f;             // padding is applied to the ACTIVATED tensor: exactly 0
+        hi[q] = (_Float16)v;
+        lo[q] = (_Float16)(v - (float)hi[q]);
+      }
+      // (slots past the patch - possible in the last j only - land in the 16 pad bytes at the end of patch row 17)
+      const bool real = (j * PPJ + PPJ - 1 < FF_NPATCH) || pixr < FF_NPATCH;
+      char* dst = buf + (real ? dtab[pix] + lg * 8 : FF_PATCH_BYTES - 16);
+      *reinterpret_cast<half4*>(dst) = hi;
+      if (NS == 2) *reinterpret_cast<half4*>(dst + (real ? 32 : 8)) = lo;
+    }
+  };
+
+  // ---- weight stream (wave 0): group G -> ring slot G % R, GL LDS-DMA instructions of 1 KiB ----
+  const int total_groups = k_nstage * GPS;
+  const char* const wsrc = g_wpack + (size_t)ng * ((size_t)(Cin / 16) * 9 * SB) + lane * 16;
+  // DMA wave w owns pieces w*GLW .. w*GLW+GLW-1 of every ring group
+  auto issue_w1 = [&](int G, int slot, int piece) __attribute__((always_inline)) {
+    const int i = wave * GLW + piece;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)G * GB + i * 1024),
+                                     (__attribute__((address_space(3))) void*)(ring + slot * GB + i * 1024), 16, 0, 0);
+  };
+  auto issue_w = [&](int G, int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < GLW; ++i) issue_w1(G, slot, i);
+  };
+
+  // ---- prologue: the first stage's patch (waves 1-3) and the first R-1 weight groups (wave 0) are requested before anything
+  // else, the tables / bias / time-embedding work runs under their latency ----
+  if (wave < NDMA) {
+#pragma unroll
+    for (int G = 0; G < R - 1; ++G)
+      if (G < total_groups) issue_w(G, G);
+  } else {
+    issue_patch(0, std::false_type{});
+  }
+  // staging tables (the pixel -> source / destination map is the same for every stage)
+  for (int pix = tid; pix < FF_NPATCH; pix += FF_THREADS) {
+    const int pr = pix / FF_PW, pc = pix - pr * FF_PW;
+    const int y = ty0 - 1 + pr, x = tx0 - 1 + pc;
+    stab[pix] = (y >= 0 && y < kH && x >= 0 && x < kW) ? y * kW + x : -1;      // zero padding outside THIS sample
+    dtab[pix] = pr * FF_RS + pc * FF_PSB;
+  }
+
+
+  // ---- accumulators start at (bias + temb) * 2^8 ----
+  // lane = pixel p32 of each M tile; its 16 results of cout tile nt are couts nt*32 + 8q + 4kh + i (q = r >> 2, i = r & 3)
+  const int c_lane = ng * NT * 32 + kh * 4;
+  floatx16 acc[2][NT];
+  {
+    float4 bv[NT * 4];                               // (all loads of a kind in one straight-line burst)
+#pragma unroll
+    for (int i = 0; i < NT * 4; ++i) bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a_bias) {
+#pragma unroll
+      for (int i = 0; i < NT * 4; ++i) bv[i] = gload4f(a_bias + c_lane + (i >> 2) * 32 + (i & 3) * 8);
+    }
+    if (a_temb) {
+      float4 tv[NT * 4];
+#pragma unroll
+      for (int i = 0; i < NT * 4; ++i) tv[i] = gload4f(a_temb + (size_t)b * a_temb_stride + c_lane + (i >> 2) * 32 + (i & 3) * 8);
+#pragma unroll
+      for (int i = 0; i < NT * 4; ++i) bv[i] = make_float4(bv[i].x + tv[i].x, bv[i].y + tv[i].y, bv[i].z + tv[i].z, bv[i].w + tv[i].w);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          acc[mt][nt][q * 4 + 0] = bv[nt * 4 + q].x * C16_WSCALE; acc[mt][nt][q * 4 + 1] = bv[nt * 4 + q].y * C16_WSCALE;
+          acc[mt][nt][q * 4 + 2] = bv[nt * 4 + q].z * C16_WSCALE; acc[mt][nt][q * 4 + 3] = bv[nt * 4 + q].w * C16_WSCALE;
+        }
+  }
+
+  // per-lane LDS offset of tap (0,0) of its pixel in M tile mt (rows 4*wave + (p32 >> 3), cols 8*mt + (p32 & 7)) + K half
+  int base[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) base[mt] = (4 * wave + (p32 >> 3)) * FF_RS + (8 * mt + (p32 & 7)) * FF_PSB + kh * 16;
+
+  ff_barrier();                                      // tables visible
+  FF_TS();
+  if (wave < NDMA) ff_wait_vm<(R - 3) * GLW>();      // groups 0 and 1 have landed
+  else store_patch(patch);
+  ff_barrier();
+  FF_TS();
+
+  // Invariant at the top of group G (after its barrier): groups G and G+1 are in LDS, so every wave may fetch the NEXT K step's
+  // fragments - also across a ring-group boundary - before it issues the current step's MFMAs (register double buffer).
+  int Gc = 0, slot = 0;                              // current group and its ring slot
+  for (int s = 0; s < k_nstage; ++s) {
+    const bool W0 = wave < NDMA;                     // (a weight-DMA wave)
+    const bool more = s + 1 < k_nstage;
+    if (!W0 && more && !FF_ABL(4)) issue_patch(s + 1, std::true_type{});
+    const char* const pb = patch + (s & 1) * FF_PATCH_BYTES;
+    half8 wa[2][NT][NS], xb[2][2][NS];
+    auto load_frags = [&](int buf, int step, int sl) __attribute__((always_inline)) {     // step: compile-time after unrolling
+      const int ksub = step / 9, tap = step - ksub * 9;
+      const int r = tap / 3, sx = tap - r * 3;
+      const char* const wb = ring + sl * GB + (step % TG) * SB + lane * 16;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl) wa[buf][nt][pl] = *reinterpret_cast<const half8*>(wb + (nt * NS + pl) * 1024);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+          xb[buf][mt][pl] = *reinterpret_cast<const half8*>(pb + base[mt] + r * FF_RS + sx * FF_PSB + (NS == 1 ? ksub * 32 : pl * 32));
+    };
+    load_frags(0, 0, slot);
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+      const int cur = step & 1;
+      const bool first = step % TG == 0, last = step % TG == TG - 1;
+      if (first && W0) {                             // refill the slot group Gc-1 has just left
+        // (measured: the pieces issued one by one between the MFMAs of the group, or split over two DMA waves - no faster)
+        const int Gn = Gc + R - 1;
+        int sn = slot + R - 1;
+        sn = sn >= R ? sn - R : sn;
+        if (Gn < total_groups && !FF_ABL(1)) issue_w(Gn, sn);
+      }
+      // the first accumulator's MFMAs, THEN the next step's fragment reads (they issue and complete under the remaining
+      // MFMAs of this step), then the rest: a wave's instruction stream stalls on the matrix pipe, so reads placed after
+      // the MFMA block would start ~160 cycles late, and reads placed before it would be waited for at once (lgkmcnt(0)).
+      // MFMAs on ONE accumulator stay back to back (tools/mfma_chain.hip: 2465 TF/s against 2218 round-robin).
+      auto mma = [&](int mt, int nt) __attribute__((always_inline)) {
+        if constexpr (NS == 2) {                     // small terms first: lo*hi, hi*lo, then hi*hi
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][nt][1], xb[cur][mt][0], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][nt][0], xb[cur][mt][1], acc[mt][nt], 0, 0, 0);
+        }
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][nt][0], xb[cur][mt][0], acc[mt][nt], 0, 0, 0);
+      };
+      __builtin_amdgcn_sched_barrier(0);
+      mma(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (step + 1 < STEPS && !FF_ABL(64)) {
+        int sl = slot;
+        if (last) sl = slot + 1 == R ? 0 : slot + 1;
+        load_frags(cur ^ 1, step + 1, sl);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 1; i < 2 * NT; ++i) {
+        mma(i / NT, i % NT);
+        if (NS == 2) __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (last) {
+        if (W0) {                                    // group Gc+2 has landed before anyone passes the barrier into group Gc+1
+          if (Gc + R - 1 < total_groups) ff_wait_vm<(R - 3) * GLW>();
+          else ff_wait_vm<0>();
+        } else if (step == STEPS - 1 && more && !FF_ABL(2)) {
+          FF_TS();
+          store_patch(patch + ((s + 1) & 1) * FF_PATCH_BYTES);
+        }
+        if (!FF_ABL(32)) ff_barrier();
+        if (step == STEPS - 1) FF_TS();
+        ++Gc;
+        slot = slot + 1 == R ? 0 : slot + 1;
+      }
+    }
+  }
+
+  // ---- epilogue ----
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int RSRC_FLAGS = 0x00020000;
+  const float wunscale = 1.0f / C16_WSCALE;
+  const size_t tile_pix = img0 + (size_t)ty0 * kW + tx0;
+  const __amdgpu_buffer_rsrc_t out_r =
+      __builtin_amdgcn_make_buffer_rsrc(a_out + tile_pix * a_out_stride + a_out_coff, 0, OOB, RSRC_FLAGS);
+  const bool has_res = a_res != nullptr && !FF_ABL(8);
+  if (FF_ABL(16)) return;
+  const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(has_res ? a_res + tile_pix * kCout : a_out), 0, OOB, RSRC_FLAGS);
+  int opix[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) opix[mt] = (4 * wave + (p32 >> 3)) * kW + 8 * mt + (p32 & 7);
+  // every read before the first store (vmcnt retires in order and counts stores)
+  if (has_res) {
+    float4 rv[2][NT][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned off = (unsigned)(opix[mt] * kCout + c_lane + nt * 32 + q * 8) * 4u;
+          const uint4f u = __builtin_amdgcn_raw_buffer_load_b128(res_r, off, 0, 0);
+          rv[mt][nt][q] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+        }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[mt][nt][q * 4 + 0] = (acc[mt][nt][q * 4 + 0] * wunscale + rv[mt][nt][q].x) * a_out_scale;
+          acc[mt][nt][q * 4 + 1] = (acc[mt][nt][q * 4 + 1] * wunscale + rv[mt][nt][q].y) * a_out_scale;
+          acc[mt][nt][q * 4 + 2] = (acc[mt][nt][q * 4 + 2] * wunscale + rv[mt][nt][q].z) * a_out_scale;
+          acc[mt][nt][q * 4 + 3] = (acc[mt][nt][q * 4 + 3] * wunscale + rv[mt][nt][q].w) * a_out_scale;
+        }
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = acc[mt][nt][r] * wunscale * a_out_scale;
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint4f ov;
+        ov.x = __float_as_uint(acc[mt][nt][q * 4 + 0]); ov.y = __float_as_uint(acc[mt][nt][q * 4 + 1]);
+        ov.z = __float_as_uint(acc[mt][nt][q * 4 + 2]); ov.w = __float_as_uint(acc[mt][nt][q * 4 + 3]);
+        const unsigned off = (unsigned)(opix[mt] * a_out_stride + c_lane + nt * 32 + q * 8) * 4u;
+        __builtin_amdgcn_raw_buffer_store_b128(ov, out_r, off, 0, 0);
+      }
+
+  FF_TS();
+  // ---- GroupNorm partials of the written tile: (sum, sum of squares) per cout over its 256 pixels ----
+  if (a_stats) {
+    constexpr int NV = NT * 16;
+    float vs[NV], vq[NV];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float a0 = acc[0][nt][r], a1 = acc[1][nt][r];
+        vs[nt * 16 + r] = a0 + a1;
+        vq[nt * 16 + r] = a0 * a0 + a1 * a1;
+      }
+    // halving butterfly over the 32 pixel lanes of a K half: after the step of a lane bit a lane keeps the lower (bit clear)
+    // or upper (bit set) half of the values, summed with its partner's copy of that half
+    // lane bits 0 and 1 first (the two big steps: 24 + 12 values) - their partners sit in the same quad, so the exchange is a
+    // DPP quad_perm move at VALU rate; bits 2 and 3 (6 + 3 values) and the plain exchange over bit 4 go through ds_bpermute
+#define FF_HALVE(XCHG, BIT, H)                                                                   \
+    {                                                                                            \
+      const bool up = (lane >> BIT) & 1;                                                         \
+      _Pragma("unroll") for (int i = 0; i < H; ++i) {                                            \
+        const float ss = up ? vs[i] : vs[i + H], ks = up ? vs[i + H] : vs[i];                    \
+        const float sq = up ? vq[i] : vq[i + H], kq = up ? vq[i + H] : vq[i];                    \
+        vs[i] = ks + XCHG(ss, BIT);                                                              \
+        vq[i] = kq + XCHG(sq, BIT);                                                              \
+      }                                                                                          \
+    }
+#define FF_X_DPP(v, BIT) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), (BIT) == 0 ? 0xB1 : 0x4E, 0xF, 0xF, true))
+#define FF_X_SHFL(v, BIT) __shfl_xor(v, 1 << (BIT))
+    FF_HALVE(FF_X_DPP, 0, NV / 2)
+    FF_HALVE(FF_X_DPP, 1, NV / 4)
+    FF_HALVE(FF_X_SHFL, 2, NV / 8)
+    FF_HALVE(FF_X_SHFL, 3, NV / 16)
+#undef FF_HALVE
+#undef FF_X_DPP
+#undef FF_X_SHFL
+    constexpr int NF = NV / 16;                        // values left per lane (3 or 4); bit 0: plain exchange
+    float* const red = reinterpret_cast<float*>(smem);       // [4 waves][NT*32 couts][2] (the patch buffers are dead)
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      vs[i] += __shfl_xor(vs[i], 16);
+      vq[i] += __shfl_xor(vq[i], 16);
+    }
+    __syncthreads();                                   // everyone is done with the patch / ring
+    if ((lane & 16) == 0) {
+      const int sel = (lane & 1) * (NV / 2) + ((lane >> 1) & 1) * (NV / 4) + ((lane >> 2) & 1) * (NV / 8) +
+                      ((lane >> 3) & 1) * (NV / 16);
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int idx = sel + i;                       // = nt*16 + r
+        const int nt = idx >> 4, r = idx & 15;
+        const int cl = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        red[(wave * NT * 32 + cl) * 2 + 0] = vs[i];
+        red[(wave * NT * 32 + cl) * 2 + 1] = vq[i];
+      }
+    }
+    __syncthreads();
+    if (tid < NT * 32) {
+      double s = 0.0, q = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) {
+        s += (double)red[(wv * NT * 32 + tid) * 2 + 0];
+        q += (double)red[(wv * NT * 32 + tid) * 2 + 1];
+      }
+      double* dst = a_stats + ((size_t)tile * kCout + ng * NT * 32 + tid) * 2;
+      dst[0] = s;
+      dst[1] = q;
+    }
+  }
+  FF_TS();
+  FF_WALL(15);
+#undef FF_TS
+#undef FF_WALL
+#undef FF_ABL
+}
+
+long long* g_ff_dbg = nullptr;      // tuning aid: per-workgroup phase stamps (csd_debug_ff_timing + CSD_FF_ABL bit 7)
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static inline int ff_nt(int cout) { return 3; }      // (NT = 4, the nf = 128 nets: needs a register diet first - 256 VGPRs + spills today)
+
+bool convff_supported(const ConvPlan& p, int ns) {
+  if (getenv("CSD_NO_FF")) return false;
+  const int kc = ns == 1 ? 32 : 16;
+  return (ns == 1 || ns == 2) && p.taps == 9 && p.stride == 1 && p.up == 0 && p.pad == 1 && p.C0 > 0 && p.C0 % kc == 0 &&
+         p.C1 % kc == 0 && p.Cout % 96 == 0 && p.OH % FF_TILE == 0 && p.OW % FF_TILE == 0 &&
+         p.IH == p.OH && p.IW == p.OW;
+}
+
+size_t convff_packed_bytes(const ConvPlan& p, int ns) {
+  const int nt = ff_nt(p.Cout);
+  return (size_t)(p.Cout / (32 * nt)) * ((p.C0 + p.C1) / 16) * 9 * nt * ns * 1024 + 4096;
+}
+
+// weights in A-fragment order of v_mfma_f32_32x32x16_f16: [cout group][cin / 16][tap][cout tile][plane][lane][8 halves],
+// lane = (k half << 5) | cout row, scaled by 2^8 (exact) so the lo plane stays out of the fp16 subnormals
+__global__ void convff_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ wpack, int layout, int cin_src,
+                                   int cout_src, int cout_off, int Cin, int Cout, int ns, int nt) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)cout_src * Cin * 9;
+  if (idx >= total) return;
+  const int tap = (int)(idx % 9);
+  const int cin = (int)((idx / 9) % Cin);
+  const int co = (int)(idx / ((size_t)9 * Cin));
+  const int cout = cout_off + co;
+  if (cin >= cin_src || cout >= Cout) return;
+  const float v = ((layout == 0) ? w[((size_t)co * cin_src + cin) * 9 + tap]
+                   : (layout == 1) ? w[(size_t)cin * cout_src + co]
+                                   : w[((size_t)cin * cout_src + co) * 9 + (8 - tap)]) * C16_WSCALE;
+  const int gc = 32 * nt;
+  const int ng = cout / gc, t = (cout % gc) / 32, row = cout % 32;
+  const int kb = cin / 16, khalf = (cin % 16) / 8, e = cin % 8;
+  const size_t step = ((size_t)ng * (Cin / 16) + kb) * 9 + tap;
+  _Float16* dst = wpack + ((step * nt + t) * (size_t)ns) * 512 + (khalf * 32 + row) * 8 + e;
+  const _Float16 hi = (_Float16)v;
+  dst[0] = hi;
+  if (ns == 2) dst[512] = (_Float16)(v - (float)hi);
+}
+
+__global__ void convff_zero_kernel(uint32_t* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
+int convff_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int cin_src, int cout_src, int cout_off,
+                       void* wpack, hipStream_t s) {
+  const int Cin = p.C0 + p.C1;
+  if (cout_off == 0) {
+    const size_t n32 = convff_packed_bytes(p, ns) / 4;
+    hipLaunchKernelGGL(convff_zero_kernel, dim3((unsigned)cdiv64(n32, 256)), dim3(256), 0, s, (uint32_t*)wpack, n32);
+    CSD_LAUNCH_CHECK();
+  }
+  const size_t total = (size_t)cout_src * Cin * 9;
+  hipLaunchKernelGGL(convff_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w, (_Float16*)wpack, layout,
+                     cin_src, cout_src, cout_off, Cin, p.Cout, ns, ff_nt(p.Cout));
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+int convff_plan_tiles(ConvPlan* p, int ns) {
+  CSD_REQUIRE(convff_supported(*p, ns), "convff: unsupported shape (Cin=%d+%d Cout=%d %dx%d)", p->C0, p->C1, p->Cout, p->OH, p->OW);
+  p->KC = C16_KC;
+  p->CoutPad = p->Cout;
+  p->NT = ff_nt(p->Cout);
+  p->n_groups = p->Cout / (32 * p->NT);
+  p->KCS = ns == 1 ? 2 : 1;
+  p->LC = 0;
+  p->MT = 0;
+  p->TH = p->TW = FF_TILE;
+  p->PH = p->PW = FF_PW;
+  p->tiles_x = p->OW / FF_TILE;
+  p->tiles_y = p->B * p->OH / FF_TILE;
+  p->lds_bytes = 0;
+  return CSD_OK;
+}
+
+template <int NS, int NT>
+static int launch_ff(const ConvFFArgs& k, hipStream_t s) {
+  auto kern = conv_ff_kernel<NS, NT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+    if (getenv("CSD_FF_OCC")) {
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), FF_THREADS, FFCfg<NS, NT>::LDS);
+      fprintf(stderr, "conv_ff<%d,%d>: %d workgroups per CU (LDS %zu B)\n", NS, NT, nb, (size_t)FFCfg<NS, NT>::LDS);
+    }
+  }
+  size_t lds = FFCfg<NS, NT>::LDS;
+  if (getenv("CSD_FF_LDS_PAD")) lds += (size_t)atoi(getenv("CSD_FF_LDS_PAD"));      // tuning aid: forces one workgroup per CU
+  hipLaunchKernelGGL(kern, dim3(k.nblocks), dim3(FF_THREADS), lds, s, reinterpret_cast<const char*>(k.a.wpack), k);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
+  CSD_REQUIRE(convff_supported(p, ns), "convff: unsupported layer");
+  CSD_REQUIRE(!a.out_nchw && a.out_stride % 4 == 0 && a.out_coff % 4 == 0 && a.src0 && (p.C1 == 0 || a.src1),
+              "convff: NHWC fp32 output with 16-byte aligned rows, fp32 NHWC sources");
+  CSD_REQUIRE((a.nscale == nullptr) == (a.nshift == nullptr), "convff: scale and shift come together");
+  CSD_REQUIRE(a.nscale == nullptr || a.act == CSD_ACT_SWISH, "convff: the fused prologue implements GroupNorm + SiLU");
+  ConvFFArgs k;
+  k.a = a;
+  k.B = p.B; k.H = p.OH; k.W = p.OW; k.C0 = p.C0; k.C1 = p.C1; k.Cout = p.Cout;
+  k.tiles_x = p.OW / FF_TILE;
+  k.tpi = (p.OH / FF_TILE) * k.tiles_x;
+  k.n_groups = p.Cout / (32 * ff_nt(p.Cout));
+  k.nblocks = p.B * k.tpi * k.n_groups;
+  k.nstage = (p.C0 + p.C1) / (ns == 1 ? 32 : 16);
+  k.abl = getenv("CSD_FF_ABL") ? atoi(getenv("CSD_FF_ABL")) : 0;
+  k.a.dbg = (k.abl & 128) ? g_ff_dbg : nullptr;
+  const int nt = ff_nt(p.Cout);
+  (void)nt;
+  if (ns == 1) return launch_ff<1, 3>(k, s);
+  return launch_ff<2, 3>(k, s);
+}
+
+}  // namespace csd
+
+// tuning aid: buf = [4096 workgroups][2 waves][16] int64 clock stamps, filled by launches with CSD_FF_ABL bit 7 set
+extern "C" int csd_debug_ff_timing(void* buf) {
+  csd::g_ff_dbg = static_cast<long long*>(buf);
+  return 0;
+}

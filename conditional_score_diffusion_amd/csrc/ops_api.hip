@@ -184,6 +184,38 @@ extern "C" int csd_conv2d_ex(const float* x, const float* weight, const float* b
   return conv2d_impl(x, weight, bias, y, B, Cin, Cout, H, W, ksize, stride, pad_mode, up2, precision, layout, scratch, stream);
 }
 
+// ---- ResnetBlock convolution with the fused GroupNorm + SiLU prologue (conv_ff.hip) ---------------------------------
+extern "C" size_t csd_conv3x3_block_scratch_bytes(int Cin, int Cout) {
+  ConvPlan p;
+  memset(&p, 0, sizeof(p));
+  p.C0 = Cin; p.Cout = Cout;
+  return convff_packed_bytes(p, 2) + 256;
+}
+
+extern "C" int csd_conv3x3_block(const float* x0, const float* x1, const float* weight, const float* bias, const float* nscale,
+                                 const float* nshift, const float* temb, int temb_stride, const float* res, float out_scale,
+                                 float* y, double* stats, int B, int C0, int C1, int Cout, int H, int W, int precision,
+                                 void* scratch, void* stream) {
+  CSD_REQUIRE(x0 && weight && y && scratch, "conv3x3_block: null argument");
+  CSD_REQUIRE(precision == CSD_PREC_F16X3 || precision == CSD_PREC_F16, "conv3x3_block: precision must be fp16x3 or fp16");
+  hipStream_t s = (hipStream_t)stream;
+  const int ns = precision_ns(precision);
+  ConvPlan p;
+  memset(&p, 0, sizeof(p));
+  p.B = B; p.IH = p.OH = H; p.IW = p.OW = W; p.C0 = C0; p.C1 = C1; p.Cout = Cout; p.taps = 9; p.stride = 1; p.pad = 1; p.up = 0;
+  CSD_REQUIRE(convff_supported(p, ns), "conv3x3_block: unsupported shape (C %d+%d -> %d, %dx%d)", C0, C1, Cout, H, W);
+  int rc = convff_plan_tiles(&p, ns);
+  if (rc) return rc;
+  void* wpack = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(scratch) + 255) & ~(uintptr_t)255);
+  if ((rc = convff_pack_weight(p, ns, weight, 0, C0 + C1, Cout, 0, wpack, s))) return rc;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.src0 = x0; a.src1 = x1; a.wpack = static_cast<const float*>(wpack); a.bias = bias; a.temb = temb; a.res = res;
+  a.nscale = nscale; a.nshift = nshift; a.out = y; a.temb_stride = temb_stride; a.out_stride = Cout; a.out_coff = 0;
+  a.out_nchw = 0; a.act = CSD_ACT_SWISH; a.out_scale = out_scale; a.stats = stats; a.dbg = nullptr;
+  return convff_launch(p, ns, a, s);
+}
+
 // ---- attention ------------------------------------------------------------------------------------------
 extern "C" size_t csd_attention_scratch_bytes(int B, int C, int H, int W) {
   const size_t L = (size_t)H * W;

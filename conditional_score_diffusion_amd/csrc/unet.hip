@@ -90,6 +90,7 @@ struct PackedConv {
   int ns = 0;                    // 0: fp32 kernel layout; 1/2: fp16 kernel layout with ns planes
   bool pw = false;               // ns != 0 and the layer runs on the pointwise fp16 kernel (conv_pw16.hip)
   bool q = false;                // ns != 0 and the layer runs on the quad-wave fp16 kernel (conv_f16_q.hip)
+  bool ff = false;               // ns != 0 and the layer runs on the fused-prologue kernel (conv_ff.hip): fp32 sources, no gn_apply16
   struct Src { int param_w, param_b, layout, cout_src, cout_off, cin_src; };
   std::vector<Src> srcs;
 };
@@ -495,7 +496,16 @@ static int build_packed_layout(Net& n) {
     // (fp16 mode: the loader/consumer schedule wins on the GroupNorm-ed convs, the quad schedule on the resampling ones,
     // which would otherwise convert fp32 -> fp16 inside the old kernel's staging loop)
     const bool q_here = use_q || (net_ns == 1 && resample && !getenv("CSD_NO_Q"));
-    if (q_here && normed && stride1 && !(fused_norm && cur_res >= 64) && conv16q_supported(one, net_ns)) {
+    // fused-prologue schedule: GroupNorm-ed stride-1 convs whose 16 x 16 tiles lie inside one sample (reads the fp32 residual
+    // stream itself: the gn_apply16 pass and its fp16 planes disappear)
+    ConvPlan ffp = pc.proto;
+    ffp.IH = ffp.IW = ffp.OH = ffp.OW = cur_res;
+    if (net_ns && normed && stride1 && !resample && n.cfg.act == CSD_ACT_SWISH && convff_supported(ffp, net_ns)) {
+      pc.ns = net_ns;
+      pc.ff = true;
+      pc.proto.KC = 16;
+      pc.w_off = take(convff_packed_bytes(pc.proto, pc.ns) / sizeof(float) + 1);
+    } else if (q_here && normed && stride1 && !(fused_norm && cur_res >= 64) && conv16q_supported(one, net_ns)) {
       pc.ns = net_ns;
       pc.q = true;
       pc.proto.KC = 16;
@@ -816,7 +826,7 @@ struct Builder {
     o.cp.stride = stride; o.cp.pad = pad; o.cp.up = up;
     o.cp.OH = (ih << up) / stride; o.cp.OW = (iw << up) / stride;
     o.i4 = pc.ns;
-    o.i2 = pc.pw ? 1 : (pc.q ? 2 : 0);
+    o.i2 = pc.ff ? 3 : (pc.pw ? 1 : (pc.q ? 2 : 0));
     const int kcs = (pc.ns && !pc.pw && norm) ? conv16_kcs(pc.ns, o.cp.C0 + o.cp.C1) : 1;    // fp16-source convs stage in bursts
     bool fused = false;     // GroupNorm affine + activation applied by the conv's loader wave (no gn_apply16 pass)
     if (pc.ns && !pc.pw && !pc.q && norm && stride == 1 && !up && o.cp.C0 % 32 == 0 && o.cp.C1 % 32 == 0 &&
@@ -828,6 +838,9 @@ struct Builder {
       }
     }
     if (fused) {
+    } else if (pc.ff) {
+      if (external_nchw || !norm || stride != 1 || up) { set_error("fused-prologue conv on an unsupported layer"); rc = CSD_ERR_INVALID; return NONE; }
+      if (convff_plan_tiles(&o.cp, pc.ns)) { rc = CSD_ERR_INVALID; return NONE; }
     } else if (pc.q) {
       if (external_nchw || (!norm && o.cp.C1 != 0) || (stride == 2 && (norm || up))) { set_error("quad fp16 conv on an unsupported layer"); rc = CSD_ERR_INVALID; return NONE; }
       o.cp.C0 = o.cp.C0 + o.cp.C1; o.cp.C1 = 0;
@@ -842,7 +855,7 @@ struct Builder {
     o.d = norm ? nscale : NONE;
     o.e = norm ? nshift : NONE;
     size_t hi16 = NONE, lo16 = NONE;
-    if (pc.ns && !pc.pw && (norm || pc.q) && !fused) {
+    if (pc.ns && !pc.pw && !pc.ff && (norm || pc.q) && !fused) {
       // fp16 kernel: normalise + activate + split ONCE per element into fp16 planes, conv copies them
       // (a quad-schedule conv without a GroupNorm - Upsample, the FIR-resampled Conv_0 of NCSN++ - gets a plain split)
       const size_t nh = ((size_t)B * ih * iw * (o.cp.C0 + o.cp.C1) + 1) / 2;      // halves -> floats
@@ -1397,7 +1410,8 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         a.out_scale = o.fscale;
         a.dbg = nullptr;
         a.stats = reinterpret_cast<double*>(W(o.stats));
-        rc = o.i2 == 2 ? conv16q_launch(o.cp, o.i4, a, s)
+        rc = o.i2 == 3 ? convff_launch(o.cp, o.i4, a, s)
+           : o.i2 == 2 ? conv16q_launch(o.cp, o.i4, a, s)
            : o.i2 ? pw16_launch(o.cp, o.i4, a, s) : (o.i4 ? conv16_launch(o.cp, o.i4, a, s, o.i3 != 0) : conv_launch(o.cp, a, s));
         break;
       }
@@ -1457,7 +1471,9 @@ static int pack_all(Net& n, float* pk, hipStream_t s) {
       const int cin_src = src.cin_src > 0 ? src.cin_src : pc.proto.C0 + pc.proto.C1;
       ConvPlan one = pc.proto;
       one.C0 = pc.proto.C0 + pc.proto.C1; one.C1 = 0;
-      rc = pc.q ? conv16q_pack_weight(one, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
+      rc = pc.ff ? convff_pack_weight(pc.proto, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
+                                      src.cout_off, pk + pc.w_off, s)
+         : pc.q ? conv16q_pack_weight(one, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
                                       src.cout_off, pk + pc.w_off, s)
          : pc.pw ? pw16_pack_weight(pc.proto, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
                                     src.cout_off, pk + pc.w_off, s)

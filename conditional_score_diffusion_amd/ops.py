@@ -51,6 +51,32 @@ def conv2d(x, weight, bias=None, stride=1, downsample_pad=False, up2=False, prec
     return y
 
 
+def conv3x3_block(x0, weight, bias=None, x1=None, nscale=None, nshift=None, temb=None, res=None, out_scale=1.0,
+                  precision='fp16x3', want_stats=False):
+    """The ResnetBlock convolution with its prologue fused (models/layers.py:632-675): y = Conv3x3(SiLU(x*nscale + nshift))
+    (+ bias + temb[:, None, None, :] + res) * out_scale on NHWC fp32 tensors; x = x0 (| x1: virtual concat).  csd_conv3x3_block.
+    Returns y [B,H,W,Cout] (and the per-tile (sum, sum of squares) partials of y when ``want_stats``)."""
+    x0, weight = _c(x0, 'x0'), _c(weight, 'weight')
+    B, H, W, C0 = x0.shape
+    C1 = 0
+    if x1 is not None:
+        x1 = _c(x1, 'x1')
+        C1 = x1.shape[3]
+    Cout = weight.shape[0]
+    if tuple(weight.shape) != (Cout, C0 + C1, 3, 3):
+        raise RuntimeError('conv3x3_block: weight %s does not match %d input channels' % (tuple(weight.shape), C0 + C1))
+    opt = [None if t is None else _c(t, 't') for t in (bias, nscale, nshift, temb, res)]
+    bias, nscale, nshift, temb, res = opt
+    y = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x0.device)
+    stats = torch.empty(B * (H // 16) * (W // 16), Cout, 2, dtype=torch.float64, device=x0.device) if want_stats else None
+    sc = _scratch(lib().csd_conv3x3_block_scratch_bytes(C0 + C1, Cout), x0.device)
+    check(lib().csd_conv3x3_block(ptr(x0), ptr(x1), ptr(weight), ptr(bias), ptr(nscale), ptr(nshift), ptr(temb),
+                                  temb.shape[1] if temb is not None else 0, ptr(res), float(out_scale), ptr(y), ptr(stats),
+                                  B, C0, C1, Cout, H, W, _lib.PREC_IDS[precision], ptr(sc), current_stream(x0.device)),
+          'conv3x3_block')
+    return (y, stats) if want_stats else y
+
+
 def attention(q, k, v):
     """softmax(q.k C^-1/2) v over H*W positions (models/layers.py:584-588)."""
     q, k, v = _c(q, 'q'), _c(k, 'k'), _c(v, 'v')

@@ -301,6 +301,19 @@ int csd_ema_update(float* ema, const float* param, int64_t n, float decay, void*
  * NHWC forms of the training operators (csrc/train_nhwc.hip): the differentiable DDPM-family graph keeps activations in
  * the library's internal layout [B, H, W, C], so no layer pays an NCHW<->NHWC change.  Same kernels as above.
  * ---------------------------------------------------------------------------------------- */
+/* The ResnetBlock convolution with its prologue fused (csrc/conv_ff.hip; reference models/layers.py:632-675: Conv(act(GroupNorm(x)))
+ * [+ Dense(temb)] [+ x]): 3x3, stride 1, pad 1 on NHWC fp32 tensors.  x0 [B,H,W,C0] (+ x1 [B,H,W,C1] or NULL: virtual concat),
+ * H % 16 == 0, W % 16 == 0, C0 / C1 multiples of 32, Cout a multiple of 96; weight OIHW [Cout, C0+C1, 3, 3]; nscale / nshift
+ * [B, C0+C1] = the GroupNorm's per-(sample, channel) rstd*gamma and beta - mean*rstd*gamma, applied as SiLU(x*scale + shift)
+ * while the operand is staged (both NULL: the convolution reads x as it is); temb [B, temb_stride] or NULL (column c of sample b
+ * is added to cout c), res [B,H,W,Cout] or NULL (added), out_scale multiplies the result.  stats (or NULL):
+ * [B*(H/16)*(W/16)][Cout][2] doubles = per-tile (sum, sum of squares) of the written tensor.  precision: CSD_PREC_F16X3 or
+ * CSD_PREC_F16.  scratch holds the packed weight: csd_conv3x3_block_scratch_bytes(C0 + C1, Cout). */
+size_t csd_conv3x3_block_scratch_bytes(int Cin, int Cout);
+int csd_conv3x3_block(const float* x0, const float* x1, const float* weight, const float* bias, const float* nscale,
+                      const float* nshift, const float* temb, int temb_stride, const float* res, float out_scale, float* y,
+                      double* stats, int B, int C0, int C1, int Cout, int H, int W, int precision, void* scratch, void* stream);
+
 /* csd_conv2d / csd_conv2d_wgrad with layout flags: bit 0 = first tensor operand (x) is NHWC, bit 1 = second (y resp. dy) is
  * NHWC.  An NHWC x needs Cin % 8 == 0.  csd_conv2d_ex bit 2: `weight` is the OIHW weight [Cin, Cout, k, k] of the TRANSPOSED
  * convolution and is applied transposed + spatially flipped (the data gradient, without materialising that weight).

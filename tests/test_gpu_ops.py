@@ -276,3 +276,66 @@ def test_up_or_down_sampling_module_vs_oracle():
     ref = torch.nn.functional.conv2d(so.upfirdn2d_ref(x, kern, pad=(2, 2)), w, stride=2)
     got = U.conv_downsample_2d(xd, w.to(dev), k)
     assert got.shape == ref.shape and (got.cpu() - ref).abs().max() <= 1e-5 * ref.abs().max()
+
+
+@pytest.mark.parametrize('precision,tol', [('fp16x3', 3e-6), ('fp16', 2e-3)])
+@pytest.mark.parametrize('B,C0,C1,Cout,H,W,norm,temb,res', [
+    (2, 96, 0, 96, 32, 32, True, True, False),       # ResnetBlock Conv_0: GroupNorm + SiLU prologue, + Dense(temb)
+    (3, 96, 96, 96, 16, 48, True, False, True),      # up-path block: virtual concat of two sources, residual, odd batch
+    (1, 64, 32, 192, 32, 16, True, True, True),      # two cout groups, unequal sources
+    (2, 32, 0, 96, 16, 16, False, False, False),     # no GroupNorm: the convolution reads x as it is
+])
+def test_conv3x3_block_fused_prologue(B, C0, C1, Cout, H, W, norm, temb, res, precision, tol):
+    """csd_conv3x3_block (csrc/conv_ff.hip) = Conv3x3(SiLU(x*scale + shift)) + bias + temb + res, and its per-tile
+    GroupNorm partials, against fp64 torch (reference models/layers.py:632-675)"""
+    from conditional_score_diffusion_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + C0 + Cout + H)
+    Cin = C0 + C1
+    x = torch.randn(B, H, W, Cin, generator=g) * 2.0 + 0.3
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    bias = torch.randn(Cout, generator=g)
+    sc = torch.rand(B, Cin, generator=g) + 0.5 if norm else None
+    sh = torch.randn(B, Cin, generator=g) * 0.5 if norm else None
+    tv = torch.randn(B, Cout + 32, generator=g) if temb else None
+    rv = torch.randn(B, H, W, Cout, generator=g) * 3.0 if res else None
+    d = dev()
+    x0 = x[..., :C0].contiguous().to(d)
+    x1 = x[..., C0:].contiguous().to(d) if C1 else None
+    tgpu = tv.to(d)[:, 16:] if temb else None           # (a column window of a wider table, like dense_all in the network)
+    opt = lambda t: None if t is None else t.to(d)      # noqa: E731
+    if temb:
+        # the wrapper makes its inputs contiguous, which would drop the row stride: call the C ABI through a strided view
+        from conditional_score_diffusion_amd import _lib
+        from conditional_score_diffusion_amd._lib import check, current_stream, lib, ptr
+        y = torch.empty(B, H, W, Cout, device=d)
+        stats = torch.empty(B * (H // 16) * (W // 16), Cout, 2, dtype=torch.float64, device=d)
+        scr = torch.empty(lib().csd_conv3x3_block_scratch_bytes(Cin, Cout), dtype=torch.uint8, device=d)
+        tfull = tv.to(d)
+        tptr = tfull.data_ptr() + 16 * 4
+        import ctypes
+        wd, bd, scd, shd, rd = w.to(d), bias.to(d), opt(sc), opt(sh), opt(rv)      # (keep the device copies alive over the call)
+        check(lib().csd_conv3x3_block(ptr(x0), ptr(x1), ptr(wd), ptr(bd), ptr(scd), ptr(shd),
+                                      ctypes.c_void_p(tptr), tfull.shape[1], ptr(rd), 0.5, ptr(y), ptr(stats), B, C0, C1, Cout,
+                                      H, W, _lib.PREC_IDS[precision], ptr(scr), current_stream(d)), 'conv3x3_block')
+        torch.cuda.synchronize()
+        tref = tv[:, 16:16 + Cout]
+    else:
+        y, stats = ops.conv3x3_block(x0, w.to(d), bias.to(d), x1=x1, nscale=opt(sc), nshift=opt(sh), res=opt(rv), out_scale=0.5,
+                                     precision=precision, want_stats=True)
+        tref = None
+    xd = x.double()
+    if norm:
+        xd = torch.nn.functional.silu(xd * sc.double()[:, None, None, :] + sh.double()[:, None, None, :])
+    ref = torch.nn.functional.conv2d(xd.permute(0, 3, 1, 2), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+    if tref is not None:
+        ref = ref + tref.double()[:, None, None, :]
+    if rv is not None:
+        ref = ref + rv.double()
+    ref = ref * 0.5
+    err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < tol, err
+    # per-tile partials: (sum, sum of squares) of the tile's 256 pixels per cout, tiles in (sample, tile row, tile col) order
+    yt = y.cpu().double().reshape(B, H // 16, 16, W // 16, 16, Cout).permute(0, 1, 3, 2, 4, 5).reshape(-1, 256, Cout)
+    st = stats.cpu()
+    assert (st[:, :, 0] - yt.sum(1)).abs().max().item() < 1e-4 * yt.abs().sum(1).max().item()
+    assert (st[:, :, 1] - (yt * yt).sum(1)).abs().max().item() < 1e-5 * (yt * yt).sum(1).max().item()
