@@ -102,6 +102,47 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(float* __restrict_
   }
 }
 
+// global-norm exactness mode: sums[0] = sum_b ||net_b||/std, sums[1] = sum_b ||z_b|| over THIS rank's samples,
+// fp32 like the reference's torch.norm(...).mean() operands; the caller all-reduces the two floats over the ranks
+__global__ __launch_bounds__(64) void norm_sums_kernel(const double* __restrict__ partial, int nchunk, float std, int B,
+                                                       float* __restrict__ sums) {
+  double g = 0, n = 0;
+  for (int b = threadIdx.x; b < B; b += 64) {
+    double sa = 0, sb = 0;
+    for (int c = 0; c < nchunk; ++c) {
+      sa += partial[((size_t)b * nchunk + c) * 2 + 0];
+      sb += partial[((size_t)b * nchunk + c) * 2 + 1];
+    }
+    g += sqrt(sa) / (double)std;
+    n += sqrt(sb);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    g += __shfl_xor(g, off);
+    n += __shfl_xor(n, off);
+  }
+  if (threadIdx.x == 0) { sums[0] = (float)g; sums[1] = (float)n; }
+}
+
+// the Langevin update with the step size of the GLOBAL batch: gbar = sums[0] / Bg, nbar = sums[1] / Bg
+__global__ __launch_bounds__(256) void langevin_update_global_kernel(float* __restrict__ x, float* __restrict__ x_mean,
+                                                                     const float* __restrict__ net, int64_t net_stride,
+                                                                     const float* __restrict__ z,
+                                                                     const float* __restrict__ sums, int Bg, float std,
+                                                                     float snr, int64_t per, size_t total) {
+  const float gbar = sums[0] / (float)Bg, nbar = sums[1] / (float)Bg;
+  const float r = snr * nbar / gbar;
+  const float step = r * r * 2.f;
+  const float nz = sqrtf(step * 2.f);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / (size_t)per;
+    const float score = net[b * net_stride + (i - b * per)] / std;
+    const float xm = x[i] + step * score;
+    x_mean[i] = xm;
+    x[i] = xm + nz * z[i];
+  }
+}
+
 __global__ __launch_bounds__(256) void reverse_diffusion_update_kernel(float* __restrict__ x,
                                                                        float* __restrict__ x_mean,
                                                                        const float* __restrict__ net,
@@ -217,6 +258,21 @@ int langevin_update_launch(float* x, float* x_mean, const float* net, int64_t ne
   const size_t total = (size_t)B * per;
   hipLaunchKernelGGL(langevin_update_kernel, dim3(ew_grid(total)), dim3(256), 0, s, x, x_mean, net, net_stride, z,
                      partial, nchunk, std, snr, B, per, total);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+int norm_sums_launch(const double* partial, int nchunk, float std, int B, float* sums, hipStream_t s) {
+  hipLaunchKernelGGL(norm_sums_kernel, dim3(1), dim3(64), 0, s, partial, nchunk, std, B, sums);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+int langevin_update_global_launch(float* x, float* x_mean, const float* net, int64_t net_stride, const float* z,
+                                  const float* sums, int Bg, float std, float snr, int B, int64_t per, hipStream_t s) {
+  const size_t total = (size_t)B * per;
+  hipLaunchKernelGGL(langevin_update_global_kernel, dim3(ew_grid(total)), dim3(256), 0, s, x, x_mean, net, net_stride, z,
+                     sums, Bg, std, snr, per, total);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }

@@ -1656,74 +1656,150 @@ __global__ void fill_labels_kernel(float* dst, float v, int B) {
   if (i < B) dst[i] = v;
 }
 
-extern "C" int csd_pc_sample(csd_unet* net, const void* packed, void* workspace, size_t workspace_bytes,
-                             void* scratch, size_t scratch_bytes, float* x, const float* y, int B,
-                             const csd_pc_params* p, void* stream) {
+// one validated view of a csd_pc_* call: scratch carved up, noise bookkeeping per step
+struct PCCtx {
+  Net* n; Plan* pl; const float* pk; float* ws;
+  float *net_out, *x_mean, *z, *zy, *labels;
+  double* partial;
+  const csd_pc_params* p;
+  float* x; const float* y;
+  int B, nchunk;
+  size_t nx, ny;
+  int64_t per, net_stride;
+  bool perturb_y;
+  hipStream_t s;
+  int draws_per_step() const { return perturb_y ? 4 : 2; }
+  // draw k (0-based) of step i: from the tape (reference order) or Philox stream 1 + i*draws + k (stream 0 is the prior)
+  const float* noise(int i, int k, float* dst, size_t n) const {
+    if (p->noise_tape) {
+      // tape layout per step: [zy_c] z_c [zy_p] z_p
+      size_t off = (size_t)i * (2 * nx + (perturb_y ? 2 * ny : 0));
+      const size_t sizes[4] = {perturb_y ? ny : nx, perturb_y ? nx : nx, ny, nx};
+      for (int j = 0; j < k; ++j) off += sizes[j];
+      return p->noise_tape + off;
+    }
+    if (randn_launch(dst, (int64_t)n, p->seed, (uint64_t)1 + (uint64_t)i * draws_per_step() + k, s)) return nullptr;
+    return dst;
+  }
+};
+
+static int pc_setup(PCCtx* c, csd_unet* net, const void* packed, void* workspace, size_t workspace_bytes, void* scratch,
+                    size_t scratch_bytes, float* x, const float* y, int B, const csd_pc_params* p, void* stream) {
   Plan* pl = nullptr;
   int rc = check_forward_args(net, packed, workspace, workspace_bytes, B, &pl);
   if (rc) return rc;
   CSD_REQUIRE(p && x && scratch, "pc_sample: null argument");
   CSD_REQUIRE(p->n_steps >= 1 && p->labels && p->std_x && p->G, "pc_sample: per-step scalar arrays missing");
-  const csd_unet_config& c = net->net.cfg;
-  CSD_REQUIRE((c.y_channels == 0) == (y == nullptr), "pc_sample: y must be given iff y_channels > 0");
-  CSD_REQUIRE(!(p->std_y && c.y_channels == 0), "pc_sample: std_y given for an unconditional network");
+  const csd_unet_config& cf = net->net.cfg;
+  CSD_REQUIRE((cf.y_channels == 0) == (y == nullptr), "pc_sample: y must be given iff y_channels > 0");
+  CSD_REQUIRE(!(p->std_y && cf.y_channels == 0), "pc_sample: std_y given for an unconditional network");
   if (scratch_bytes < csd_pc_scratch_bytes(net, B)) {
     set_error("pc_sample: scratch too small");
     return CSD_ERR_WORKSPACE;
   }
   CSD_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 255) == 0, "pc_sample: scratch must be 256-byte aligned");
-  hipStream_t s = (hipStream_t)stream;
-  const size_t hw = (size_t)c.image_size * c.image_size;
-  const size_t nx = (size_t)B * c.x_channels * hw, ny = (size_t)B * c.y_channels * hw;
-  const size_t no = (size_t)B * c.out_channels * hw;
+  const size_t hw = (size_t)cf.image_size * cf.image_size;
+  c->n = &net->net; c->pl = pl; c->pk = static_cast<const float*>(packed); c->ws = static_cast<float*>(workspace);
+  c->p = p; c->x = x; c->y = y; c->B = B; c->s = (hipStream_t)stream;
+  c->nx = (size_t)B * cf.x_channels * hw; c->ny = (size_t)B * cf.y_channels * hw;
+  const size_t no = (size_t)B * cf.out_channels * hw;
   float* f = static_cast<float*>(scratch);
-  float* net_out = f; f += align_up(no, 64);
-  float* x_mean = f; f += align_up(nx, 64);
-  float* z = f; f += align_up(nx, 64);
-  float* zy = f; f += align_up(std::max(ny, (size_t)B * hw), 64);
-  float* labels = f; f += align_up((size_t)B, 64);
-  double* partial = reinterpret_cast<double*>(f);
-  const int64_t per = (int64_t)c.x_channels * hw;
-  const int nchunk = sumsq_nchunk(per);
-  const bool perturb_y = p->std_y != nullptr;
-  // paired networks emit [score_x | score_y] per sample: the x block of sample b starts at
-  // b*out_channels*hw, which the update kernels take as `net_stride`.
-  const int64_t net_stride = (int64_t)c.out_channels * hw;
-  const float* tape = p->noise_tape;
-  uint64_t draw = 1;   // draw 0 is the prior, owned by the caller
-  auto next_noise = [&](float* dst, size_t n) -> const float* {
-    if (tape) { const float* r = tape; tape += n; return r; }
-    randn_launch(dst, (int64_t)n, p->seed, draw, s);
-    ++draw;
-    return dst;
-  };
-  const float* pk = static_cast<const float*>(packed);
-  float* ws = static_cast<float*>(workspace);
-  for (int i = 0; i < p->n_steps; ++i) {
-    g_prof.step_on = (i % g_prof.step_stride) == 0;
-    hipLaunchKernelGGL(fill_labels_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, labels, p->labels[i], B);
-    CSD_LAUNCH_CHECK();
-    for (int phase = 0; phase < 2; ++phase) {   // corrector, then predictor (sampling/conditional.py:208-211)
-      const float* zyp = nullptr;
-      if (perturb_y) zyp = next_noise(zy, ny);
-      rc = run_plan(net->net, *pl, pk, ws, x, y, labels, net_out, zyp, perturb_y ? p->std_y[i] : 0.f, s);
-      if (rc) return rc;
-      const float* zp = next_noise(z, nx);
-      ProfScope prof(CSD_PROF_SAMPLER, 0, 8.0 * nx * 4, s);
-      if (phase == 0) {
-        if ((rc = sumsq_rows_launch(net_out, net_stride, zp, partial, B, per, nchunk, s))) return rc;
-        rc = langevin_update_launch(x, x_mean, net_out, net_stride, zp, partial, nchunk, p->std_x[i], p->snr, B,
-                                    per, s);
-      } else {
-        rc = reverse_diffusion_update_launch(x, x_mean, net_out, net_stride, zp, p->std_x[i], p->G[i], B, per, s);
-      }
-      if (rc) return rc;
+  c->net_out = f; f += align_up(no, 64);
+  c->x_mean = f; f += align_up(c->nx, 64);
+  c->z = f; f += align_up(c->nx, 64);
+  c->zy = f; f += align_up(std::max(c->ny, (size_t)B * hw), 64);
+  c->labels = f; f += align_up((size_t)B, 64);
+  c->partial = reinterpret_cast<double*>(f);
+  c->per = (int64_t)cf.x_channels * hw;
+  c->nchunk = sumsq_nchunk(c->per);
+  c->perturb_y = p->std_y != nullptr;
+  // paired networks emit [score_x | score_y] per sample: the x block of sample b starts at b*out_channels*hw
+  c->net_stride = (int64_t)cf.out_channels * hw;
+  return CSD_OK;
+}
+
+// phase 0: corrector (sampling/conditional.py:208-209), phase 1: predictor (:211).  part bit 0: network + noise + (corrector:
+// norm partials); bit 1: the update.  norm_sums != null: the corrector's step size comes from those two (all-reduced) sums.
+static int pc_phase(const PCCtx& c, int i, int phase, int part, float* sums_out, const float* sums_in, int Bg) {
+  int rc;
+  const csd_pc_params* p = c.p;
+  const int k0 = phase * (c.perturb_y ? 2 : 1);
+  const float* zp = c.p->noise_tape ? c.noise(i, k0 + (c.perturb_y ? 1 : 0), nullptr, c.nx) : c.z;
+  if (part & 1) {
+    if (phase == 0) {
+      hipLaunchKernelGGL(fill_labels_kernel, dim3(cdiv(c.B, 256)), dim3(256), 0, c.s, c.labels, p->labels[i], c.B);
+      CSD_LAUNCH_CHECK();
     }
-    if (p->record) {
-      CSD_CHECK_HIP(hipMemcpyAsync(p->record + (size_t)i * nx, x, nx * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const float* zyp = nullptr;
+    if (c.perturb_y) { zyp = c.noise(i, k0, c.zy, c.ny); if (!zyp) return CSD_ERR_HIP; }
+    rc = run_plan(*c.n, *c.pl, c.pk, c.ws, c.x, c.y, c.labels, c.net_out, zyp, c.perturb_y ? p->std_y[i] : 0.f, c.s);
+    if (rc) return rc;
+    zp = c.noise(i, k0 + (c.perturb_y ? 1 : 0), c.z, c.nx);
+    if (!zp) return CSD_ERR_HIP;
+    if (phase == 0) {
+      ProfScope prof(CSD_PROF_SAMPLER, 0, 2.0 * c.nx * 4, c.s);
+      if ((rc = sumsq_rows_launch(c.net_out, c.net_stride, zp, c.partial, c.B, c.per, c.nchunk, c.s))) return rc;
+      if (sums_out && (rc = norm_sums_launch(c.partial, c.nchunk, p->std_x[i], c.B, sums_out, c.s))) return rc;
     }
   }
-  g_prof.step_on = true;
-  if (p->denoise) CSD_CHECK_HIP(hipMemcpyAsync(x, x_mean, nx * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (part & 2) {
+    ProfScope prof(CSD_PROF_SAMPLER, 0, 6.0 * c.nx * 4, c.s);
+    if (phase == 0) {
+      rc = sums_in ? langevin_update_global_launch(c.x, c.x_mean, c.net_out, c.net_stride, zp, sums_in, Bg, p->std_x[i], p->snr,
+                                                   c.B, c.per, c.s)
+                   : langevin_update_launch(c.x, c.x_mean, c.net_out, c.net_stride, zp, c.partial, c.nchunk, p->std_x[i],
+                                            p->snr, c.B, c.per, c.s);
+    } else {
+      rc = reverse_diffusion_update_launch(c.x, c.x_mean, c.net_out, c.net_stride, zp, p->std_x[i], p->G[i], c.B, c.per, c.s);
+    }
+    if (rc) return rc;
+  }
   return CSD_OK;
+}
+
+static int pc_step_tail(const PCCtx& c, int i) {
+  const csd_pc_params* p = c.p;
+  if (p->record)
+    CSD_CHECK_HIP(hipMemcpyAsync(p->record + (size_t)i * c.nx, c.x, c.nx * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+  if (i == p->n_steps - 1 && p->denoise)
+    CSD_CHECK_HIP(hipMemcpyAsync(c.x, c.x_mean, c.nx * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+  return CSD_OK;
+}
+
+extern "C" int csd_pc_sample(csd_unet* net, const void* packed, void* workspace, size_t workspace_bytes,
+                             void* scratch, size_t scratch_bytes, float* x, const float* y, int B,
+                             const csd_pc_params* p, void* stream) {
+  PCCtx c;
+  int rc = pc_setup(&c, net, packed, workspace, workspace_bytes, scratch, scratch_bytes, x, y, B, p, stream);
+  if (rc) return rc;
+  for (int i = 0; i < p->n_steps; ++i) {
+    g_prof.step_on = (i % g_prof.step_stride) == 0;
+    for (int phase = 0; phase < 2; ++phase)     // corrector, then predictor (sampling/conditional.py:208-211)
+      if ((rc = pc_phase(c, i, phase, 3, nullptr, nullptr, 0))) return rc;
+    if ((rc = pc_step_tail(c, i))) return rc;
+  }
+  g_prof.step_on = true;
+  return CSD_OK;
+}
+
+extern "C" int csd_pc_step_begin(csd_unet* net, const void* packed, void* workspace, size_t workspace_bytes, void* scratch,
+                                 size_t scratch_bytes, float* x, const float* y, int B, const csd_pc_params* p, int step,
+                                 float* norm_sums, void* stream) {
+  PCCtx c;
+  int rc = pc_setup(&c, net, packed, workspace, workspace_bytes, scratch, scratch_bytes, x, y, B, p, stream);
+  if (rc) return rc;
+  CSD_REQUIRE(norm_sums && step >= 0 && step < p->n_steps, "pc_step_begin: bad step %d / null norm_sums", step);
+  return pc_phase(c, step, 0, 1, norm_sums, nullptr, 0);
+}
+
+extern "C" int csd_pc_step_end(csd_unet* net, const void* packed, void* workspace, size_t workspace_bytes, void* scratch,
+                               size_t scratch_bytes, float* x, const float* y, int B, const csd_pc_params* p, int step,
+                               const float* norm_sums, int global_batch, void* stream) {
+  PCCtx c;
+  int rc = pc_setup(&c, net, packed, workspace, workspace_bytes, scratch, scratch_bytes, x, y, B, p, stream);
+  if (rc) return rc;
+  CSD_REQUIRE(norm_sums && global_batch >= B && step >= 0 && step < p->n_steps, "pc_step_end: bad arguments");
+  if ((rc = pc_phase(c, step, 0, 2, nullptr, norm_sums, global_batch))) return rc;
+  if ((rc = pc_phase(c, step, 1, 3, nullptr, nullptr, 0))) return rc;
+  return pc_step_tail(c, step);
 }

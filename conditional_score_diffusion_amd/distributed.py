@@ -7,9 +7,12 @@ image's trajectory is independent, so the condition batch ``y`` is cut into cont
 shards, each rank runs the fused PC loop on its shard with NO per-step communication, and ONE
 ``all_gather`` (direct one-hop over xGMI: 2.4 MB per rank at 8 x 160^2 images) collects the result.
 
-Exactness ("per-shard" mode): the Langevin step size uses batch-mean norms
-(sampling/correctors.py:102-104), so a sharded run equals the reference run independently per
-shard - which is exactly what Lightning-DDP testing does - not one process with the global batch.
+Exactness: the Langevin step size uses batch-mean norms (sampling/correctors.py:102-104).
+* "per-shard" mode (default): a sharded run equals the reference run independently per shard - which is exactly
+  what Lightning-DDP testing does; no per-step communication at all.
+* "global-norm" mode (``global_norm=True``): identical to ONE reference process holding the global batch - every
+  PC step all-reduces two fp32 sums (8 bytes, RCCL) between the library's csd_pc_step_begin / csd_pc_step_end
+  calls (sampling/fused.py); everything stays on the device, the host never waits.
 """
 import torch
 import torch.distributed as dist
@@ -28,7 +31,7 @@ def rank_seed(seed, rank):
     return (int(seed) * 1000003 + 7919 * int(rank)) & 0x7FFFFFFFFFFFFFFF
 
 
-def sample_sharded(sampler, model, y_global=None, n_total=None, seed=None, group=None, **sampler_kw):
+def sample_sharded(sampler, model, y_global=None, n_total=None, seed=None, group=None, global_norm=False, **sampler_kw):
     """Run ``sampler`` on this rank's shard and all-gather the samples.
 
     sampler : ``fn(model, y_shard, seed=..., **kw) -> (x, info)`` for conditional sampling (as returned
@@ -40,6 +43,11 @@ def sample_sharded(sampler, model, y_global=None, n_total=None, seed=None, group
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if seed is None:        # a fresh base key per call from torch's generator (rank_seed keeps the ranks' streams distinct)
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    if global_norm and world > 1:
+        n_global = y_global.shape[0] if y_global is not None else n_total
+        if not n_global:
+            raise ValueError('global-norm mode needs the global batch size (y_global or n_total)')
+        sampler_kw['global_norm'] = (lambda sums: dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group), int(n_global))
     if y_global is not None:
         lo, hi = shard_bounds(y_global.shape[0], rank, world)
         x_local, info = sampler(model, y_global[lo:hi].contiguous(), seed=rank_seed(seed, rank), **sampler_kw)

@@ -123,10 +123,10 @@ def get_pc_conditional_sampler(sde, shape, predictor, corrector, snr, p_steps, c
     if use_path:
         return path_sampler
 
-    def pc_conditional_sampler(model, y, show_evolution=False, noise_tape=None, seed=None):
+    def pc_conditional_sampler(model, y, show_evolution=False, noise_tape=None, seed=None, global_norm=None):
         if fused.fusable(model, sde, predictor, corrector, c_steps, probability_flow, continuous):
             x, rec, _ = fused.run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=noise_tape,
-                                  seed=seed, record=show_evolution)
+                                  seed=seed, record=show_evolution, global_norm=global_norm)
             if show_evolution:
                 return x, {'evolution': {'x': rec.cpu(), 'y': None}}
             return x, {}

@@ -54,8 +54,15 @@ def fresh_seed():
 
 
 def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=None, record=False,
-        unconditional_label=None):
-    """Run the fused loop; returns (samples, record_or_None, timesteps).  ``seed=None``: a fresh key per call (fresh_seed)."""
+        unconditional_label=None, global_norm=None):
+    """Run the fused loop; returns (samples, record_or_None, timesteps).  ``seed=None``: a fresh key per call (fresh_seed).
+
+    ``global_norm``: None = the Langevin step size uses the batch means of THIS call's batch (the reference run on this batch;
+    one library call enqueues the whole loop).  Otherwise ``(reduce_fn, global_batch)``: the batch is one shard of a larger one
+    and the step size must use the means over the GLOBAL batch (identical to one reference process holding all of it,
+    sampling/correctors.py:100-106): every PC step is enqueued as csd_pc_step_begin -> ``reduce_fn(sums)`` -> csd_pc_step_end,
+    where ``sums`` is a 2-float device tensor and ``reduce_fn`` adds the other shards' sums into it in place (an 8-byte
+    ``torch.distributed.all_reduce``) - no host synchronisation anywhere."""
     if seed is None:
         seed = fresh_seed()
     c_sde = sde['x'] if isinstance(sde, dict) else sde
@@ -96,9 +103,19 @@ def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=
     p.seed = int(seed)
     p.record = rec.data_ptr() if rec is not None else None
     yy = y.contiguous() if y is not None else None
-    check(lib().csd_pc_sample(model._h, ptr(model._packed), ptr(ws), ws.numel(), ptr(scratch), scratch.numel(),
-                              ptr(x), ptr(yy) if yy is not None else None, B, ctypes.byref(p),
-                              current_stream(dev)), 'pc_sample')
+    if global_norm is None:
+        check(lib().csd_pc_sample(model._h, ptr(model._packed), ptr(ws), ws.numel(), ptr(scratch), scratch.numel(),
+                                  ptr(x), ptr(yy) if yy is not None else None, B, ctypes.byref(p),
+                                  current_stream(dev)), 'pc_sample')
+    else:
+        reduce_fn, global_batch = global_norm
+        sums = torch.zeros(2, dtype=torch.float32, device=dev)
+        args = (model._h, ptr(model._packed), ptr(ws), ws.numel(), ptr(scratch), scratch.numel(), ptr(x),
+                ptr(yy) if yy is not None else None, B, ctypes.byref(p))
+        for i in range(p_steps):
+            check(lib().csd_pc_step_begin(*args, i, ptr(sums), current_stream(dev)), 'pc_step_begin')
+            reduce_fn(sums)
+            check(lib().csd_pc_step_end(*args, i, ptr(sums), int(global_batch), current_stream(dev)), 'pc_step_end')
     # keep the host arrays alive until the enqueue returned (they are read at enqueue time only)
     del labels, std_x, G, std_y
     return x, rec, ts

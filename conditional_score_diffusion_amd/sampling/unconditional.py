@@ -153,12 +153,12 @@ def get_pc_sampler(sde, shape, predictor, corrector, snr, p_steps, c_steps, prob
     corr_fn = functools.partial(shared_corrector_update_fn, sde=sde, corrector=corrector, continuous=continuous,
                                 snr=snr, n_steps=c_steps)
 
-    def pc_sampler(model, show_evolution=False, noise_tape=None, seed=None):
+    def pc_sampler(model, show_evolution=False, noise_tape=None, seed=None, global_norm=None):
         steps = p_steps * (c_steps + 1)
         if fused.fusable(model, sde, predictor, corrector, c_steps, probability_flow, continuous):
             label = 'fourier' if getattr(model, 'embedding_type', 'positional') == 'fourier' else 'sigma'
             x, rec, ts = fused.run(model, sde, shape, None, p_steps, snr, eps, denoise, noise_tape=noise_tape,
-                                   seed=seed, record=show_evolution, unconditional_label=label)
+                                   seed=seed, record=show_evolution, unconditional_label=label, global_norm=global_norm)
             info = {'times': ts, 'steps': steps}
             if show_evolution:
                 info['evolution'] = rec.cpu()

@@ -164,6 +164,21 @@ size_t csd_pc_scratch_bytes(const csd_unet* net, int B);
 int csd_pc_sample(csd_unet* net, const void* packed, void* workspace, size_t workspace_bytes,
                   void* scratch, size_t scratch_bytes, float* x, const float* y, int B,
                   const csd_pc_params* p, void* stream);
+/* The same loop one PC step at a time, for the GLOBAL-NORM exactness mode of batch-sharded sampling (identical to
+ * ONE reference process holding the global batch; the Langevin step size uses batch-mean norms, sampling/correctors.py:100-106).
+ *   csd_pc_step_begin(step): corrector network evaluation + its noise draw; norm_sums[0] = sum_b ||score_b||_2 and
+ *                            norm_sums[1] = sum_b ||z_b||_2 over THIS rank's B samples (two fp32 on the device).
+ *   -- the caller all-reduces (SUM) the two floats over the ranks: one 8-byte RCCL collective, no host synchronisation --
+ *   csd_pc_step_end(step):   Langevin update with gbar = norm_sums[0] / global_batch, nbar = norm_sums[1] / global_batch,
+ *                            then the predictor half of the step; after the last step x holds x_mean when p->denoise.
+ * Same params / scratch / noise order as csd_pc_sample (with global_batch == B and no all-reduce the two calls per step
+ * reproduce it); p->record is honoured. */
+int csd_pc_step_begin(csd_unet* net, const void* packed, void* workspace, size_t workspace_bytes, void* scratch,
+                      size_t scratch_bytes, float* x, const float* y, int B, const csd_pc_params* p, int step,
+                      float* norm_sums, void* stream);
+int csd_pc_step_end(csd_unet* net, const void* packed, void* workspace, size_t workspace_bytes, void* scratch,
+                    size_t scratch_bytes, float* x, const float* y, int B, const csd_pc_params* p, int step,
+                    const float* norm_sums, int global_batch, void* stream);
 
 /* Stand-alone update kernels (the "noise-add" steps), usable with any score source:
  *   csd_langevin_step: sampling/correctors.py:88-108 (alpha = 1)

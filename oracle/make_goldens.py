@@ -456,6 +456,126 @@ def gen_sr3_160_long(ref):
     np.savez_compressed(os.path.join(OUT, 'sr3_160_long.npz'), **out)
 
 
+def _ref_pc_conditional(ref, cfg, model, sde, y, tape, p_steps, show_evolution=False):
+    xs = (y.shape[0],) + tuple(cfg.data.shape_x)
+    co = ref['sampling.conditional']
+    sampler = co.get_pc_conditional_sampler(sde, xs, ref['sampling.predictors'].get_predictor(cfg.sampling.predictor),
+                                            ref['sampling.correctors'].get_corrector(cfg.sampling.corrector), snr=cfg.sampling.snr,
+                                            p_steps=p_steps, c_steps=1, probability_flow=False, continuous=True, denoise=True,
+                                            use_path=False, eps=1e-5)
+    with ref_import.TapeRandn(tape) as tr:
+        res, info = sampler(model, y, show_evolution=show_evolution)
+        assert tr.i == len(tape), (tr.i, len(tape))
+    return res, info
+
+
+def gen_sharded_modes(ref):
+    """the two exactness modes of batch-sharded sampling on a global batch of 4 split over 2 ranks, 10 PC steps, one
+    noise tape: 'global' = ONE reference process holding all 4 samples (batch-mean norms over 4), 'shard<r>' = the reference run
+    independently on shard r (what Lightning-DDP testing does) with its slice of the tape -> tests/golden/sharded_modes.npz"""
+    out = {}
+    P, B = 10, 4
+    for case in ('sr3_tiny', 'cmde_tiny'):
+        cfg, _ = cases.case_config(case)
+        model, _ = build_ref_model(ref, cfg)
+        sde = sdes_for(ref, cfg)
+        y = cases.case_y(case, B=B)
+        tape = cases.tape(cases.pc_tape_shapes(case, P, B=B), seed=91)
+        with torch.no_grad():
+            res, _ = _ref_pc_conditional(ref, cfg, model, sde, y, tape, P)
+            out[case + '_global'] = res.numpy()
+            for r in range(2):
+                rs, _ = _ref_pc_conditional(ref, cfg, model, sde, y[2 * r:2 * r + 2], [t[2 * r:2 * r + 2] for t in tape], P)
+                out['%s_shard%d' % (case, r)] = rs.numpy()
+        d = np.abs(np.concatenate([out[case + '_shard0'], out[case + '_shard1']]) - out[case + '_global']).max()
+        print(case, 'global vs per-shard max difference', d)
+    np.savez_compressed(os.path.join(OUT, 'sharded_modes.npz'), **out)
+
+
+def gen_long_tiny(ref):
+    """The REAL 1000-step schedule end to end on the tiny SR3 / CMDE nets (B = 2, noise tape by seed): x after every 100th PC
+    step and the final denoised sample -> tests/golden/long_tiny.npz"""
+    out = {}
+    P = 1000
+    for case in ('sr3_tiny', 'cmde_tiny'):
+        cfg, B = cases.case_config(case)
+        model, _ = build_ref_model(ref, cfg)
+        sde = sdes_for(ref, cfg)
+        y = cases.case_y(case)
+        tape = cases.tape(cases.pc_tape_shapes(case, P), seed=1000)
+        with torch.no_grad():
+            res, info = _ref_pc_conditional(ref, cfg, model, sde, y, tape, P, show_evolution=True)
+        out[case + '_final'] = res.numpy()
+        out[case + '_evo'] = info['evolution']['x'][99::100].numpy()
+        print(case, '1000 steps: |x| max', float(res.abs().max()))
+    np.savez_compressed(os.path.join(OUT, 'long_tiny.npz'), **out)
+
+
+def _import_eval_tools():
+    """lightning_callbacks/evaluation_tools.py of the reference, imported unmodified; its missing THIRD-PARTY imports get stand-ins:
+    matplotlib / PIL / torchvision are unused by the functions exercised here, and of OpenCV only ``getGaussianKernel`` and
+    ``filter2D`` are called (by ``ssim``, which keeps the border-independent 'valid' region) - provided from their documented
+    definitions on scipy (Gaussian of sigma s: exp(-(i-(n-1)/2)^2 / (2 s^2)) normalised; filter2D = correlation)."""
+    import importlib.util
+    import types
+    import scipy.ndimage as ndi
+    cv2 = types.ModuleType('cv2')
+
+    def getGaussianKernel(n, sigma):
+        i = np.arange(n, dtype=np.float64) - (n - 1) / 2.0
+        g = np.exp(-(i * i) / (2.0 * sigma * sigma))
+        return (g / g.sum()).reshape(n, 1)
+
+    cv2.getGaussianKernel = getGaussianKernel
+    cv2.filter2D = lambda img, ddepth, kernel: ndi.correlate(img, kernel, mode='mirror')
+    mods = {'cv2': cv2}
+    for name in ('matplotlib', 'matplotlib.pyplot', 'PIL'):
+        mods[name] = types.ModuleType(name)
+    mods['matplotlib'].pyplot = mods['matplotlib.pyplot']
+    ref_import.install()              # (torchvision / torchvision.transforms stand-ins)
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    try:
+        spec = importlib.util.spec_from_file_location('_ref_eval_tools', os.path.join(ref_import.REF, 'lightning_callbacks', 'evaluation_tools.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mod
+
+
+def eval_case():
+    """seeded image batches of the evaluation fixture: 'samples' = ground truth + noise, clamped (what the test callback compares)"""
+    rs = np.random.RandomState(2025)
+    x = rs.uniform(0, 1, size=(3, 3, 40, 48)).astype(np.float32)
+    x = (x + np.roll(x, 1, axis=2) + np.roll(x, 1, axis=3) + np.roll(x, 2, axis=2)) / 4.0        # (some spatial correlation)
+    s = np.clip(x + rs.standard_normal(x.shape).astype(np.float32) * 0.05, 0, 1)
+    mask_info = np.array([[5, 7, 16], [0, 0, 20], [20, 28, 20]])
+    return torch.from_numpy(x), torch.from_numpy(s), mask_info
+
+
+def gen_eval(ref):
+    """PSNR / SSIM / bicubic resize / consistency values of the reference's evaluation_tools on seeded images
+    -> tests/golden/eval_tools.npz"""
+    et = _import_eval_tools()
+    x, s, mask_info = eval_case()
+    nx = torch.swapaxes(x.clone(), 1, -1).numpy() * 255
+    ns = torch.swapaxes(s.clone(), 1, -1).numpy() * 255
+    out = {'mean_psnr': np.float64(et.calculate_mean_psnr(ns, nx)), 'mean_ssim': np.float64(et.calculate_mean_ssim(ns, nx)),
+           'psnr_each': np.array([et.calculate_psnr(ns[i], nx[i]) for i in range(3)]),
+           'ssim_each': np.array([et.calculate_ssim(ns[i], nx[i]) for i in range(3)])}
+    for scale in (0.25, 0.125, 2.0):
+        out['resize_%g' % scale] = et.resize(x, scale).numpy()
+    out['consistency_sr'] = np.float64(et.get_calculate_consistency_fn('super-resolution')(s, x, 4))
+    out['consistency_inp'] = np.float64(et.get_calculate_consistency_fn('inpainting')(s, x, mask_info))
+    print({k: (v if np.ndim(v) == 0 else np.shape(v)) for k, v in out.items()})
+    np.savez_compressed(os.path.join(OUT, 'eval_tools.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)

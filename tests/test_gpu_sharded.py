@@ -1,0 +1,184 @@
+"""-m gpu: the two exactness modes of batch-sharded sampling against runs of the reference itself
+(tests/golden/sharded_modes.npz, oracle/make_goldens.py:gen_sharded_modes), the 1000-step schedule end to end on the tiny nets
+(tests/golden/long_tiny.npz), and the collectives of the N > 1 paths in two processes on the one GPU of the test box."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import cases  # noqa: E402
+from test_gpu_network import build, dev, sdes_for  # noqa: E402
+
+
+def _sampler(cfg, sde, B, P):
+    from conditional_score_diffusion_amd.sampling import conditional
+    from conditional_score_diffusion_amd.sampling.correctors import get_corrector
+    from conditional_score_diffusion_amd.sampling.predictors import get_predictor
+    return conditional.get_pc_conditional_sampler(sde, (B,) + tuple(cfg.data.shape_x), get_predictor(cfg.sampling.predictor),
+                                                  get_corrector(cfg.sampling.corrector), snr=cfg.sampling.snr, p_steps=P,
+                                                  c_steps=1, continuous=True, denoise=True, eps=1e-5)
+
+
+@pytest.mark.parametrize('case', ['sr3_tiny', 'cmde_tiny'])
+def test_per_shard_and_global_norm_modes_vs_reference(golden_dir, case):
+    """per-shard mode = the reference run on each shard alone; global-norm mode = ONE reference process with the global batch.
+    The two shards run here as two interleaved 'ranks' of one process: csd_pc_step_begin on both, their two-float sums added
+    (what the 8-byte all-reduce does), csd_pc_step_end on both."""
+    import ctypes
+    from conditional_score_diffusion_amd import _lib
+    from conditional_score_diffusion_amd._lib import check, current_stream, lib, ptr
+    from conditional_score_diffusion_amd.sampling import fused
+    g = np.load(os.path.join(golden_dir, 'sharded_modes.npz'))
+    cfg, nc, p, model = build(case)
+    sde = sdes_for(cfg)
+    smax = float((sde['x'] if isinstance(sde, dict) else sde).sigma_max)
+    P, B = 10, 4
+    y = cases.case_y(case, B=B).to(dev())
+    tape = cases.tape(cases.pc_tape_shapes(case, P, B=B), seed=91)
+    # per-shard mode: the fused loop on each shard with its slice of the tape
+    for r in range(2):
+        out, _ = _sampler(cfg, sde, 2, P)(model, y[2 * r:2 * r + 2].contiguous(), noise_tape=[t[2 * r:2 * r + 2] for t in tape])
+        assert np.abs(out.cpu().numpy() - g['%s_shard%d' % (case, r)]).max() / smax < 2e-4
+    # the modes really differ (otherwise this test would not distinguish them)
+    assert np.abs(np.concatenate([g[case + '_shard0'], g[case + '_shard1']]) - g[case + '_global']).max() / smax > 1e-3
+    # global-norm mode, two interleaved ranks
+    c_sde = sde['x'] if isinstance(sde, dict) else sde
+    ts, labels, std_x, G, std_y = fused.step_scalars(sde, P, 1e-5)
+    model._ensure_packed()
+    fp = lambda t: ctypes.cast(t.data_ptr(), ctypes.POINTER(ctypes.c_float))      # noqa: E731
+    ranks = []
+    for r in range(2):
+        tp = [t[2 * r:2 * r + 2].float() for t in tape]
+        x = (tp[0] * c_sde.sigma_max).to(dev()).contiguous()
+        flat = torch.cat([t.reshape(-1) for t in tp[1:]]).to(dev()).contiguous()
+        prm = _lib.PCParams()
+        prm.n_steps, prm.labels, prm.std_x, prm.G = P, fp(labels), fp(std_x), fp(G)
+        prm.std_y = fp(std_y) if std_y is not None else None
+        prm.snr, prm.denoise, prm.noise_tape, prm.seed, prm.record = float(cfg.sampling.snr), 1, flat.data_ptr(), 0, None
+        ws = torch.empty_like(model._workspace(2))                                   # (each rank its own workspace / scratch)
+        scratch = torch.empty(lib().csd_pc_scratch_bytes(model._h, 2), dtype=torch.uint8, device=dev())
+        sums = torch.zeros(2, device=dev())
+        ranks.append(dict(x=x, y=y[2 * r:2 * r + 2].contiguous(), flat=flat, prm=prm, ws=ws, scratch=scratch, sums=sums))
+    st = current_stream(dev())
+    for i in range(P):
+        for k in ranks:
+            check(lib().csd_pc_step_begin(model._h, ptr(model._packed), ptr(k['ws']), k['ws'].numel(), ptr(k['scratch']),
+                                          k['scratch'].numel(), ptr(k['x']), ptr(k['y']), 2, ctypes.byref(k['prm']), i,
+                                          ptr(k['sums']), st), 'pc_step_begin')
+        tot = ranks[0]['sums'] + ranks[1]['sums']                                     # the all-reduce
+        for k in ranks:
+            k['sums'].copy_(tot)
+            check(lib().csd_pc_step_end(model._h, ptr(model._packed), ptr(k['ws']), k['ws'].numel(), ptr(k['scratch']),
+                                        k['scratch'].numel(), ptr(k['x']), ptr(k['y']), 2, ctypes.byref(k['prm']), i,
+                                        ptr(k['sums']), B, st), 'pc_step_end')
+    got = torch.cat([ranks[0]['x'], ranks[1]['x']]).cpu().numpy()
+    assert np.abs(got - g[case + '_global']).max() / smax < 2e-4
+    # and with global_batch == B and no exchange the two-phase calls ARE csd_pc_sample
+    one = _sampler(cfg, sde, 2, P)
+    a, _ = one(model, y[:2].contiguous(), noise_tape=[t[:2] for t in tape])
+    b, _ = one(model, y[:2].contiguous(), noise_tape=[t[:2] for t in tape], global_norm=(lambda s: None, 2))
+    assert np.abs(a.cpu().numpy() - b.cpu().numpy()).max() / smax < 1e-6
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-3), ('fp16x3', 1e-3)])
+@pytest.mark.parametrize('case', ['sr3_tiny', 'cmde_tiny'])
+def test_thousand_step_schedule_vs_reference(golden_dir, case, precision, tol):
+    """the real 1000-step schedule end to end (2000 network evaluations; labels, sigma(t), G_i of every step)"""
+    g = np.load(os.path.join(golden_dir, 'long_tiny.npz'))
+    cfg, nc, p, model = build(case, precision)
+    sde = sdes_for(cfg)
+    B = cases.CASES[case][1]
+    tape = cases.tape(cases.pc_tape_shapes(case, 1000), seed=1000)
+    out, info = _sampler(cfg, sde, B, 1000)(model, cases.case_y(case).to(dev()), noise_tape=tape, show_evolution=True)
+    ev = info['evolution']['x'][99::100].numpy()
+    for j in range(10):
+        ref = g[case + '_evo'][j]
+        assert np.abs(ev[j] - ref).max() <= tol * np.abs(ref).max(), (case, precision, j)
+    ref = g[case + '_final']
+    err = np.abs(out.cpu().numpy() - ref)
+    assert err.max() <= tol * np.abs(ref).max()
+    assert (err <= tol * np.abs(ref) + tol * np.sqrt((ref.astype(np.float64) ** 2).mean())).all()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _two_rank_worker(rank, world, port, backend, q):
+    """both ranks on cuda:0: sharded sampling in both modes + the bucketed gradient all-reduce of the training path"""
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        kw = {'device_id': torch.device('cuda:0')} if backend == 'nccl' else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path[:0] = [root, os.path.join(root, 'oracle'), os.path.join(root, 'tests')]
+        import cases as cs
+        from test_gpu_network import build as bld, sdes_for as sf
+        from conditional_score_diffusion_amd import distributed as D, optim
+        case, P, B = 'sr3_tiny', 10, 4
+        cfg, nc, p, model = bld(case)
+        sde = sf(cfg)
+        y = cs.case_y(case, B=B).to('cuda:0')
+        tape = cs.tape(cs.pc_tape_shapes(case, P, B=B), seed=91)
+        lo, hi = D.shard_bounds(B, rank, world)
+        res = {}
+        for mode in (False, True):
+            out, _ = D.sample_sharded(_sampler(cfg, sde, hi - lo, P), model, y_global=y, seed=5, global_norm=mode,
+                                      noise_tape=[t[lo:hi] for t in tape])
+            res['global' if mode else 'shard'] = out.cpu().numpy()
+        # GradSync: the summed flat gradient equals the sum of the ranks' gradients
+        net = torch.nn.Linear(64, 64).to('cuda:0')
+        flat = optim.FlatParams.of(net.parameters())
+        sync = D.GradSync(flat, bucket_bytes=8 << 10)
+        flat.zero_grad()
+        xin = torch.full((2, 64), float(rank + 1), device='cuda:0')
+        sync.scale_loss(net(xin).sum()).backward()
+        sync.finish()
+        res['grad'] = flat.grad.cpu().numpy()
+        q.put((rank, res, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:      # pragma: no cover
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+
+
+@pytest.mark.parametrize('backend', ['nccl', 'gloo'])
+def test_two_ranks_on_one_gpu(golden_dir, backend):
+    """the collectives of the N > 1 paths - the final all_gather, the per-step 8-byte all-reduce of the global-norm mode, the
+    bucketed gradient all-reduce - executed by two processes that share the one GPU of the test box, over RCCL ('nccl') when the
+    library accepts two ranks on one device (it reports 'Duplicate GPU' otherwise: skipped) and over gloo with device tensors"""
+    import torch.multiprocessing as mp
+    g = np.load(os.path.join(golden_dir, 'sharded_modes.npz'))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, backend, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = [q.get(timeout=600) for _ in range(2)]
+    for pr in procs:
+        pr.join(timeout=120)
+    errs = [e for _, _, e in got if e]
+    if errs:
+        if backend == 'nccl' and any(('uplicate GPU' in e or 'invalid usage' in e or 'NCCL' in e or 'RCCL' in e) for e in errs):
+            pytest.skip('RCCL refuses two ranks on one device: ' + errs[0].strip().splitlines()[-1][:200])
+        raise AssertionError(errs[0])
+    smax = float(np.sqrt(3 * 20 * 20))
+    for rank, res, _ in got:
+        assert np.abs(res['shard'] - np.concatenate([g['sr3_tiny_shard0'], g['sr3_tiny_shard1']])).max() / smax < 2e-4
+        assert np.abs(res['global'] - g['sr3_tiny_global']).max() / smax < 2e-4
+    # d(sum(W x + b))/dW = sum_b x_b: rank r contributes 2*(r+1) per entry, scaled by 1/world -> (2 + 4)/2 = 3
+    w = got[0][1]['grad'][:64 * 64]
+    assert np.allclose(w, 3.0) and np.allclose(got[0][1]['grad'], got[1][1]['grad'])

@@ -503,6 +503,7 @@ def _ncsnpp_train_case():
     cfg.optim = cases.make_config().optim
     cfg.model.ema_rate = 0.999
     cfg.seed = 42
+    cfg.training.likelihood_weighting, cfg.training.reduce_mean = True, True      # (the two-SDE loss branch requires it)
     cfg.model.sigma_min_x, cfg.model.sigma_max_x, cfg.model.sigma_min_y, cfg.model.sigma_max_y = 0.01, 50., 0.01, 1.0
     return cfg, x
 

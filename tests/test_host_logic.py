@@ -231,6 +231,46 @@ def test_lightning_checkpoint_reader(tmp_path):
         checkpoint.split_lightning_state_dict({'state_dict': {'other.weight': torch.zeros(1)}})
 
 
+class _Evil:
+    def __reduce__(self):
+        import os as _os
+        return (_os.system, ('echo pwned > /tmp/csd_pwned',))
+
+
+def test_checkpoint_with_config_rebuilds_the_sdes_and_refuses_code(tmp_path):
+    """hyper_parameters.config + the VS-CMDE buffers -> model, sde['y'] with the checkpoint's sigma_max_y / sigma_min_y
+    (ConditionalSdeGenerativeModel.py:136-175, lightning_modules/utils.py:23-27); a pickle that would execute code is refused."""
+    from conditional_score_diffusion_amd import checkpoint, sde_lib
+    from conditional_score_diffusion_amd.models import utils as mutils
+    cfg, _ = cases.case_config('cmde_tiny')
+    cfg.training.lightning_module = 'conditional_decreasing_variance'
+    cfg.data.use_data_mean = False
+    src = mutils.create_model(cfg)
+    sd = {'score_model.' + k: v.clone() for k, v in src.state_dict().items()}
+    sd['sigma_max_y'], sd['sigma_min_y'] = torch.tensor(0.37), torch.tensor(0.004)
+    path = os.path.join(tmp_path, 'vs.ckpt')
+    torch.save({'state_dict': sd, 'hyper_parameters': {'config': cfg}, 'epoch': 3, 'global_step': 1234}, path)
+    mod = checkpoint.load_score_module(path)
+    assert isinstance(mod.sde, dict) and isinstance(mod.sde['x'], sde_lib.cVESDE) and isinstance(mod.sde['y'], sde_lib.VESDE)
+    assert mod.sde['y'].sigma_max == pytest.approx(0.37) and mod.sde['y'].sigma_min == pytest.approx(0.004)
+    assert mod.sde['x'].sigma_max == pytest.approx(cfg.model.sigma_max_x) and mod.sampling_eps == 1e-5
+    assert mod.config.model.nf == cfg.model.nf and tuple(mod.config.model.ch_mult) == tuple(cfg.model.ch_mult)
+    for (k, a), (_, b) in zip(src.state_dict().items(), mod.score_model.state_dict().items()):
+        assert torch.equal(a, b), k
+    # SR3 config: one conditional SDE, no y SDE
+    c2, _ = cases.case_config('sr3_tiny')
+    c2.data.use_data_mean = False
+    s2, eps2 = checkpoint.configure_sde(c2)
+    assert isinstance(s2, sde_lib.cVESDE) and eps2 == 1e-5
+    evil = os.path.join(tmp_path, 'evil.ckpt')
+    torch.save({'state_dict': sd, 'hyper_parameters': {'config': _Evil()}}, evil)
+    if os.path.exists('/tmp/csd_pwned'):
+        os.remove('/tmp/csd_pwned')
+    with pytest.raises(Exception):
+        checkpoint.read_checkpoint(evil)
+    assert not os.path.exists('/tmp/csd_pwned')
+
+
 def test_vs_cmde_variance_schedule():
     """get_reduction_fn (lightning_callbacks/callbacks.py:81-86): starts at y0, reaches yk at xk steps, inverse multiplicative in between -
     the edges2shoes values (configs/.../edges2shoes_ours_DV.py:101-104)."""
