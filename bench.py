@@ -111,9 +111,20 @@ def cpu_baseline(cfg, steps=4, B=4):
         so.pc_sample_conditional(p, nc, y, so.NoiseTape(tape), (cfg.model.sigma_min_x, cfg.model.sigma_max_x), None,
                                  sr3=True, p_steps=1000, snr=cfg.sampling.snr, N=1000, max_steps=steps)
         dt = time.time() - t0
-    return {'value': B / (1000.0 * dt / steps), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+    return {'value': B / (1000.0 * dt / steps), 'unit': 'images/sec', 'cores': cores, 'host_logical_cores': os.cpu_count(),
+            'host_cpu': _cpu_model(), 'kind': 'port',
             'sample': 'B=%d images x %d PC step(s) (=%d network evaluations) of the 1000-step schedule at 160x160, '
                       'torch %s CPU fp32, %d threads, %.1f s wall' % (B, steps, 2 * steps * B, torch.__version__, cores, dt)}
+
+
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
 
 
 def main():
@@ -241,12 +252,13 @@ def main():
             dom_kernel, dom_peak = 'conv_f32_kernel (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)', F32_MFMA_PEAK_TF
             dom_note = 'fp32 MFMA dense peak'
         elif args.precision == 'fp16x3':
-            dom_kernel, dom_peak = ('3x3 stride-1 convolution class: conv_f16_q_kernel<NS=2> (quad-wave implicit GEMM, 3x '
-                                    'v_mfma_f32_16x16x32_f16 per product) + conv_f16_lc_kernel / conv_f16_kernel<NS=2>'), F16_MFMA_PEAK_TF / 3
+            dom_kernel, dom_peak = ('3x3 stride-1 convolution class: conv_ff_kernel<NS=2> (fused GroupNorm+SiLU+split prologue, LDS-DMA weight '
+                                    'ring, 3x v_mfma_f32_32x32x16_f16 per product; the 160^2 / 80^2 levels = 70 % of the class time) + '
+                                    'conv_f16_q_kernel<NS=2> (40^2 and below)'), F16_MFMA_PEAK_TF / 3
             dom_note = 'fp16 MFMA dense peak (2500 TF) / 3 MFMAs per algorithmic product; achieved counts algorithmic flops'
         else:
-            dom_kernel, dom_peak = ('3x3 stride-1 convolution class: conv_f16_lc_kernel<NS=1> (loader/consumer persistent implicit '
-                                    'GEMM, v_mfma_f32_32x32x16_f16) + conv_f16_kernel<NS=1>'), F16_MFMA_PEAK_TF
+            dom_kernel, dom_peak = ('3x3 stride-1 convolution class: conv_ff_kernel<NS=1> (fused GroupNorm+SiLU prologue, v_mfma_f32_32x32x16_f16) '
+                                    '+ conv_f16_lc_kernel<NS=1> (40^2 and below)'), F16_MFMA_PEAK_TF
             dom_note = 'fp16 MFMA dense peak'
         # which roof bounds the dominant kernel: arithmetic intensity of its launches vs the ridge of its MFMA peak
         dom_gbs = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9 if dom['ms'] > 0 else 0.0
@@ -259,7 +271,7 @@ def main():
         # HBM traffic of the same kernel class from PMC counters (a separate rocprofv3 pass cannot run inside this
         # process): the committed summary of tools/pmc_hbm.sh for this mode, bytes per launch like `achieved`
         traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_hbm_traffic_%s.json' % args.precision)
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_hbm_traffic_%s.json' % args.precision)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic = tj['conv3x3_class']['hbm_bytes_per_launch']
@@ -277,7 +289,7 @@ def main():
         hbm_roof = HBM_PEAK_GBS * 1e9 / bytes_per_img                      # images/s/GPU
         flop_roof = F32_MFMA_PEAK_TF * 1e12 / (2000 * ALG_FLOP_PER_IMG_NFE)
         res = {
-            'metric': 'images/sec for 1000-step PC sampling, NCSN++-family score net, CelebA 160x160',
+            'metric': 'images/sec for 1000-step PC sampling, ddpm_paired_SR3 score net of celebA_SR3_160 (BASELINE configs[1]), 160x160',
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'fp32': 'f32', 'fp16x3': 'f16x3 (split hi+lo fp16 operands, 3 MFMAs, f32 accumulate; f32-class error)',
@@ -332,6 +344,25 @@ def main():
                                                                 'precision', 'params', 'achieved_TFLOPs_3x_fwd')}
             except Exception as e:
                 res['training_side_bench'] = {'error': str(e)[:200]}
+            # BASELINE configs[2] (CMDE inpainting 128x128, two SDEs) and the architecture north_star names (NCSN++ with the SR3-160
+            # hyper-parameters), same precision mode, B = 64: side figures with their own HBM-roofline fractions (SURVEY.md 8d bytes)
+            try:
+                tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'bench_other.py')
+                r = subprocess.run([sys.executable, tool, args.precision, 'bench'], capture_output=True, text=True, timeout=600)
+                js = [json.loads(l) for l in r.stdout.strip().splitlines() if l.startswith('{')]
+                cm, nc = js[0], js[1]
+                cm_roof = HBM_PEAK_GBS * 1e9 / (2000 * (591.3e6 + ALG_WEIGHT_BYTES_PER_NFE / 64))
+                nc_bytes = 1085.7e6 + 4.0 * nc['params'] / 64
+                res['side_benches'] = {
+                    'configs2_cmde_inpainting_128': {'images_per_sec_1000_steps': cm['images_per_sec_1000_steps'], 'ms_per_pc_step': cm['ms_per_pc_step'],
+                                                     'batch': cm['batch'], 'hbm_roofline_images_per_sec': cm_roof,
+                                                     'hbm_roofline_frac': cm['images_per_sec_1000_steps'] / cm_roof},
+                    'ncsnpp_paired_sr3_160_hyperparameters': {'image_evaluations_per_sec': nc['images_per_sec_per_nfe'], 'batch': nc['batch'],
+                                                              'images_per_sec_1000_steps_equiv': nc['images_per_sec_per_nfe'] / 2000.0,
+                                                              'params': nc['params'], 'algorithmic_bytes_per_image_nfe': nc_bytes,
+                                                              'hbm_roofline_frac': nc['images_per_sec_per_nfe'] * nc_bytes / (HBM_PEAK_GBS * 1e9)}}
+            except Exception as e:
+                res['side_benches'] = {'error': str(e)[:200]}
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()

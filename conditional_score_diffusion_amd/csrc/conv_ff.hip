@@ -70,9 +70,11 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
 #endif
   int ts_n = 0;
 #define FF_TS() do { if (a_dbg && (tid == 0 || tid == 64) && blockIdx.x < 4096 && ts_n < 16) a_dbg[(blockIdx.x * 2 + (tid >> 6)) * 16 + ts_n++] = clock64(); } while (0)
+#define FF_FS(i) do { if (a_dbg && (k_abl & 256) && s == 2 && (tid == 0 || tid == 64) && blockIdx.x < 1024) a_dbg[4096 * 2 * 16 + (blockIdx.x * 2 + (tid >> 6)) * 64 + (i)] = clock64(); } while (0)
 #define FF_WALL(i) do { if (a_dbg && (tid == 0 || tid == 64) && blockIdx.x < 4096) a_dbg[(blockIdx.x * 2 + (tid >> 6)) * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define FF_WALL(i) do { } while (0)
+#define FF_FS(i) do { } while (0)
 #define FF_ABL(bit) false
 #define FF_TS() do { } while (0)
 #endif
@@ -276,20 +278,24 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][nt][0], xb[cur][mt][0], acc[mt][nt], 0, 0, 0);
       };
       __builtin_amdgcn_sched_barrier(0);
+      FF_FS(step * 5 + 0);
       mma(0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      FF_FS(step * 5 + 1);
       if (step + 1 < STEPS && !FF_ABL(64)) {
         int sl = slot;
         if (last) sl = slot + 1 == R ? 0 : slot + 1;
         load_frags(cur ^ 1, step + 1, sl);
       }
       __builtin_amdgcn_sched_barrier(0);
+      FF_FS(step * 5 + 2);
 #pragma unroll
       for (int i = 1; i < 2 * NT; ++i) {
         mma(i / NT, i % NT);
         if (NS == 2) __builtin_amdgcn_sched_barrier(0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      FF_FS(step * 5 + 3);
       if (last) {
         if (W0) {                                    // group Gc+2 has landed before anyone passes the barrier into group Gc+1
           if (Gc + R - 1 < total_groups) ff_wait_vm<(R - 3) * GLW>();
@@ -298,6 +304,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
           FF_TS();
           store_patch(patch + ((s + 1) & 1) * FF_PATCH_BYTES);
         }
+        FF_FS(step * 5 + 4);
         if (!FF_ABL(32)) ff_barrier();
         if (step == STEPS - 1) FF_TS();
         ++Gc;
@@ -438,6 +445,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
   FF_WALL(15);
 #undef FF_TS
 #undef FF_WALL
+#undef FF_FS
 #undef FF_ABL
 }
 

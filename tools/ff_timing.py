@@ -14,13 +14,15 @@ x0 = torch.randn(B, H, H, C0, device=dev); x1 = torch.randn(B, H, H, C1, device=
 w = torch.randn(Cout, Cin, 3, 3, device=dev) * (1.0 / (Cin * 9)) ** 0.5; b = torch.randn(Cout, device=dev)
 sc, sh = torch.rand(B, Cin, device=dev) + 0.5, torch.randn(B, Cin, device=dev)
 r = torch.randn(B, H, H, Cout, device=dev) if res else None
-buf = torch.zeros(4096 * 2 * 16, dtype=torch.int64, device=dev)
+buf = torch.zeros(4096 * 2 * 16 + 1024 * 2 * 64, dtype=torch.int64, device=dev)
 _lib.lib().csd_debug_ff_timing.argtypes = [ctypes.c_void_p]
 ops.conv3x3_block(x0, w, b, x1=x1, nscale=sc, nshift=sh, res=r, precision=prec, want_stats=True)
 _lib.lib().csd_debug_ff_timing(ctypes.c_void_p(buf.data_ptr()))
 ops.conv3x3_block(x0, w, b, x1=x1, nscale=sc, nshift=sh, res=r, precision=prec, want_stats=True)
 torch.cuda.synchronize()
-t = buf.cpu().numpy().reshape(4096, 2, 16)
+allb = buf.cpu().numpy()
+t = allb[:4096 * 2 * 16].reshape(4096, 2, 16)
+fine = allb[4096 * 2 * 16:].reshape(1024, 2, 64)
 for wv in (0, 1):
     tt = t[:, wv]
     tt = tt[tt[:, 0] != 0]
@@ -36,3 +38,16 @@ for wv in (0, 1):
     print('   steady-state: total %.0f | %s' % ((late[:, nz - 1] - late[:, 0]).mean(), ' '.join('%6.0f' % v for v in dl.mean(0))))
 span = t[:, 0, :14][t[:, 0, 0] != 0]
 print('kernel span (first start -> last end among sampled wgs): %.0f clk' % (span.max() - span[:, 0].min()))
+
+if int(os.environ.get('CSD_FF_ABL', '0')) & 256:
+    # per-step anatomy of stage 2 (split mode: one step = one ring group): [top .. first MFMA triple .. fragment reads issued .. 15 MFMAs
+    # .. (wave 0: DMA wait / wave 1: conversion) .. barrier passed = next top]
+    for wv in (0, 1):
+        f = fine[:, wv]
+        f = f[f[:, 0] != 0]
+        n = int((f[0] != 0).sum())
+        d = np.diff(f[:, :n], axis=1).mean(0)
+        print('wave %d stage 2, per step [mma0 | issue reads | 15 mma | tail | barrier]:' % wv)
+        for st in range(n // 5):
+            seg = d[st * 5:st * 5 + 5]
+            print('   step %d: %s' % (st, ' '.join('%6.0f' % v for v in seg)))

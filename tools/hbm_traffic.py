@@ -28,7 +28,7 @@ def main(tag, outpath):
                      'fetch_bytes_per_launch': fetch, 'write_bytes_per_launch': write})
         name = key[0]
         in16_old = name.startswith('conv_f16_kernel') and name.rstrip('>').split(',')[-2].strip() == 'true'
-        if name.startswith('conv_f16_q_kernel') or name.startswith('conv_f16_lc_kernel') or in16_old:
+        if name.startswith(('conv_ff_kernel', 'conv_f16_q_kernel', 'conv_f16_lc_kernel')) or in16_old:
             cls['launches'] += n
             cls['fetch'] += fetch * n
             cls['write'] += write * n
