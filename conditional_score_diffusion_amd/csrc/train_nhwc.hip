@@ -124,8 +124,8 @@ __global__ void gn_bwd_final_nhwc_kernel(const double* __restrict__ partial, con
 // pass 3: dx, elementwise; thread = (pixel row, 4 channels) with its coefficients in registers
 __global__ __launch_bounds__(TN_THREADS) void gn_bwd_apply_nhwc_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ rs, const float* __restrict__ ms, const float* __restrict__ coef, float* __restrict__ dx, int HW,
-    int C, int act, int nchunk) {
+    const float* __restrict__ rs, const float* __restrict__ ms, const float* __restrict__ coef, const float* __restrict__ add,
+    float* __restrict__ dx, int HW, int C, int act, int nchunk) {
   const int C4 = C >> 2;
   const int rows = TN_THREADS / C4;
   const int tid = threadIdx.x;
@@ -154,6 +154,10 @@ __global__ __launch_bounds__(TN_THREADS) void gn_bwd_apply_nhwc_kernel(
       const float xh = xa[j] * rr[j] + mm[j];
       const float du = da[j] * t_dact(xh * gg[j] + bb[j], act);
       o[j] = du * ca[j] - cb[j] - xh * cc[j];
+    }
+    if (add) {                                     // a second gradient path into the same tensor (residual shortcut), fused
+      const float4 av = *reinterpret_cast<const float4*>(add + base + (size_t)p * C);
+      o[0] += av.x; o[1] += av.y; o[2] += av.z; o[3] += av.w;
     }
     *reinterpret_cast<float4*>(dx + base + (size_t)p * C) = make_float4(o[0], o[1], o[2], o[3]);
   }
@@ -275,10 +279,10 @@ extern "C" int csd_groupnorm_act_nhwc(const float* x, const float* gamma, const 
   return gn_apply_launch(x, sc, sh, y, B, HW, C, act, s);
 }
 
-extern "C" int csd_groupnorm_act_backward_nhwc(const float* x, const float* gamma, const float* beta, const float* rs,
-                                               const float* ms, const float* dy, float* dx, float* dgamma_rows,
-                                               float* dbeta_rows, int row_stride, int B, int C, int HW, int groups, int act,
-                                               void* scratch, void* stream) {
+// dx = GroupNorm(+act) backward of dy (+ add, when given: the gradient arriving over the residual shortcut)
+int csd::groupnorm_act_backward_nhwc_add(const float* x, const float* gamma, const float* beta, const float* rs, const float* ms,
+                                         const float* dy, const float* add, float* dx, float* dgamma_rows, float* dbeta_rows,
+                                         int row_stride, int B, int C, int HW, int groups, int act, void* scratch, void* stream) {
   CSD_REQUIRE(x && gamma && beta && rs && ms && dy && dx && dgamma_rows && dbeta_rows && scratch, "groupnorm_act_backward_nhwc: null argument");
   CSD_REQUIRE(C % 4 == 0 && C <= 1024 && groups > 0 && C % groups == 0, "groupnorm_act_backward_nhwc: C=%d groups=%d unsupported", C, groups);
   CSD_REQUIRE(row_stride >= C, "groupnorm_act_backward_nhwc: row_stride %d < C", row_stride);
@@ -293,10 +297,18 @@ extern "C" int csd_groupnorm_act_backward_nhwc(const float* x, const float* gamm
   hipLaunchKernelGGL(gn_bwd_final_nhwc_kernel, dim3(B), dim3(256), (size_t)C * 2 * sizeof(double), s, partial, gamma, rs,
                      dgamma_rows, dbeta_rows, coef, HW, C, groups, nchunk, row_stride);
   CSD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_apply_nhwc_kernel, dim3(nchunk, B), dim3(TN_THREADS), 0, s, x, dy, gamma, beta, rs, ms, coef, dx, HW,
-                     C, act, nchunk);
+  hipLaunchKernelGGL(gn_bwd_apply_nhwc_kernel, dim3(nchunk, B), dim3(TN_THREADS), 0, s, x, dy, gamma, beta, rs, ms, coef, add, dx,
+                     HW, C, act, nchunk);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
+}
+
+extern "C" int csd_groupnorm_act_backward_nhwc(const float* x, const float* gamma, const float* beta, const float* rs,
+                                               const float* ms, const float* dy, float* dx, float* dgamma_rows,
+                                               float* dbeta_rows, int row_stride, int B, int C, int HW, int groups, int act,
+                                               void* scratch, void* stream) {
+  return groupnorm_act_backward_nhwc_add(x, gamma, beta, rs, ms, dy, nullptr, dx, dgamma_rows, dbeta_rows, row_stride, B, C, HW, groups,
+                                         act, scratch, stream);
 }
 
 extern "C" int csd_bias_add_nhwc(const float* x, const float* bias, float* out, int B, int HW, int C, void* stream) {

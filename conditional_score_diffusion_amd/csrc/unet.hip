@@ -1511,6 +1511,8 @@ struct csd_unet {
   Net net;
 };
 
+#include "train_graph.h"
+
 extern "C" int csd_profile_select(unsigned class_mask, int step_stride) {
   g_prof.mask = class_mask;
   g_prof.step_stride = step_stride > 0 ? step_stride : 1;
@@ -1559,7 +1561,10 @@ extern "C" int csd_unet_create(const csd_unet_config* cfg, csd_unet** out) {
   return CSD_OK;
 }
 
-extern "C" void csd_unet_destroy(csd_unet* net) { delete net; }
+extern "C" void csd_unet_destroy(csd_unet* net) {
+  if (net) g_train.erase(&net->net);
+  delete net;
+}
 
 extern "C" int csd_unet_num_params(const csd_unet* net) { return net ? (int)net->net.params.size() : 0; }
 

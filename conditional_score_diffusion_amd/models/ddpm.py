@@ -72,6 +72,8 @@ class HipUNet(nn.Module):
         self._act_name = act
         self._train_calls = 0
         self.train_layout = os.environ.get('CSD_TRAIN_LAYOUT', 'nhwc')     # 'nhwc' | 'nchw' (see _train_forward)
+        self.train_executor = os.environ.get('CSD_TRAIN_EXECUTOR', 'planned')   # 'planned' (csd_unet_backward) | 'operators' (autograd)
+        self._train_ws = None
         self.dropout_seed = int(getattr(config, 'seed', 0) or 0)   # Philox key of the dropout masks
         cfg = _lib.UNetConfig()
         cfg.arch = self.arch
@@ -227,6 +229,38 @@ class HipUNet(nn.Module):
         return out
 
 
+    # -- training-mode evaluation: ONE planned graph behind the C ABI (csd_unet_train_forward / csd_unet_backward) -------------------
+    def _train_workspace(self, B):
+        need = lib().csd_unet_train_workspace_bytes(self._h, B, self._dropout)
+        if need == 0:
+            raise RuntimeError('libcsd_hip: cannot plan the training graph at batch %d: %s' % (B, lib().csd_last_error().decode()))
+        if self._train_ws is None or self._train_ws.numel() < need or self._train_ws.device != self.device:
+            self._train_ws = None
+            self._train_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._train_ws
+
+    def _train_params(self):
+        params = dict(self.named_parameters())
+        return [params[name] for name in self._param_names]
+
+    def _train_forward_planned(self, x, y, labels):
+        """``model.train()`` + autograd as ONE node: the forward is csd_unet_train_forward (the reference's layer sequence,
+        models/ddpm.py:149-213, dropout on, activations kept in a library workspace), the backward csd_unet_backward (every
+        parameter gradient from one call).  ``self.grad_sink``: when a Trainer owns the flat gradient buffer the gradients are
+        written straight into ``p.grad`` (which it zeroed) and autograd is handed nothing to accumulate."""
+        B, S = x.shape[0], self.image_size
+        if tuple(x.shape) != (B, self.x_channels, S, S):
+            raise RuntimeError('x has shape %s, expected %s' % (tuple(x.shape), (B, self.x_channels, S, S)))
+        if self.y_channels:
+            require_gpu_tensor(y, 'y')
+            if tuple(y.shape) != (B, self.y_channels, S, S):
+                raise RuntimeError('y has shape %s, expected %s' % (tuple(y.shape), (B, self.y_channels, S, S)))
+        labels = labels.to(device=x.device, dtype=torch.float32).contiguous()
+        if labels.shape != (B,):
+            raise RuntimeError('labels must have shape [%d]' % B)
+        self._train_calls += 1
+        return _PlannedNet.apply(self, x.contiguous(), y.contiguous() if self.y_channels else None, labels, *self._train_params())
+
     # -- training-mode evaluation: differentiable, operator-granular ------------------------------------------
     def _train_forward(self, x, y, labels):
         """``model.train()`` + autograd: the reference forward (models/ddpm.py:149-213) layer by layer on differentiable HIP
@@ -238,6 +272,8 @@ class HipUNet(nn.Module):
         from .. import ops
         if not self._cfg.resamp_with_conv:
             raise NotImplementedError('training with resamp_with_conv=False is not provided')
+        if self.train_executor == 'planned' and self.arch == 0 and self.train_layout == 'nhwc':
+            return self._train_forward_planned(x, y, labels)
         nhwc = self.train_layout == 'nhwc'
         if nhwc:
             from .. import grad_ops_nhwc as G
@@ -326,6 +362,47 @@ class HipUNet(nn.Module):
         if nhwc:
             return G.conv2d(h, m[i + 1].weight, m[i + 1].bias, precision=prec, layout=G.IN_NHWC)
         return G.conv2d(h, m[i + 1].weight, m[i + 1].bias, precision=prec)
+
+
+class _PlannedNet(torch.autograd.Function):
+    """The whole training-mode network as one autograd node over csd_unet_train_forward / csd_unet_backward."""
+
+    @staticmethod
+    def forward(ctx, model, x, y, labels, *params):
+        B = x.shape[0]
+        for name, p in zip(model._param_names, params):
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.device != x.device:
+                raise RuntimeError('parameter %s must be contiguous float32 on %s' % (name, x.device))
+        ws = model._train_workspace(B)
+        table = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        out = torch.empty(B, model.out_channels, model.image_size, model.image_size, dtype=torch.float32, device=x.device)
+        check(lib().csd_unet_train_forward(model._h, table, ptr(ws), ws.numel(), ptr(x), ptr(y) if y is not None else None,
+                                           ptr(labels), ptr(out), B, model._dropout, model.dropout_seed, model._train_calls,
+                                           current_stream(x.device)), 'unet_train_forward')
+        ctx.model, ctx.table, ctx.ws, ctx.B = model, table, ws, B
+        ctx.shapes = [(p.shape, p.numel()) for p in params]
+        ctx.sink = [p.grad for p in params] if getattr(model, 'grad_sink', False) else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, B = ctx.model, ctx.B
+        dout = dout.contiguous()
+        direct = ctx.sink is not None and all(g is not None and g.is_contiguous() and g.data_ptr() % 16 == 0 for g in ctx.sink)
+        if direct:
+            grads = ctx.sink
+        else:
+            offs = [0]
+            for _, n in ctx.shapes:
+                offs.append(offs[-1] + (n + 3) // 4 * 4)
+            flat = torch.empty(offs[-1], dtype=torch.float32, device=dout.device)
+            grads = [flat[o:o + n].view(shape) for o, (shape, n) in zip(offs, ctx.shapes)]
+        gtable = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        check(lib().csd_unet_backward(model._h, ctx.table, gtable, ptr(ctx.ws), ctx.ws.numel(), ptr(dout), B,
+                                      current_stream(dout.device)), 'unet_backward')
+        if direct:
+            return (None, None, None, None) + (None,) * len(grads)
+        return (None, None, None, None) + tuple(grads)
 
 
 @utils.register_model(name='ddpm')

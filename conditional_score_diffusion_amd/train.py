@@ -4,7 +4,8 @@ Replaces ``BaseSdeGenerativeModel.training_step`` / ``configure_optimizers`` (li
 52-96), the EMA callback (lightning_modules/callbacks.py:119-133, models/ema.py) and Lightning-DDP's gradient all-reduce
 (run_lib.py:55-73) with one process per GPU over ``torch.distributed`` (RCCL):
 
-* forward + backward on the HIP operators of grad_ops (csrc/backward.hip);
+* forward + backward as ONE planned graph behind csd_unet_train_forward / csd_unet_backward (DDPM family; csrc/train_graph.h) or
+  on the differentiable HIP operators of grad_ops (NCSN++; csrc/backward.hip);
 * gradients accumulate into ONE flat buffer, all-reduced in 32 MiB buckets that are launched from autograd hooks while the
   backward of earlier layers is still running (distributed.GradSync);
 * ONE fused kernel applies clipping + Adam + EMA (optim.FusedAdam / csd_adam_step).
@@ -41,6 +42,10 @@ class Trainer:
         self.optimize_fn = optim.optimization_manager(config)
         self.ema = optim.ExponentialMovingAverage(self.flat, decay=config.model.ema_rate)
         self.sync = GradSync(self.flat, group, bucket_bytes)
+        # planned training graph (csd_unet_backward): the gradients are written straight into the flat buffer's views (p.grad, zeroed
+        # by zero_grad()) - autograd has nothing to accumulate and GradSync.finish() reduces every bucket after the backward
+        if getattr(model, 'train_executor', None) == 'planned':
+            model.grad_sink = True
         self.step = 0                     # completed optimizer steps (the warm-up factor of step k is k / warmup)
 
     def _build_loss_fns(self):

@@ -360,6 +360,23 @@ int csd_attention_nhwc(const float* qkv, float* out, int B, int L, int C, void* 
 int csd_attention_backward_nhwc(const float* qkv, const float* dout, float* dqkv, int B, int L, int C, void* scratch,
                                 void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training step of the DDPM-family network as ONE planned graph (replaces torch autograd over
+ * models/ddpm.py:149-213 + models/layers.py:524-675 in `model.train()` mode, run_lib.py:55-73).
+ *   csd_unet_train_forward: the forward with nn.Dropout(dropout_p) active (mask = Philox keyed by (dropout_seed,
+ *     (call_index << 16) + running dropout index), models/layers.py:647,662); every tensor a gradient needs stays in `workspace`.
+ *   csd_unet_backward: given d loss / d out ([B, out_channels, S, S]), writes d loss / d parameter i to grads[i] (overwrite).
+ * params[i] / grads[i]: device pointers of parameter i in csd_unet_param_info order and layout (fp32, 16-byte aligned).
+ * One backward per forward, same handle / workspace / B; the workspace must not be touched in between.
+ * csd_unet_train_workspace_bytes depends on B and on whether dropout_p > 0. arch 0 only (NCSN++ trains per operator).
+ * ---------------------------------------------------------------------------------------- */
+size_t csd_unet_train_workspace_bytes(csd_unet* net, int B, float dropout_p);
+int csd_unet_train_forward(csd_unet* net, const float* const* params, void* workspace, size_t workspace_bytes, const float* x,
+                           const float* y, const float* labels, float* out, int B, float dropout_p, uint64_t dropout_seed,
+                           uint64_t call_index, void* stream);
+int csd_unet_backward(csd_unet* net, const float* const* params, float* const* grads, void* workspace, size_t workspace_bytes,
+                      const float* d_out, int B, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -163,11 +163,14 @@ def test_dropout_mask_and_backward():
     assert torch.allclose(x.grad, g * y.detach())
 
 
-def _hip_loss_and_grads(case, precision='fp32', layout='nhwc'):
+def _hip_loss_and_grads(case, precision='fp32', layout='nhwc', executor='planned', dropout=None):
     from conditional_score_diffusion_amd import losses
     cfg, B, x, y, u, tape = cases.grad_case(case)
+    if dropout is not None:
+        cfg.model.dropout = dropout
     cfg, nc, p, model = build(cfg, precision)
     model.train_layout = layout
+    model.train_executor = executor
     sde = sdes_for(cfg)
     if cfg.model.name == 'ddpm':
         fn, batch = losses.get_general_sde_loss_fn(sde, True, False, True, True, True), x.to(dev())
@@ -186,13 +189,14 @@ def _hip_loss_and_grads(case, precision='fp32', layout='nhwc'):
     return float(loss.detach()), {k: v.grad for k, v in model.named_parameters()}, model
 
 
-@pytest.mark.parametrize('layout', ['nhwc', 'nchw'])
+@pytest.mark.parametrize('layout,executor', [('nhwc', 'planned'), ('nhwc', 'operators'), ('nchw', 'operators')])
 @pytest.mark.parametrize('case', list(cases.CASES))
-def test_training_loss_and_grads_vs_reference(golden_dir, case, layout):
+def test_training_loss_and_grads_vs_reference(golden_dir, case, layout, executor):
     """loss.backward() through the HIP backward kernels vs the reference's autograd (fixture) and the oracle's (all entries);
-    both executors of the training graph: NHWC activations (default) and the NCHW per-operator ABI."""
+    all three executors of the training graph: the planned graph behind csd_unet_train_forward / csd_unet_backward (default), autograd
+    over the NHWC operators, autograd over the NCHW per-operator ABI."""
     g = np.load(os.path.join(golden_dir, 'grads.npz'))
-    loss, grads, _ = _hip_loss_and_grads(case, layout=layout)
+    loss, grads, _ = _hip_loss_and_grads(case, layout=layout, executor=executor)
     worst = check_grads_vs_fixture(g, case, loss, grads, 1e-3)
     o_loss, o_grads = oracle_loss_and_grads(case)
     assert abs(loss - o_loss) <= 1e-4 * abs(o_loss)
@@ -202,6 +206,50 @@ def test_training_loss_and_grads_vs_reference(golden_dir, case, layout):
         scale = max(float(v.abs().max()), float(v.double().norm()) / np.sqrt(v.numel()))
         assert err <= 1e-3 * scale + 1e-6 * total / np.sqrt(v.numel()), (k, err, scale)
     print(case, 'worst sampled rel err vs reference', worst)
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('fp16x3', 2e-4)])
+@pytest.mark.parametrize('case', list(cases.CASES))
+def test_planned_graph_equals_operator_graph(case, precision, tol):
+    """csd_unet_train_forward / csd_unet_backward against autograd over the per-layer operators, dropout 0.1 ON (same Philox
+    stream ids in both): same loss, same gradient for every parameter (the two differ only in summation order)."""
+    la, ga, ma = _hip_loss_and_grads(case, precision, 'nhwc', 'planned', dropout=0.1)
+    lb, gb, mb = _hip_loss_and_grads(case, precision, 'nhwc', 'operators', dropout=0.1)
+    assert ma._train_calls == mb._train_calls == 1
+    assert abs(la - lb) <= 1e-5 * abs(lb)
+    total = float(np.sqrt(sum(float((v.double() ** 2).sum()) for v in gb.values())))
+    worst = 0.0
+    for k, v in gb.items():
+        assert ga[k] is not None, k
+        err = float((ga[k].double() - v.double()).abs().max())
+        scale = max(float(v.abs().max()), float(v.double().norm()) / np.sqrt(v.numel()))
+        assert err <= tol * scale + 1e-7 * total / np.sqrt(v.numel()), (k, err, scale)
+        if scale > 1e-6 * total:           # (mathematically-zero gradients, e.g. the attention key bias, hold rounding noise only)
+            worst = max(worst, err / scale)
+    print(case, precision, 'planned vs operators: worst relative gradient difference %.2e' % worst)
+
+
+def test_planned_graph_call_sequence_errors():
+    """backward without a matching forward, a short workspace and NCSN++ (no planned training graph) fail loudly"""
+    import ctypes
+    from conditional_score_diffusion_amd._lib import lib, ptr
+    cfg, B, x, y, u, tape = cases.grad_case('sr3_tiny')
+    cfg, nc, p, model = build(cfg)
+    ps = model._train_params()
+    table = (ctypes.c_void_p * len(ps))(*[q.data_ptr() for q in ps])
+    gs = [torch.zeros_like(q) for q in ps]
+    gtable = (ctypes.c_void_p * len(ps))(*[q.data_ptr() for q in gs])
+    ws = model._train_workspace(B)
+    dout = torch.zeros(B, model.out_channels, model.image_size, model.image_size, device=dev())
+    assert lib().csd_unet_backward(model._h, table, gtable, ptr(ws), ws.numel(), ptr(dout), B, None) == -3     # CSD_ERR_STATE
+    assert b'csd_unet_train_forward' in lib().csd_last_error()
+    xs = x.to(dev()); ys = y.to(dev()); lab = torch.full((B,), 3., device=dev()); out = torch.empty_like(dout)
+    assert lib().csd_unet_train_forward(model._h, table, ptr(ws), 1024, ptr(xs), ptr(ys), ptr(lab), ptr(out), B, 0.0, 0, 1, None) == -5
+    assert lib().csd_unet_train_forward(model._h, table, ptr(ws), ws.numel(), ptr(xs), ptr(ys), ptr(lab), ptr(out), B, 0.0, 0, 1, None) == 0
+    assert lib().csd_unet_backward(model._h, table, gtable, ptr(ws), ws.numel(), ptr(dout), B + 1, None) == -3
+    assert lib().csd_unet_backward(model._h, table, gtable, ptr(ws), ws.numel(), ptr(dout), B, None) == 0
+    assert lib().csd_unet_backward(model._h, table, gtable, ptr(ws), ws.numel(), ptr(dout), B, None) == -3        # consumed
+    torch.cuda.synchronize()
 
 
 def test_training_fp16x3_grads_close_to_fp32():
