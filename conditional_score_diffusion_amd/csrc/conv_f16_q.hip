@@ -386,6 +386,10 @@ __global__ void conv16q_pack_kernel(const float* __restrict__ w, _Float16* __res
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)cout_src * Cin * 9;
   if (idx >= total) return;
+  {                                                    // the prefetch slack behind the last fragment (read, never multiplied) is zeroed here
+    const size_t body32 = (size_t)(Cout / (32 * ntq)) * 2 * (Cin / 32) * 9 * ntq * ns * 256, slack32 = (size_t)ntq * ns * 1024;
+    if (cout_off == 0 && idx < slack32) reinterpret_cast<uint32_t*>(wpack)[body32 + idx] = 0u;
+  }
   const int tap = (int)(idx % 9);
   const int cin = (int)((idx / 9) % Cin);
   const int co = (int)(idx / ((size_t)9 * Cin));
@@ -413,7 +417,7 @@ __global__ void conv16q_zero_kernel(uint32_t* p, size_t n) {
 
 int conv16q_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int cin_src, int cout_src, int cout_off,
                         void* wpack, hipStream_t s) {
-  if (cout_off == 0) {
+  if (cout_off == 0 && (cin_src != p.C0 || cout_src != p.Cout)) {     // (a weight that fills the packed layout needs no zero fill)
     const size_t n32 = conv16q_packed_bytes(p, ns) / 4;
     hipLaunchKernelGGL(conv16q_zero_kernel, dim3((unsigned)cdiv64(n32, 256)), dim3(256), 0, s, (uint32_t*)wpack, n32);
     CSD_LAUNCH_CHECK();
