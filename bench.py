@@ -133,7 +133,7 @@ def main():
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU')
-    ap.add_argument('--precision', default=os.environ.get('CSD_PRECISION', 'fp16x3'), choices=['fp32', 'fp16x3', 'fp16'],
+    ap.add_argument('--precision', default=os.environ.get('CSD_PRECISION', 'fp16x3'), choices=['fp32', 'fp16x3', 'fp16f8', 'fp16'],
                     help='arithmetic of the 3x3 contractions (all modes pass the 1e-3 parity tests)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='tuning aid: time the loop without the in-library event profiler')
@@ -256,6 +256,13 @@ def main():
                                     'ring, 3x v_mfma_f32_32x32x16_f16 per product; the 160^2 / 80^2 levels = 70 % of the class time) + '
                                     'conv_f16_q_kernel<NS=2> (40^2 and below)'), F16_MFMA_PEAK_TF / 3
             dom_note = 'fp16 MFMA dense peak (2500 TF) / 3 MFMAs per algorithmic product; achieved counts algorithmic flops'
+        elif args.precision == 'fp16f8':
+            dom_kernel, dom_peak = ('3x3 stride-1 convolution class: conv_ff_kernel<NS=2,F8> (fused GroupNorm+SiLU+split prologue, LDS-DMA weight '
+                                    'ring; hi*hi on v_mfma_f32_32x32x16_f16, the two correction products K-concatenated on '
+                                    'v_mfma_scale_f32_32x32x64_f8f6f4; the 160^2 / 80^2 levels) + conv_f16_q_kernel<NS=2> (40^2 and below, '
+                                    '3 fp16 MFMAs per product)'), F16_MFMA_PEAK_TF / 2
+            dom_note = ('fp16 MFMA dense peak (2500 TF) / 2: one fp16 MFMA per product + two correction products at the fp8 rate '
+                        '(half an fp16 MFMA each); achieved counts algorithmic flops')
         else:
             dom_kernel, dom_peak = ('3x3 stride-1 convolution class: conv_ff_kernel<NS=1> (fused GroupNorm+SiLU prologue, v_mfma_f32_32x32x16_f16) '
                                     '+ conv_f16_lc_kernel<NS=1> (40^2 and below)'), F16_MFMA_PEAK_TF
@@ -293,6 +300,8 @@ def main():
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'fp32': 'f32', 'fp16x3': 'f16x3 (split hi+lo fp16 operands, 3 MFMAs, f32 accumulate; f32-class error)',
+                      'fp16f8': 'f16+f8 (operands split hi+lo; hi*hi on the fp16 MFMA, the two correction products with e4m3 operands on the '
+                                'fp8 MFMA, f32 accumulate; 1e-4-class error, certified to 1e-3)',
                       'fp16': 'f16 (f32 accumulate)'}[args.precision], 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: celebA_SR3_160 (ddpm_paired_SR3, nf=96, ch_mult (1,1,2,2,3,3), '
                                    'attn 20/10/5), 1000-step PC (reverse_diffusion + langevin, snr 0.15), '
@@ -320,7 +329,7 @@ def main():
             # the other two arithmetic modes, measured the same way in short side runs (reported, not the headline)
             import subprocess
             alt = {}
-            for mode in ('fp32', 'fp16x3', 'fp16'):
+            for mode in ('fp32', 'fp16x3', 'fp16f8', 'fp16'):
                 if mode == args.precision:
                     continue
                 try:

@@ -18,7 +18,7 @@ MAX_LEVELS = 8
 MAX_ATTN = 8
 
 ACT_IDS = {'none': 0, 'swish': 1, 'relu': 2, 'lrelu': 3, 'elu': 4}
-PREC_IDS = {'fp32': 0, 'f32': 0, 'fp16x3': 1, 'fp16': 2}
+PREC_IDS = {'fp32': 0, 'f32': 0, 'fp16x3': 1, 'fp16': 2, 'fp16f8': 3}
 
 
 class UNetConfig(ctypes.Structure):

@@ -11,6 +11,7 @@
 namespace csd {
 
 typedef unsigned int uint4f __attribute__((ext_vector_type(4)));
+typedef int int8v __attribute__((ext_vector_type(8)));
 
 #define FF_THREADS 256
 #define FF_TILE 16

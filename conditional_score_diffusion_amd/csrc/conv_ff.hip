@@ -30,8 +30,17 @@
 
 namespace csd {
 
-template <int NS, int NT>
+// F8 (NS = 2 only): "fp16 + fp8 corrections" - the operands are still split x = hi + lo, hi*hi runs on v_mfma_f32_32x32x16_f16, but
+// the two correction products hi_w*lo_x + lo_w*hi_x (2^-11 of the result: ~4 significant bits are enough) run K-concatenated
+// on the fp8 matrix cores: ONE v_mfma_scale_f32_32x32x64_f8f6f4 (OCP e4m3 operands, block scale 2^-11 undoing the scaling
+// of the lo parts) per TWO taps x 16 channels, its K = 64 being [hi_w | lo_w] . [lo_x | hi_x] of tap t (lanes 0-31) and of
+// tap t+1 (lanes 32-63).  MFMA cycles per 16-channel stage: 54 x 32 + 30 x 64 = 3648 against 162 x 32 = 5184; measured
+// network error 2e-5 norm-wise / 8e-5 element-wise (oracle/fp8_correction_study.py) against 1.2e-6 / 4.5e-6 of the full split.
+// LDS formats: pixel record [hi fp16 x16 | lo*2^11 e4m3 x16 | hi e4m3 x16] (64 B, as NS = 2); weight step [cout tile][plane]
+// with plane 0 = fp16 A fragments, plane 1 = [cout row][hi e4m3 x16 | lo*2^11 e4m3 x16] (32 B per row).
+template <int NS, int NT, bool F8>
 __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __restrict__ g_wpack, const ConvFFArgs k) {
+  static_assert(!F8 || NS == 2, "the fp8-correction form shares the two-plane layouts");
   using C = FFCfg<NS, NT>;
   constexpr int KC = C::KC, STEPS = C::STEPS, TG = C::TG, GPS = C::GPS, SB = C::SB, GB = C::GB, GL = C::GL, R = C::R;
   constexpr int G4 = C::G4, NSLOT = C::NSLOT, PPJ = C::PPJ, NDMA = C::NDMA, GLW = C::GLW;
@@ -143,17 +152,34 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
         for (int q = 0; q < 4; ++q) h[q] = h[q] * __builtin_amdgcn_rcpf(1.0f + __expf(-h[q]));      // (v_rcp_f32: 1 ulp)
       }
       half4 hi, lo;
+      float lof[4], hif[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float v = in ? h[q] : 0.f;             // padding is applied to the ACTIVATED tensor: exactly 0
         hi[q] = (_Float16)v;
         lo[q] = (_Float16)(v - (float)hi[q]);
+        if constexpr (F8) {
+          // e4m3 saturates at 448 and turns larger inputs into NaN: clamp (|lo| * 2^11 <= |hi| by construction)
+          hif[q] = __builtin_fminf(__builtin_fmaxf((float)hi[q], -448.f), 448.f);
+          lof[q] = __builtin_fminf(__builtin_fmaxf((v - (float)hi[q]) * 2048.f, -448.f), 448.f);
+        }
       }
       // (slots past the patch - possible in the last j only - land in the 16 pad bytes at the end of patch row 17)
       const bool real = (j * PPJ + PPJ - 1 < FF_NPATCH) || pixr < FF_NPATCH;
       char* dst = buf + (real ? dtab[pix] + lg * 8 : FF_PATCH_BYTES - 16);
       *reinterpret_cast<half4*>(dst) = hi;
-      if (NS == 2) *reinterpret_cast<half4*>(dst + (real ? 32 : 8)) = lo;
+      if constexpr (F8) {
+        int l8 = 0, h8 = 0;
+        l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lof[0], lof[1], l8, false);
+        l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lof[2], lof[3], l8, true);
+        h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hif[0], hif[1], h8, false);
+        h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hif[2], hif[3], h8, true);
+        char* d8 = buf + (real ? dtab[pix] + 32 + lg * 4 : FF_PATCH_BYTES - 8);
+        *reinterpret_cast<int*>(d8) = l8;
+        *reinterpret_cast<int*>(d8 + (real ? 16 : 4)) = h8;
+      } else if (NS == 2) {
+        *reinterpret_cast<half4*>(dst + (real ? 32 : 8)) = lo;
+      }
     }
   };
 
@@ -224,6 +250,10 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) base[mt] = (4 * wave + (p32 >> 3)) * FF_RS + (8 * mt + (p32 & 7)) * FF_PSB + kh * 16;
 
+  int base8[2];                                      // F8: the pixel record itself (the lane's K half selects a TAP there, not a channel half)
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) base8[mt] = (4 * wave + (p32 >> 3)) * FF_RS + (8 * mt + (p32 & 7)) * FF_PSB + 32;
+
   ff_barrier();                                      // tables visible
   FF_TS();
   if (wave < NDMA) ff_wait_vm<(R - 3) * GLW>();      // groups 0 and 1 have landed
@@ -239,7 +269,8 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
     const bool more = s + 1 < k_nstage;
     if (!W0 && more && !FF_ABL(4)) issue_patch(s + 1, std::true_type{});
     const char* const pb = patch + (s & 1) * FF_PATCH_BYTES;
-    half8 wa[2][NT][NS], xb[2][2][NS];
+    constexpr int NP = F8 ? 1 : NS;                  // fp16 planes read per fragment
+    half8 wa[2][NT][NP], xb[2][2][NP];
     auto load_frags = [&](int buf, int step, int sl) __attribute__((always_inline)) {     // step: compile-time after unrolling
       const int ksub = step / 9, tap = step - ksub * 9;
       const int r = tap / 3, sx = tap - r * 3;
@@ -247,12 +278,37 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int pl = 0; pl < NS; ++pl) wa[buf][nt][pl] = *reinterpret_cast<const half8*>(wb + (nt * NS + pl) * 1024);
+        for (int pl = 0; pl < NP; ++pl) wa[buf][nt][pl] = *reinterpret_cast<const half8*>(wb + (nt * NS + pl) * 1024);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int pl = 0; pl < NS; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
           xb[buf][mt][pl] = *reinterpret_cast<const half8*>(pb + base[mt] + r * FF_RS + sx * FF_PSB + (NS == 1 ? ksub * 32 : pl * 32));
+    };
+    // F8: operands of the correction MFMA of the tap pair (tap, tap + 1): lanes 0-31 carry tap, lanes 32-63 tap + 1 (whose ring
+    // group has landed: the invariant below); the unpaired last tap multiplies zeros in the upper K half
+    int8v wa8[NT], xb8[2];
+    auto load_frags8 = [&](int tap, int sl) __attribute__((always_inline)) {
+      const bool pair = tap + 1 < 9;
+      const int t1 = pair ? tap + 1 : tap;
+      const int o0 = (tap / 3) * FF_RS + (tap % 3) * FF_PSB, o1 = (t1 / 3) * FF_RS + (t1 % 3) * FF_PSB;
+      const int sl1 = pair ? (sl + 1 == R ? 0 : sl + 1) : sl;
+      const char* const wb = ring + (kh ? sl1 : sl) * GB + p32 * 32;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const uint4f a = *reinterpret_cast<const uint4f*>(wb + (nt * 2 + 1) * 1024);
+        const uint4f c = *reinterpret_cast<const uint4f*>(wb + (nt * 2 + 1) * 1024 + 16);
+        const bool z = !pair && kh;
+        wa8[nt] = int8v{z ? 0 : (int)a.x, z ? 0 : (int)a.y, z ? 0 : (int)a.z, z ? 0 : (int)a.w,
+                        z ? 0 : (int)c.x, z ? 0 : (int)c.y, z ? 0 : (int)c.z, z ? 0 : (int)c.w};
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const char* const xp = pb + base8[mt] + (kh ? o1 : o0);
+        const uint4f a = *reinterpret_cast<const uint4f*>(xp);
+        const uint4f c = *reinterpret_cast<const uint4f*>(xp + 16);
+        xb8[mt] = int8v{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)c.x, (int)c.y, (int)c.z, (int)c.w};
+      }
     };
     load_frags(0, 0, slot);
 #pragma unroll
@@ -271,7 +327,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
       // the MFMA block would start ~160 cycles late, and reads placed before it would be waited for at once (lgkmcnt(0)).
       // MFMAs on ONE accumulator stay back to back (tools/mfma_chain.hip: 2465 TF/s against 2218 round-robin).
       auto mma = [&](int mt, int nt) __attribute__((always_inline)) {
-        if constexpr (NS == 2) {                     // small terms first: lo*hi, hi*lo, then hi*hi
+        if constexpr (NS == 2 && !F8) {              // small terms first: lo*hi, hi*lo, then hi*hi
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][nt][1], xb[cur][mt][0], acc[mt][nt], 0, 0, 0);
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][nt][0], xb[cur][mt][1], acc[mt][nt], 0, 0, 0);
         }
@@ -287,12 +343,23 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
         if (last) sl = slot + 1 == R ? 0 : slot + 1;
         load_frags(cur ^ 1, step + 1, sl);
       }
+      const bool corr = F8 && (step % 2 == 0);       // taps 0, 2, 4, 6 bring their right neighbour, tap 8 goes alone
+      if constexpr (F8) {
+        if (corr) load_frags8(step, slot);           // (read under the remaining fp16 MFMAs of this step)
+      }
       __builtin_amdgcn_sched_barrier(0);
       FF_FS(step * 5 + 2);
 #pragma unroll
       for (int i = 1; i < 2 * NT; ++i) {
         mma(i / NT, i % NT);
         if (NS == 2) __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (F8) {
+#pragma unroll
+        for (int i = 0; i < (corr ? 2 * NT : 0); ++i) {
+          acc[i / NT][i % NT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa8[i % NT], xb8[i / NT], acc[i / NT][i % NT], 0, 0, 0,
+                                                                                  116, 0, 127);      // block scale 2^-11 on A
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       FF_FS(step * 5 + 3);
@@ -459,14 +526,14 @@ static inline int ff_nt(int cout) { return 3; }      // (NT = 4, the nf = 128 ne
 bool convff_supported(const ConvPlan& p, int ns) {
   if (getenv("CSD_NO_FF")) return false;
   const int kc = ns == 1 ? 32 : 16;
-  return (ns == 1 || ns == 2) && p.taps == 9 && p.stride == 1 && p.up == 0 && p.pad == 1 && p.C0 > 0 && p.C0 % kc == 0 &&
+  return (ns >= 1 && ns <= 3) && p.taps == 9 && p.stride == 1 && p.up == 0 && p.pad == 1 && p.C0 > 0 && p.C0 % kc == 0 &&
          p.C1 % kc == 0 && p.Cout % 96 == 0 && p.OH % FF_TILE == 0 && p.OW % FF_TILE == 0 &&
          p.IH == p.OH && p.IW == p.OW;
 }
 
 size_t convff_packed_bytes(const ConvPlan& p, int ns) {
   const int nt = ff_nt(p.Cout);
-  return (size_t)(p.Cout / (32 * nt)) * ((p.C0 + p.C1) / 16) * 9 * nt * ns * 1024 + 4096;
+  return (size_t)(p.Cout / (32 * nt)) * ((p.C0 + p.C1) / 16) * 9 * nt * (ns == 3 ? 2 : ns) * 1024 + 4096;
 }
 
 // weights in A-fragment order of v_mfma_f32_32x32x16_f16: [cout group][cin / 16][tap][cout tile][plane][lane][8 halves],
@@ -488,10 +555,18 @@ __global__ void convff_pack_kernel(const float* __restrict__ w, _Float16* __rest
   const int ng = cout / gc, t = (cout % gc) / 32, row = cout % 32;
   const int kb = cin / 16, khalf = (cin % 16) / 8, e = cin % 8;
   const size_t step = ((size_t)ng * (Cin / 16) + kb) * 9 + tap;
-  _Float16* dst = wpack + ((step * nt + t) * (size_t)ns) * 512 + (khalf * 32 + row) * 8 + e;
+  const int planes = ns == 3 ? 2 : ns;                // ns = 3: fp16 hi plane + one plane of e4m3 correction operands
+  _Float16* dst = wpack + ((step * nt + t) * (size_t)planes) * 512 + (khalf * 32 + row) * 8 + e;
   const _Float16 hi = (_Float16)v;
   dst[0] = hi;
   if (ns == 2) dst[512] = (_Float16)(v - (float)hi);
+  if (ns == 3) {                                      // [cout row][hi e4m3 x16 | lo * 2^11 e4m3 x16]
+    const float hf = fminf(fmaxf((float)hi, -448.f), 448.f), lf = fminf(fmaxf((v - (float)hi) * 2048.f, -448.f), 448.f);
+    const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(hf, lf, 0, false);
+    unsigned char* c8 = reinterpret_cast<unsigned char*>(wpack + ((step * nt + t) * (size_t)planes + 1) * 512) + row * 32 + (cin % 16);
+    c8[0] = (unsigned char)(pk & 255);
+    c8[16] = (unsigned char)((pk >> 8) & 255);
+  }
 }
 
 __global__ void convff_zero_kernel(uint32_t* p, size_t n) {
@@ -531,9 +606,9 @@ int convff_plan_tiles(ConvPlan* p, int ns) {
   return CSD_OK;
 }
 
-template <int NS, int NT>
+template <int NS, int NT, bool F8>
 static int launch_ff(const ConvFFArgs& k, hipStream_t s) {
-  auto kern = conv_ff_kernel<NS, NT>;
+  auto kern = conv_ff_kernel<NS, NT, F8>;
   static bool attr_set = false;
   if (!attr_set) {
     CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -573,8 +648,9 @@ int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
   // (its consumer waves have nobody to cover their epilogue and fragment-read latency)
   static const bool persistent = getenv("CSD_FF_PERSISTENT") != nullptr;
   if (persistent) return convffp_launch(k, ns, s);
-  if (ns == 1) return launch_ff<1, 3>(k, s);
-  return launch_ff<2, 3>(k, s);
+  if (ns == 1) return launch_ff<1, 3, false>(k, s);
+  if (ns == 3) return launch_ff<2, 3, true>(k, s);
+  return launch_ff<2, 3, false>(k, s);
 }
 
 }  // namespace csd

@@ -104,7 +104,7 @@ extern "C" size_t csd_conv_scratch_bytes(int B, int Cin, int Cout, int H, int W,
 int csd::conv2d_impl(const float* x, const float* weight, const float* bias, const float* res, const float* temb, float* y, int B,
                      int Cin, int Cout, int H, int W, int ksize, int stride, int pad_mode, int up2, int precision, int layout, void* scratch, void* stream) {
   CSD_REQUIRE(x && weight && y && scratch, "conv2d: null argument");
-  CSD_REQUIRE(precision >= CSD_PREC_F32 && precision <= CSD_PREC_F16, "conv2d: bad precision id %d", precision);
+  CSD_REQUIRE(precision >= CSD_PREC_F32 && precision <= CSD_PREC_F16F8, "conv2d: bad precision id %d", precision);
   const bool in_nhwc = layout & 1, out_nhwc = layout & 2;
   CSD_REQUIRE(!res || out_nhwc, "conv2d: a residual needs an NHWC output");
   hipStream_t s = (hipStream_t)stream;
@@ -205,9 +205,10 @@ extern "C" int csd_conv3x3_block(const float* x0, const float* x1, const float* 
                                  float* y, double* stats, int B, int C0, int C1, int Cout, int H, int W, int precision,
                                  void* scratch, void* stream) {
   CSD_REQUIRE(x0 && weight && y && scratch, "conv3x3_block: null argument");
-  CSD_REQUIRE(precision == CSD_PREC_F16X3 || precision == CSD_PREC_F16, "conv3x3_block: precision must be fp16x3 or fp16");
+  CSD_REQUIRE(precision == CSD_PREC_F16X3 || precision == CSD_PREC_F16 || precision == CSD_PREC_F16F8,
+              "conv3x3_block: precision must be fp16x3, fp16 or fp16f8");
   hipStream_t s = (hipStream_t)stream;
-  const int ns = precision_ns(precision);
+  const int ns = precision == CSD_PREC_F16F8 ? 3 : precision_ns(precision);
   ConvPlan p;
   memset(&p, 0, sizeof(p));
   p.B = B; p.IH = p.OH = H; p.IW = p.OW = W; p.C0 = C0; p.C1 = C1; p.Cout = Cout; p.taps = 9; p.stride = 1; p.pad = 1; p.up = 0;

@@ -235,7 +235,7 @@ static int build_modules(Net& n) {
               c.image_size, c.n_levels - 1);
   CSD_REQUIRE(c.x_channels >= 1 && c.x_channels + c.y_channels <= 8, "unet: x+y channels must be <= 8");
   CSD_REQUIRE(c.act >= CSD_ACT_SWISH && c.act <= CSD_ACT_ELU, "unet: bad activation id %d", c.act);
-  CSD_REQUIRE(c.precision >= CSD_PREC_F32 && c.precision <= CSD_PREC_F16, "unet: bad precision id %d", c.precision);
+  CSD_REQUIRE(c.precision >= CSD_PREC_F32 && c.precision <= CSD_PREC_F16F8, "unet: bad precision id %d", c.precision);
   auto add = [&](ModKind k, int cin, int cout) {
     Module m;
     m.kind = k; m.idx = (int)n.mods.size(); m.cin = cin; m.cout = cout;
@@ -349,7 +349,7 @@ static int build_modules_ncsnpp(Net& n) {
   CSD_REQUIRE(c.out_channels == c.x_channels + c.y_channels, "ncsnpp: the network maps its %d input channels to as many outputs",
               c.x_channels + c.y_channels);
   CSD_REQUIRE(c.act >= CSD_ACT_SWISH && c.act <= CSD_ACT_ELU, "ncsnpp: bad activation id %d", c.act);
-  CSD_REQUIRE(c.precision >= CSD_PREC_F32 && c.precision <= CSD_PREC_F16, "ncsnpp: bad precision id %d", c.precision);
+  CSD_REQUIRE(c.precision >= CSD_PREC_F32 && c.precision <= CSD_PREC_F16F8, "ncsnpp: bad precision id %d", c.precision);
   CSD_REQUIRE(c.conditional, "ncsnpp: only time-conditional networks are supported");
   CSD_REQUIRE(c.progressive >= 0 && c.progressive <= 1 && c.progressive_input >= 0 && c.progressive_input <= 1,
               "ncsnpp: 'residual' progressive growing is not supported");
@@ -501,7 +501,7 @@ static int build_packed_layout(Net& n) {
     ConvPlan ffp = pc.proto;
     ffp.IH = ffp.IW = ffp.OH = ffp.OW = cur_res;
     if (net_ns && normed && stride1 && !resample && n.cfg.act == CSD_ACT_SWISH && convff_supported(ffp, net_ns)) {
-      pc.ns = net_ns;
+      pc.ns = n.cfg.precision == CSD_PREC_F16F8 ? 3 : net_ns;      // 3: fp16 hi*hi + fp8 corrections (conv_ff.hip)
       pc.ff = true;
       pc.proto.KC = 16;
       pc.w_off = take(convff_packed_bytes(pc.proto, pc.ns) / sizeof(float) + 1);

@@ -42,7 +42,10 @@ enum { CSD_ACT_NONE = 0, CSD_ACT_SWISH = 1, CSD_ACT_RELU = 2, CSD_ACT_LRELU = 3,
 enum {
   CSD_PREC_F32 = 0,          /* fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32): exact fp32 fmaf chain */
   CSD_PREC_F16X3 = 1,        /* split-fp16 (hi+lo) operands, 3 fp16 MFMAs, fp32 accumulate        */
-  CSD_PREC_F16 = 2           /* fp16 operands, fp32 accumulate                                      */
+  CSD_PREC_F16 = 2,          /* fp16 operands, fp32 accumulate                                      */
+  CSD_PREC_F16F8 = 3         /* split operands; hi*hi on the fp16 MFMA, the two correction products K-concatenated on the fp8 MFMA
+                                (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3 operands, block scale 2^-11) in the fused-prologue block
+                                convolution; every other layer as CSD_PREC_F16X3.  Network error ~2e-5 (fp16x3: 1e-6, fp16: 5e-4) */
 };
 
 const char* csd_version(void);
