@@ -133,7 +133,7 @@ def main():
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU')
-    ap.add_argument('--precision', default=os.environ.get('CSD_PRECISION', 'fp16x3'), choices=['fp32', 'fp16x3', 'fp16f8', 'fp16'],
+    ap.add_argument('--precision', default=os.environ.get('CSD_PRECISION', 'fp16f8'), choices=['fp32', 'fp16x3', 'fp16f8', 'fp16'],
                     help='arithmetic of the 3x3 contractions (all modes pass the 1e-3 parity tests)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='tuning aid: time the loop without the in-library event profiler')

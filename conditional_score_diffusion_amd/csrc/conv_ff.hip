@@ -244,6 +244,35 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
           acc[mt][nt][q * 4 + 2] = bv[nt * 4 + q].z * C16_WSCALE; acc[mt][nt][q * 4 + 3] = bv[nt * 4 + q].w * C16_WSCALE;
         }
   }
+  // the residual (the block's shortcut) joins the accumulators HERE, not in the epilogue: its loads travel under the first
+  // stage's patch round trip, the epilogue is scale + store only (it used to spend ~10 k cycles per tile on issue -> wait -> add)
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int RSRC_FLAGS = 0x00020000;
+  const size_t tile_pix = img0 + (size_t)ty0 * kW + tx0;
+  int opix[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) opix[mt] = (4 * wave + (p32 >> 3)) * kW + 8 * mt + (p32 & 7);
+  if (a_res != nullptr && !FF_ABL(8)) {
+    const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_res + tile_pix * kCout), 0, OOB, RSRC_FLAGS);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {                 // (one M tile at a time: 48 registers of loads in flight, not 96)
+      uint4f rv[NT][4];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          rv[nt][q] = __builtin_amdgcn_raw_buffer_load_b128(res_r, (unsigned)(opix[mt] * kCout + c_lane + nt * 32 + q * 8) * 4u, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[mt][nt][q * 4 + 0] += __uint_as_float(rv[nt][q].x) * C16_WSCALE;
+          acc[mt][nt][q * 4 + 1] += __uint_as_float(rv[nt][q].y) * C16_WSCALE;
+          acc[mt][nt][q * 4 + 2] += __uint_as_float(rv[nt][q].z) * C16_WSCALE;
+          acc[mt][nt][q * 4 + 3] += __uint_as_float(rv[nt][q].w) * C16_WSCALE;
+        }
+    }
+  }
 
   // per-lane LDS offset of tap (0,0) of its pixel in M tile mt (rows 4*wave + (p32 >> 3), cols 8*mt + (p32 & 7)) + K half
   int base[2];
@@ -381,51 +410,16 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
   }
 
   // ---- epilogue ----
-  constexpr unsigned OOB = 0x80000000u;
-  constexpr int RSRC_FLAGS = 0x00020000;
   const float wunscale = 1.0f / C16_WSCALE;
-  const size_t tile_pix = img0 + (size_t)ty0 * kW + tx0;
   const __amdgpu_buffer_rsrc_t out_r =
       __builtin_amdgcn_make_buffer_rsrc(a_out + tile_pix * a_out_stride + a_out_coff, 0, OOB, RSRC_FLAGS);
-  const bool has_res = a_res != nullptr && !FF_ABL(8);
   if (FF_ABL(16)) return;
-  const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(has_res ? a_res + tile_pix * kCout : a_out), 0, OOB, RSRC_FLAGS);
-  int opix[2];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) opix[mt] = (4 * wave + (p32 >> 3)) * kW + 8 * mt + (p32 & 7);
-  // every read before the first store (vmcnt retires in order and counts stores)
-  if (has_res) {
-    float4 rv[2][NT][4];
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const unsigned off = (unsigned)(opix[mt] * kCout + c_lane + nt * 32 + q * 8) * 4u;
-          const uint4f u = __builtin_amdgcn_raw_buffer_load_b128(res_r, off, 0, 0);
-          rv[mt][nt][q] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
-        }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[mt][nt][q * 4 + 0] = (acc[mt][nt][q * 4 + 0] * wunscale + rv[mt][nt][q].x) * a_out_scale;
-          acc[mt][nt][q * 4 + 1] = (acc[mt][nt][q * 4 + 1] * wunscale + rv[mt][nt][q].y) * a_out_scale;
-          acc[mt][nt][q * 4 + 2] = (acc[mt][nt][q * 4 + 2] * wunscale + rv[mt][nt][q].z) * a_out_scale;
-          acc[mt][nt][q * 4 + 3] = (acc[mt][nt][q * 4 + 3] * wunscale + rv[mt][nt][q].w) * a_out_scale;
-        }
-  } else {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = acc[mt][nt][r] * wunscale * a_out_scale;
-  }
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = acc[mt][nt][r] * wunscale * a_out_scale;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll

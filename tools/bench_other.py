@@ -11,7 +11,7 @@ from conditional_score_diffusion_amd.models import utils as mutils
 from conditional_score_diffusion_amd.sampling import conditional, correctors, predictors
 
 dev = torch.device('cuda:0')
-prec = sys.argv[1] if len(sys.argv) > 1 else 'fp16x3'
+prec = sys.argv[1] if len(sys.argv) > 1 else 'fp16f8'
 
 
 def cmde128(B=64, steps=20):
