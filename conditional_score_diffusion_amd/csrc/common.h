@@ -130,7 +130,7 @@ int pw16_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int 
 int pw16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s);
 // y16 = fp16 split of act(x*scale + shift): hi plane (and lo plane when ns == 2), NHWC halves [B*HW][C0+C1]
 int gn_apply16_launch(const float* src0, const float* src1, int C0, int C1, const float* nscale, const float* nshift,
-                      void* hi, void* lo, int B, int HW, int act, hipStream_t s);
+                      void* hi, void* lo, int B, int HW, int act, hipStream_t s, int f8 = 0);
 static inline int precision_ns(int precision) {   // CSD_PREC_* -> number of fp16 planes (0: fp32 kernel)
   return (precision == CSD_PREC_F16X3 || precision == CSD_PREC_F16F8) ? 2 : (precision == CSD_PREC_F16 ? 1 : 0);
 }

@@ -47,7 +47,14 @@ __device__ __forceinline__ double dpp_row16_sum(double v) {
 // S: stride.  S = 2 is the reference Downsample (pad (0,1,0,1), models/layers.py:619-625): the patch of a TH x TW output
 // tile is (2*TH+1) x (2*TW+1) input pixels and a lane's tap (0,0) sits at (2*ty, 2*tx).
 // NTQ: 16-cout tiles per N half - 3 (Cout % 96 == 0: the nf = 96 nets) or 4 (Cout % 128 == 0: the nf = 128 nets)
-template <int MQ, int NS, bool MASK, int PWC, int S, int NTQ>
+// F8 (NS = 2 layouts): "fp16 + fp8 corrections" (CSD_PREC_F16F8).  hi*hi stays on v_mfma_f32_16x16x32_f16; the two correction products
+// hi_w*lo_x + lo_w*hi_x run K-concatenated on v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 operands, block scale 2^-11): ONE instruction
+// per cout tile per TWO taps x 32 channels - lanes 0-31 carry tap t (K block = channel half), lanes 32-63 tap t+1.  The second
+// plane of the staged pixel holds, per channel, the byte pair (lo * 2^11, hi) in e4m3 (written by gn_apply16_kernel), the second
+// plane of a weight step [channel half][cout row][16 x (hi, lo * 2^11)] - byte j of an A lane meets byte j of the B lane.
+typedef int int8q __attribute__((ext_vector_type(8)));
+
+template <int MQ, int NS, bool MASK, int PWC, int S, int NTQ, bool F8>
 __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void* __restrict__ g_hi,
                                                                     const void* __restrict__ g_lo,
                                                                     const char* __restrict__ g_wpack,
@@ -171,14 +178,30 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
   constexpr int BR = 3;
   const int nk32 = Cin / 32;
   const char* wstep = g_wpack + ((size_t)(ng * 2 + ni) * nk32 * TAPS) * WSTEP + lane * 16;
-  half8 wreg[BR][NTQ][NS];
+  constexpr int NP = F8 ? 1 : NS;               // fp16 planes read per fragment
+  half8 wreg[BR][NTQ][NP];
 #pragma unroll
   for (int q = 0; q < BR - 1; ++q)
 #pragma unroll
     for (int t = 0; t < NTQ; ++t)
 #pragma unroll
-      for (int p = 0; p < NS; ++p) wreg[q][t][p] = gload_h8(wstep + (size_t)q * WSTEP + (t * NS + p) * 1024);
+      for (int p = 0; p < NP; ++p) wreg[q][t][p] = gload_h8(wstep + (size_t)q * WSTEP + (t * NS + p) * 1024);
   wstep += (size_t)(BR - 2) * WSTEP;
+  // F8: correction operands of a tap pair, one pair ahead: lane (kq >> 1) selects the tap, (kq & 1) the channel half
+  const char* const w8base = g_wpack + ((size_t)(ng * 2 + ni) * nk32 * TAPS + (kq >> 1)) * WSTEP + (lane & 31) * 32 + 1024;
+  int8q w8[1][NTQ];                              // (single buffer: refilled right after a pair's MFMAs, two taps before its next use)
+  auto load_w8 = [&](int buf, int step) {       // step = global K step (stage * 9 + tap) of the pair's first tap
+#pragma unroll
+    for (int t = 0; t < NTQ; ++t) {
+      const uint4q a = *reinterpret_cast<const uint4q*>(w8base + (size_t)step * WSTEP + t * NS * 1024);
+      const uint4q c = *reinterpret_cast<const uint4q*>(w8base + (size_t)step * WSTEP + t * NS * 1024 + 16);
+      w8[buf][t] = int8q{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)c.x, (int)c.y, (int)c.z, (int)c.w};
+    }
+  };
+  if constexpr (F8) load_w8(0, 0);
+  int base8[MQ];                                 // the lane's pixel record + second plane + channel half (tap added per pair)
+#pragma unroll
+  for (int j = 0; j < MQ; ++j) base8[j] = base[j] - kq * 16 + LO + (kq & 1) * 32;
 
   floatx4q acc[MQ][NTQ];
 #pragma unroll
@@ -210,12 +233,12 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
 #else
     constexpr int RING = 2;
 #endif
-    half8 preg[RING][NS];
+    half8 preg[RING][NP];
     auto load_frag = [&](int q) {               // q = tap * MQ + j
       const int tap_ = q / MQ, j_ = q % MQ;
       const char* p = smem16 + base[j_] + (tap_ / KS) * rstride + (tap_ % KS) * PSB;
 #pragma unroll
-      for (int pl = 0; pl < NS; ++pl) preg[q % RING][pl] = *reinterpret_cast<const half8*>(p + pl * LO);
+      for (int pl = 0; pl < NP; ++pl) preg[q % RING][pl] = *reinterpret_cast<const half8*>(p + pl * LO);
     };
 #pragma unroll
     for (int q = 0; q < RING - 1; ++q) load_frag(q);
@@ -235,16 +258,17 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
 #pragma unroll
       for (int t = 0; t < ((CSD_Q_ABLATE & 1) ? 1 : NTQ); ++t)
 #pragma unroll
-        for (int p = 0; p < NS; ++p) wreg[bn][t][p] = gload_h8(wstep + (t * NS + p) * 1024);
+        for (int p = 0; p < NP; ++p) wreg[bn][t][p] = gload_h8(wstep + (t * NS + p) * 1024);
+
 #pragma unroll
       for (int j = 0; j < MQ; ++j) {
         const int q = tap * MQ + j;
         if (q + RING - 1 < TAPS * MQ) load_frag(q + RING - 1);
         __builtin_amdgcn_sched_barrier(0);
-        half8 b[NS];
+        half8 b[NP];
         const bool v = !MASK || (((vbits[j] >> r) & 1u) && ((vbits[j] >> (3 + sx)) & 1u));
 #pragma unroll
-        for (int pl = 0; pl < NS; ++pl) {
+        for (int pl = 0; pl < NP; ++pl) {
           b[pl] = preg[q % RING][pl];
           if (MASK && !v) {
 #pragma unroll
@@ -253,13 +277,42 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
         }
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) {
-          if (NS == 2) {
+          if constexpr (NS == 2 && !F8) {
             acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[bc][t][1], b[0], acc[j][t], 0, 0, 0);
             acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[bc][t][0], b[1], acc[j][t], 0, 0, 0);
           }
           acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[bc][t][0], b[0], acc[j][t], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (F8) {
+        if (tap % 2 == 1 || tap == TAPS - 1) {     // the pair (t0, t0 + 1) is complete (or the last tap stands alone)
+          const int t0 = tap % 2 == 1 ? tap - 1 : tap;
+          const bool pair = t0 + 1 < TAPS;
+          const int t1 = pair ? t0 + 1 : t0;
+          const int o0 = (t0 / KS) * rstride + (t0 % KS) * PSB, o1 = (t1 / KS) * rstride + (t1 % KS) * PSB;
+          const int off = (kq >> 1) ? o1 : o0;
+          constexpr int wb = 0;
+#pragma unroll
+          for (int j = 0; j < MQ; ++j) {
+            const char* xp = smem16 + base8[j] + off;
+            const uint4q a = *reinterpret_cast<const uint4q*>(xp);
+            const uint4q c = *reinterpret_cast<const uint4q*>(xp + 16);
+            bool ok = pair || (kq >> 1) == 0;        // the upper K half of the unpaired tap multiplies zeros
+            if (MASK) {
+              const int tt = (kq >> 1) ? t1 : t0;
+              ok = ok && ((vbits[j] >> (tt / KS)) & 1u) && ((vbits[j] >> (3 + tt % KS)) & 1u);
+            }
+            const int8q b8 = int8q{ok ? (int)a.x : 0, ok ? (int)a.y : 0, ok ? (int)a.z : 0, ok ? (int)a.w : 0,
+                                   ok ? (int)c.x : 0, ok ? (int)c.y : 0, ok ? (int)c.z : 0, ok ? (int)c.w : 0};
+#pragma unroll
+            for (int t = 0; t < NTQ; ++t)
+              acc[j][t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8[wb][t], b8, acc[j][t], 0, 0, 0, 116, 0, 127);
+          }
+          // the next pair's correction weights (the last pair of a stage fetches the next stage's first): two taps of MFMAs to arrive
+          const int nxt = t0 + 2 < TAPS ? stg * TAPS + t0 + 2 : (stg + 1) * TAPS;
+          if (t0 + 2 < TAPS || more) load_w8(0, nxt);
+        }
       }
     }
     static_assert(TAPS % BR == 0, "weight ring phase");
@@ -368,20 +421,22 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
 // host side
 // ---------------------------------------------------------------------------------------------
 bool conv16q_supported(const ConvPlan& p, int ns) {
-  return (ns == 1 || ns == 2) && p.taps == 9 && ((p.stride == 1 && (p.up == 0 || p.up == 1)) || (p.stride == 2 && p.up == 0)) &&
-         p.C1 == 0 && p.C0 % 32 == 0 && (p.Cout % 96 == 0 || p.Cout % 128 == 0);
+  return (ns >= 1 && ns <= 3) && p.taps == 9 && ((p.stride == 1 && (p.up == 0 || p.up == 1)) || (p.stride == 2 && p.up == 0)) &&
+         p.C1 == 0 && p.C0 % 32 == 0 && (p.Cout % 96 == 0 || (p.Cout % 128 == 0 && ns != 3));
 }
 
 // 16-cout tiles per N half: groups of 96 couts where that divides (the layout the nf = 96 nets have always had), else of 128
 static inline int q_ntq(int cout) { return cout % 96 == 0 ? 3 : 4; }
 
+// ns = 3 (fp16 + fp8 corrections): two planes like ns = 2, the second one holds e4m3 byte pairs
 size_t conv16q_packed_bytes(const ConvPlan& p, int ns) {
+  if (ns == 3) ns = 2;
   const int ntq = q_ntq(p.Cout);
   return (size_t)(p.Cout / (32 * ntq)) * 2 * (p.C0 / 32) * 9 * ntq * ns * 1024 + (size_t)4 * ntq * ns * 1024;   // + prefetch slack
 }
 
 __global__ void conv16q_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ wpack, int layout, int cin_src,
-                                    int cout_src, int cout_off, int Cin, int Cout, int ns, int ntq) {
+                                    int cout_src, int cout_off, int Cin, int Cout, int ns, int ntq, int f8) {
   // one thread per (cout in [cout_off, cout_off + cout_src), cin, tap)
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)cout_src * Cin * 9;
@@ -407,7 +462,15 @@ __global__ void conv16q_pack_kernel(const float* __restrict__ w, _Float16* __res
   _Float16* dst = wpack + (step * ntq + t) * (size_t)ns * 512 + lane * 8 + q;
   const _Float16 hi = (_Float16)v;
   dst[0] = hi;
-  if (ns == 2) dst[512] = (_Float16)(v - (float)hi);
+  if (ns == 2 && !f8) dst[512] = (_Float16)(v - (float)hi);
+  if (f8) {                                            // second plane: [channel half][cout row][16 x (hi, lo * 2^11)] in e4m3
+    const float hf = fminf(fmaxf((float)hi, -448.f), 448.f), lf = fminf(fmaxf((v - (float)hi) * 2048.f, -448.f), 448.f);
+    const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(hf, lf, 0, false);
+    unsigned char* c8 = reinterpret_cast<unsigned char*>(wpack + ((step * ntq + t) * (size_t)ns + 1) * 512) +
+                        (((cin % 32) / 16) * 16 + r) * 32 + (cin % 16) * 2;
+    c8[0] = (unsigned char)(pk & 255);
+    c8[1] = (unsigned char)((pk >> 8) & 255);
+  }
 }
 
 __global__ void conv16q_zero_kernel(uint32_t* p, size_t n) {
@@ -417,6 +480,8 @@ __global__ void conv16q_zero_kernel(uint32_t* p, size_t n) {
 
 int conv16q_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int cin_src, int cout_src, int cout_off,
                         void* wpack, hipStream_t s) {
+  const int f8 = ns == 3;
+  if (f8) ns = 2;
   if (cout_off == 0 && (cin_src != p.C0 || cout_src != p.Cout)) {     // (a weight that fills the packed layout needs no zero fill)
     const size_t n32 = conv16q_packed_bytes(p, ns) / 4;
     hipLaunchKernelGGL(conv16q_zero_kernel, dim3((unsigned)cdiv64(n32, 256)), dim3(256), 0, s, (uint32_t*)wpack, n32);
@@ -424,7 +489,7 @@ int conv16q_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, i
   }
   const size_t total = (size_t)cout_src * p.C0 * 9;
   hipLaunchKernelGGL(conv16q_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w, (_Float16*)wpack, layout,
-                     cin_src, cout_src, cout_off, p.C0, p.Cout, ns, q_ntq(p.Cout));
+                     cin_src, cout_src, cout_off, p.C0, p.Cout, ns, q_ntq(p.Cout), f8);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
@@ -439,6 +504,7 @@ int conv16q_plan_tiles(ConvPlan* p, int ns) {
   p->n_groups = p->Cout / (32 * p->NT);
   p->KCS = 2;
   p->LC = 0;
+  if (ns == 3) ns = 2;                          // (same staged-pixel geometry)
   const int psb = 32 * 2 * ns + 16;
   const int spp = 2 * ns * 2;
   const int st = p->stride;
@@ -483,9 +549,9 @@ int conv16q_plan_tiles(ConvPlan* p, int ns) {
   return CSD_OK;
 }
 
-template <int MQ, int NS, bool MASK, int PWC, int S, int NTQ>
+template <int MQ, int NS, bool MASK, int PWC, int S, int NTQ, bool F8 = false>
 static int launch_q(const Conv16KArgs& k, size_t lds, hipStream_t s) {
-  auto kern = conv_f16_q_kernel<MQ, NS, MASK, PWC, S, NTQ>;
+  auto kern = conv_f16_q_kernel<MQ, NS, MASK, PWC, S, NTQ, F8>;
   static bool attr_set = false;
   if (!attr_set) {
     CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -544,6 +610,25 @@ int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) 
     if (mask) return launch_q<MQ_, NS_, true, 34, 2, NTQ_>(k, p.lds_bytes, s);      \
     return launch_q<MQ_, NS_, false, 34, 2, NTQ_>(k, p.lds_bytes, s);               \
   }
+#define CSD_Q8_CASE(MQ_, NTQ_)                                                         \
+  if (p.MT == MQ_ && ns == 3 && p.NT == NTQ_ && p.stride == 1) {                     \
+    if (p.PW <= 24) {                                                                \
+      if (mask) return launch_q<MQ_, 2, true, 24, 1, NTQ_, true>(k, p.lds_bytes, s);  \
+      return launch_q<MQ_, 2, false, 24, 1, NTQ_, true>(k, p.lds_bytes, s);           \
+    }                                                                                \
+    if (mask) return launch_q<MQ_, 2, true, 34, 1, NTQ_, true>(k, p.lds_bytes, s);    \
+    return launch_q<MQ_, 2, false, 34, 1, NTQ_, true>(k, p.lds_bytes, s);             \
+  }                                                                                  \
+  if (p.MT == MQ_ && ns == 3 && p.NT == NTQ_ && p.stride == 2) {                     \
+    if (p.PW <= 24) {                                                                \
+      if (mask) return launch_q<MQ_, 2, true, 24, 2, NTQ_, true>(k, p.lds_bytes, s);  \
+      return launch_q<MQ_, 2, false, 24, 2, NTQ_, true>(k, p.lds_bytes, s);           \
+    }                                                                                \
+    if (mask) return launch_q<MQ_, 2, true, 34, 2, NTQ_, true>(k, p.lds_bytes, s);    \
+    return launch_q<MQ_, 2, false, 34, 2, NTQ_, true>(k, p.lds_bytes, s);             \
+  }
+  CSD_Q8_CASE(4, 3) CSD_Q8_CASE(2, 3)      // (Cout % 96 == 0 only: with four cout tiles the 128-pixel form spills; those nets run the full split)
+#undef CSD_Q8_CASE
   CSD_Q_CASE(4, 2, 3) CSD_Q_CASE(2, 2, 3) CSD_Q_CASE(4, 1, 3) CSD_Q_CASE(2, 1, 3)
   CSD_Q_CASE(4, 2, 4) CSD_Q_CASE(2, 2, 4) CSD_Q_CASE(4, 1, 4) CSD_Q_CASE(2, 1, 4)
 #undef CSD_Q_CASE

@@ -204,7 +204,7 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(GA_THREADS) void gn_apply16_kernel(
     const float* __restrict__ src0, const float* __restrict__ src1, int C0, int C1,
     const float* __restrict__ nscale, const float* __restrict__ nshift, half8_t* __restrict__ hi,
-    half8_t* __restrict__ lo, int HW, int act, int nchunk) {
+    half8_t* __restrict__ lo, int HW, int act, int nchunk, int f8) {
   const int C = C0 + C1;
   const int C8 = C >> 3;
   const int rows = GA_THREADS / C8;           // pixel rows per sweep (>= 1: C <= 2048)
@@ -251,6 +251,11 @@ __global__ __launch_bounds__(GA_THREADS) void gn_apply16_kernel(
       }
       h[j] = (_Float16)t;
       l[j] = (_Float16)(t - (float)h[j]);
+      if (f8) {          // second plane = per channel the e4m3 byte pair (lo * 2^11, hi): operands of the fp8 correction MFMA
+        const float hf = fminf(fmaxf((float)h[j], -448.f), 448.f), lf = fminf(fmaxf((t - (float)h[j]) * 2048.f, -448.f), 448.f);
+        const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(lf, hf, 0, false);
+        l[j] = __builtin_bit_cast(_Float16, (unsigned short)(pk & 0xffff));
+      }
     }
     hdst[(size_t)p * C8] = h;
     if (ldst) ldst[(size_t)p * C8] = l;
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(GA_THREADS) void gn_apply16_kernel(
 }
 
 int gn_apply16_launch(const float* src0, const float* src1, int C0, int C1, const float* nscale, const float* nshift,
-                      void* hi, void* lo, int B, int HW, int act, hipStream_t s) {
+                      void* hi, void* lo, int B, int HW, int act, hipStream_t s, int f8) {
   const int C = C0 + C1;
   CSD_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && C / 8 <= GA_THREADS, "gn_apply16: channels must be multiples of 8, <= 2048");
   int nchunk = cdiv(4096, B);
@@ -266,7 +271,7 @@ int gn_apply16_launch(const float* src0, const float* src1, int C0, int C1, cons
   if (nchunk > maxchunk) nchunk = maxchunk;
   if (nchunk < 1) nchunk = 1;
   hipLaunchKernelGGL(gn_apply16_kernel, dim3(nchunk, B), dim3(GA_THREADS), 0, s, src0, src1, C0, C1, nscale, nshift,
-                     static_cast<half8_t*>(hi), static_cast<half8_t*>(lo), HW, act, nchunk);
+                     static_cast<half8_t*>(hi), static_cast<half8_t*>(lo), HW, act, nchunk, f8);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
