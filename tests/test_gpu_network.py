@@ -104,7 +104,7 @@ def test_pc_trajectory_vs_golden(golden_dir, case, p_steps):
         assert np.abs(ev.numpy() - g['pc10_evolution']).max() / smax < 2e-4
 
 
-@pytest.mark.parametrize('precision,tol_net,tol_traj', [('fp16x3', 1e-4, 2e-4), ('fp16', 2e-2, 1e-3)])
+@pytest.mark.parametrize('precision,tol_net,tol_traj', [('fp16x3', 1e-4, 2e-4), ('fp16f8', 3e-4, 2e-4), ('fp16', 2e-2, 1e-3)])
 @pytest.mark.parametrize('case', ['sr3_tiny', 'cmde_tiny'])
 def test_fp16_mfma_modes_vs_golden(golden_dir, case, precision, tol_net, tol_traj):
     """the reduced-precision conv modes against the SAME reference fixtures: split-fp16 must hold the
@@ -134,7 +134,7 @@ def test_fp16_mfma_modes_vs_golden(golden_dir, case, precision, tol_net, tol_tra
     assert e_net < tol_net and e_traj < tol_traj, (e_net, e_traj)
 
 
-@pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('fp16x3', 2e-5), ('fp16', 5e-3)])
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('fp16x3', 2e-5), ('fp16f8', 2e-4), ('fp16', 5e-3)])
 def test_nf96_batch_unmasked_tiles(precision, tol):
     """nf=96 (3 cout tiles per workgroup), 32x32 images, B=3: pixel tiles lie inside one image, so the
     fp16 kernel runs WITHOUT tap masks and must zero the halo rows that belong to the neighbouring image of
@@ -150,6 +150,31 @@ def test_nf96_batch_unmasked_tiles(precision, tol):
         ref = so.paired_forward(p, nc, x, y, lab, True)
         out = model({'x': x.to(dev()), 'y': y.to(dev())}, lab.to(dev()))
     assert rel(out.cpu().numpy(), ref.numpy()) < tol
+
+
+@pytest.mark.parametrize('S,B,ch_mult,attn', [(40, 3, (1, 2, 2), (20, 10)), (32, 5, (1, 1, 2, 2, 3, 3), (4, 2, 1)), (64, 2, (1, 2, 2, 3), (8,)),
+                                            (80, 2, (1, 2, 3), (20,))])
+def test_fp16f8_networks_vs_oracle(S, B, ch_mult, attn):
+    """the fp8-correction arithmetic (CSD_PREC_F16F8) through every kernel form that carries it: conv_ff at 80 / 64 / 32 / 16 pixel
+    maps, conv_f16_q with and without tap masks (tiles straddling samples at 40 / 20 / 10 / 8 / 5 / 4 / 2 / 1), the unpaired ninth
+    tap, odd batches - nf = 96 networks with the SR3-160 block structure against the fp32 oracle: norm-wise 1e-4, element-wise
+    4e-4 (measured ~1e-5 / 4e-5; plain fp16 sits at 7e-4 / 3e-3 on the same inputs)"""
+    kw = dict(cases.SR3_160)
+    kw.update(image_size=S, ch_mult=ch_mult, attn_resolutions=attn)
+    cfg = cases.make_config(**kw)
+    cfg, nc, p, model = build(cfg, 'fp16f8')
+    rs = np.random.RandomState(3)
+    x = torch.from_numpy(rs.standard_normal((B, 3, S, S)).astype(np.float32) * 20)
+    y = torch.from_numpy(rs.uniform(0, 1, (B, 3, S, S)).astype(np.float32))
+    lab = torch.full((B,), 600.)
+    with torch.no_grad():
+        ref = so.paired_forward(p, nc, x, y, lab, True).double()
+        out = model({'x': x.to(dev()), 'y': y.to(dev())}, lab.to(dev())).double().cpu()
+    rms = float(ref.pow(2).mean().sqrt())
+    nw = float((out - ref).norm() / ref.norm())
+    ew = float(((out - ref).abs() / (ref.abs() + rms)).max())
+    print('fp16f8 %dx%d B=%d: %.2e norm-wise, %.2e element-wise' % (S, S, B, nw, ew))
+    assert nw < 1e-4 and ew < 4e-4
 
 
 def test_generic_per_step_path_matches_fused():
@@ -186,7 +211,7 @@ def test_generic_per_step_path_matches_fused():
     assert rel(xm.cpu().numpy(), x_f.cpu().numpy(), floor=sde.sigma_max) < 1e-5
 
 
-@pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('fp16x3', 2e-5), ('fp16', 3e-3)])
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('fp16x3', 2e-5), ('fp16f8', 2e-4), ('fp16', 3e-3)])
 def test_full_size_sr3_160_forward_vs_oracle(precision, tol):
     """cfg1/cfg2 network (nf=96, ch_mult (1,1,2,2,3,3), attention at 20/10/5) at 160x160, B=2, every precision mode
     (measured: fp32 2.1e-6, fp16x3 1.8e-6, fp16 8.6e-4):
@@ -290,7 +315,7 @@ def test_use_path_sampler_vs_golden(golden_dir):
     assert np.abs(out.cpu().numpy() - g['out']).max() / smax < 2e-4
 
 
-@pytest.mark.parametrize('precision,tol', [('fp16x3', 3e-5), ('fp16', 5e-3), ('fp32', 3e-5)])
+@pytest.mark.parametrize('precision,tol', [('fp16x3', 3e-5), ('fp16f8', 3e-4), ('fp16', 5e-3), ('fp32', 3e-5)])
 def test_nf128_network_vs_oracle(precision, tol):
     """nf = 128 (the VS-CMDE edges2shoes and NCSN++-256 widths): Cout = 128 / 256 run the quad schedule with four 16-cout
     tiles per N half (groups of 128 couts) instead of three; odd batch, tiles that straddle samples."""

@@ -84,7 +84,7 @@ def test_per_shard_and_global_norm_modes_vs_reference(golden_dir, case):
     assert np.abs(a.cpu().numpy() - b.cpu().numpy()).max() / smax < 1e-6
 
 
-@pytest.mark.parametrize('precision,tol', [('fp32', 1e-3), ('fp16x3', 1e-3)])
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-3), ('fp16x3', 1e-3), ('fp16f8', 1e-3)])
 @pytest.mark.parametrize('case', ['sr3_tiny', 'cmde_tiny'])
 def test_thousand_step_schedule_vs_reference(golden_dir, case, precision, tol):
     """the real 1000-step schedule end to end (2000 network evaluations; labels, sigma(t), G_i of every step)"""
