@@ -151,17 +151,21 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
 #pragma unroll
         for (int q = 0; q < 4; ++q) h[q] = h[q] * __builtin_amdgcn_rcpf(1.0f + __expf(-h[q]));      // (v_rcp_f32: 1 ulp)
       }
+      // VALU instructions are NOT free next to MFMAs on this chip (tools/mfma_valu_overlap.hip: a second wave's VALU stream overlaps a
+      // wave's MFMA stream by ~15 %): every instruction here is matrix-pipe time.  hi by packed conversion; lo = v - hi as ONE mixed-
+      // precision fma on the fp16 value (no conversion back); the e4m3 "hi" operand is taken from v itself (3 mantissa bits either way)
       half4 hi, lo;
       float lof[4], hif[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float v = in ? h[q] : 0.f;             // padding is applied to the ACTIVATED tensor: exactly 0
         hi[q] = (_Float16)v;
-        lo[q] = (_Float16)(v - (float)hi[q]);
         if constexpr (F8) {
           // e4m3 saturates at 448 and turns larger inputs into NaN: clamp (|lo| * 2^11 <= |hi| by construction)
-          hif[q] = __builtin_fminf(__builtin_fmaxf((float)hi[q], -448.f), 448.f);
-          lof[q] = __builtin_fminf(__builtin_fmaxf((v - (float)hi[q]) * 2048.f, -448.f), 448.f);
+          hif[q] = __builtin_amdgcn_fmed3f(v, -448.f, 448.f);
+          lof[q] = __builtin_amdgcn_fmed3f(__builtin_fmaf((float)hi[q], -2048.f, v * 2048.f), -448.f, 448.f);
+        } else {
+          lo[q] = (_Float16)__builtin_fmaf((float)hi[q], -1.0f, v);
         }
       }
       // (slots past the patch - possible in the last j only - land in the 16 pad bytes at the end of patch row 17)
