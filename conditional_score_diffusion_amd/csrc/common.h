@@ -112,6 +112,10 @@ size_t conv16q_packed_bytes(const ConvPlan& p, int ns);
 int conv16q_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int cin_src, int cout_src, int cout_off,
                         void* wpack, hipStream_t s);
 int conv16q_plan_tiles(ConvPlan* p, int ns);
+// phase-decomposed Upsample on the quad schedule (ConvPlan.up == 2; conv_f16_q.hip)
+bool conv16q_up4_supported(const ConvPlan& p, int ns);
+size_t conv16q_up4_packed_bytes(const ConvPlan& p, int ns);
+int conv16q_pack_weight_up4(const ConvPlan& p, int ns, const float* w, void* wpack, hipStream_t s);
 int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s);
 // fused-prologue schedule (conv_ff.hip): 3x3 stride-1 layers on 16 x 16 tiles that lie inside one sample, fp32 NHWC sources
 // (two-source virtual concat), GroupNorm affine + activation + fp16 split applied while staging (no gn_apply16 pass)

@@ -54,12 +54,17 @@ __device__ __forceinline__ double dpp_row16_sum(double v) {
 // plane of a weight step [channel half][cout row][16 x (hi, lo * 2^11)] - byte j of an A lane meets byte j of the B lane.
 typedef int int8q __attribute__((ext_vector_type(8)));
 
-template <int MQ, int NS, bool MASK, int PWC, int S, int NTQ, bool F8>
+// UP4 (S = 1): the reference Upsample = nearest x2 + 3x3 conv (models/layers.py:600-604) as FOUR 2x2 convolutions of the SOURCE image,
+// one per output phase (a, b) = (row, column parity): output (2y+a, 2x+b) reads source rows {y-1, y} (a = 0) or {y, y+1} (a = 1) -
+// taps that land on the same source pixel are summed when the weights are packed (conv16q_pack_up4_kernel).  4 taps instead of 9 per
+// output pixel (2.25x fewer MACs); a workgroup = (source tile, phase, cout group), its outputs are written with stride 2.
+template <int MQ, int NS, bool MASK, int PWC, int S, int NTQ, bool F8, bool UP4 = false>
 __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void* __restrict__ g_hi,
                                                                     const void* __restrict__ g_lo,
                                                                     const char* __restrict__ g_wpack,
                                                                     const Conv16KArgs k) {
-  constexpr int TAPS = 9, KS = 3, KCS = 2;
+  static_assert(!UP4 || (S == 1 && !F8), "the phase form is the stride-1 Upsample conv (a resampling conv: full split)");
+  constexpr int TAPS = UP4 ? 4 : 9, KS = UP4 ? 2 : 3, KCS = 2;
   constexpr int LO = 32 * KCS;               // byte offset of the lo plane inside a staged pixel
   constexpr int PSB = 32 * KCS * NS + 16;    // bytes per staged pixel
   constexpr int NPIX = 2 * MQ * 16;          // pixels per workgroup tile
@@ -91,11 +96,13 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
     w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
   const int ng = w % k.n_groups;
-  const int tile = w / k.n_groups;
+  const int tile4 = w / k.n_groups;          // UP4: (source tile, phase); else the tile
+  const int ph = UP4 ? (tile4 & 3) : 0, pa = ph >> 1, pb = ph & 1;
+  const int tile = UP4 ? (tile4 >> 2) : tile4;
   const int tile_y = tile / k.tiles_x;
   const int ov0 = tile_y * k.TH, ox0 = (tile - tile_y * k.tiles_x) * k.TW;
-  constexpr int P = (S == 2) ? 0 : 1;        // top/left padding
-  const int prow0 = ov0 * S - P, pcol0 = ox0 * S - P;
+  const int Py = UP4 ? 1 - pa : ((S == 2) ? 0 : 1), Px = UP4 ? 1 - pb : ((S == 2) ? 0 : 1);        // top / left padding
+  const int prow0 = ov0 * S - Py, pcol0 = ox0 * S - Px;
   const int EH = (S == 2) ? k.IH : k.OH, EW = (S == 2) ? k.IW : k.OW;     // the image the patch coordinates live in
   const int Cin = k.C0;
   const int npatch = k.PH * k.PW;
@@ -115,11 +122,12 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
     unsigned vb = 0;
 #pragma unroll
     for (int r = 0; r < KS; ++r) {
-      const int iy = oy * S + r - P, ix = ox * S + r - P;
+      const int iy = oy * S + r - Py, ix = ox * S + r - Px;
       vb |= ((mv && iy >= 0 && iy < EH) ? 1u : 0u) << r;      // (bounds of the image the conv runs on: upsampled when k.up)
       vb |= ((mv && ix >= 0 && ix < EW) ? 1u : 0u) << (3 + r);
     }
-    otab[m] = mv ? (ov - ov0) * k.OW + ox : -1;
+    // (UP4: k.OH / k.OW are the SOURCE size; the output pixel sits at (2 ov + a, 2 ox + b) of the 2 OW wide output)
+    otab[m] = mv ? (UP4 ? (ov - ov0) * 4 * k.OW + 2 * ox : (ov - ov0) * k.OW + ox) : -1;
     btab[m] = mv ? b : 0;
     vtab[m] = (int)vb;
   }
@@ -175,9 +183,9 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
   };
 
   // ---- weight stream of this wave: 3 fragments (x NS planes) per K step, ring of BR steps ----
-  constexpr int BR = 3;
+  constexpr int BR = UP4 ? 2 : 3;
   const int nk32 = Cin / 32;
-  const char* wstep = g_wpack + ((size_t)(ng * 2 + ni) * nk32 * TAPS) * WSTEP + lane * 16;
+  const char* wstep = g_wpack + ((size_t)((UP4 ? ph * k.n_groups * 2 : 0) + ng * 2 + ni) * nk32 * TAPS) * WSTEP + lane * 16;
   constexpr int NP = F8 ? 1 : NS;               // fp16 planes read per fragment
   half8 wreg[BR][NTQ][NP];
 #pragma unroll
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
       for (int p = 0; p < NP; ++p) wreg[q][t][p] = gload_h8(wstep + (size_t)q * WSTEP + (t * NS + p) * 1024);
   wstep += (size_t)(BR - 2) * WSTEP;
   // F8: correction operands of a tap pair, one pair ahead: lane (kq >> 1) selects the tap, (kq & 1) the channel half
-  const char* const w8base = g_wpack + ((size_t)(ng * 2 + ni) * nk32 * TAPS + (kq >> 1)) * WSTEP + (lane & 31) * 32 + 1024;
+  const char* const w8base = g_wpack + ((size_t)(ng * 2 + ni) * nk32 * TAPS + (kq >> 1)) * WSTEP + (lane & 31) * 32 + 1024;      // (never with UP4)
   int8q w8[1][NTQ];                              // (single buffer: refilled right after a pair's MFMAs, two taps before its next use)
   auto load_w8 = [&](int buf, int step) {       // step = global K step (stage * 9 + tap) of the pair's first tap
 #pragma unroll
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
   constexpr unsigned OOB = 0x80000000u;
   constexpr int RSRC_FLAGS = 0x00020000;
   const float wunscale = 1.0f / C16_WSCALE;
-  const size_t o_base = (size_t)ov0 * k.OW;
+  const size_t o_base = UP4 ? ((size_t)(2 * ov0 + pa) * 2 * k.OW + pb) : (size_t)ov0 * k.OW;
   const int b0 = ov0 / k.OH;
   const bool has_res = k.a.res != nullptr, has_temb = k.a.temb != nullptr;
   const __amdgpu_buffer_rsrc_t out_r =
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
       for (int i = 0; i < 4; ++i) {
         const double s = dpp_row16_sum(st_s[t][i]), q = dpp_row16_sum(st_q[t][i]);
         if (l16 == 0) {
-          double* dst = k.a.stats + (((size_t)tile * 2 + mi) * k.Cout + c_base + t * 16 + i) * 2;
+          double* dst = k.a.stats + (((size_t)tile4 * 2 + mi) * k.Cout + c_base + t * 16 + i) * 2;
           dst[0] = s;
           dst[1] = q;
         }
@@ -423,6 +431,58 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
 bool conv16q_supported(const ConvPlan& p, int ns) {
   return (ns >= 1 && ns <= 3) && p.taps == 9 && ((p.stride == 1 && (p.up == 0 || p.up == 1)) || (p.stride == 2 && p.up == 0)) &&
          p.C1 == 0 && p.C0 % 32 == 0 && (p.Cout % 96 == 0 || (p.Cout % 128 == 0 && ns != 3));
+}
+
+// ConvPlan.up == 2 selects the phase-decomposed Upsample (UP4): same source / output sizes as up == 1
+bool conv16q_up4_supported(const ConvPlan& p, int ns) {
+  ConvPlan q = p;
+  q.up = 1;
+  return (ns == 1 || ns == 2) && p.stride == 1 && conv16q_supported(q, ns) && !getenv("CSD_NO_UP4");
+}
+
+size_t conv16q_up4_packed_bytes(const ConvPlan& p, int ns) {
+  const int ntq = p.Cout % 96 == 0 ? 3 : 4;
+  return (size_t)4 * (p.Cout / (32 * ntq)) * 2 * (p.C0 / 32) * 4 * ntq * ns * 1024 + (size_t)4 * ntq * ns * 1024;   // 4 phases x 4 taps
+}
+
+// phase weights: W_ab[i][j] = sum of the 3x3 taps (r, s) whose upsampled source row / column is i / j of the phase's 2x2 window:
+// a = 0: i = 0 <- {r = 0}, i = 1 <- {1, 2};  a = 1: i = 0 <- {0, 1}, i = 1 <- {2}  (columns alike); summed in fp32, then split.
+// layout [phase][cout group][N half][cin / 32][tap 0..3][16-cout tile][plane][lane][8 halves]
+__global__ void conv16q_pack_up4_kernel(const float* __restrict__ w, _Float16* __restrict__ wpack, int Cin, int Cout, int ns, int ntq) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)Cout * Cin * 16;
+  {
+    const size_t body32 = (size_t)4 * (Cout / (32 * ntq)) * 2 * (Cin / 32) * 4 * ntq * ns * 256, slack32 = (size_t)ntq * ns * 1024;
+    if (idx < slack32) reinterpret_cast<uint32_t*>(wpack)[body32 + idx] = 0u;
+  }
+  if (idx >= total) return;
+  const int pt = (int)(idx % 16), ph = pt >> 2, tap = pt & 3;
+  const int cin = (int)((idx / 16) % Cin);
+  const int cout = (int)(idx / ((size_t)16 * Cin));
+  const int a = ph >> 1, b = ph & 1, i = tap >> 1, j = tap & 1;
+  const int r0 = a == 0 ? (i == 0 ? 0 : 1) : (i == 0 ? 0 : 2), r1 = a == 0 ? (i == 0 ? 0 : 2) : (i == 0 ? 1 : 2);
+  const int s0 = b == 0 ? (j == 0 ? 0 : 1) : (j == 0 ? 0 : 2), s1 = b == 0 ? (j == 0 ? 0 : 2) : (j == 0 ? 1 : 2);
+  float v = 0.f;
+  for (int r = r0; r <= r1; ++r)
+    for (int sx = s0; sx <= s1; ++sx) v += w[((size_t)cout * Cin + cin) * 9 + r * 3 + sx];
+  v *= C16_WSCALE;
+  const int gc = 32 * ntq, hc = 16 * ntq;
+  const int ng = cout / gc, ni = (cout % gc) / hc, t = (cout % hc) / 16, rr = cout % 16;
+  const int kb = cin / 32, kq = (cin % 32) / 8, q = cin % 8;
+  const int lane = kq * 16 + rr;
+  const size_t step = (((size_t)ph * (Cout / gc) * 2 + ng * 2 + ni) * (Cin / 32) + kb) * 4 + tap;
+  _Float16* dst = wpack + (step * ntq + t) * (size_t)ns * 512 + lane * 8 + q;
+  const _Float16 hi = (_Float16)v;
+  dst[0] = hi;
+  if (ns == 2) dst[512] = (_Float16)(v - (float)hi);
+}
+
+int conv16q_pack_weight_up4(const ConvPlan& p, int ns, const float* w, void* wpack, hipStream_t s) {
+  const size_t total = (size_t)p.Cout * p.C0 * 16;
+  hipLaunchKernelGGL(conv16q_pack_up4_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w, (_Float16*)wpack, p.C0, p.Cout, ns,
+                     p.Cout % 96 == 0 ? 3 : 4);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
 }
 
 // 16-cout tiles per N half: groups of 96 couts where that divides (the layout the nf = 96 nets have always had), else of 128
@@ -495,9 +555,13 @@ int conv16q_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, i
 }
 
 static int in_coord_q(int t, int stride = 1) { return stride * (t - 1) + 3; }      // patch extent of a t-pixel tile edge (3x3)
+static int in_coord_k(int t, int stride, int ks) { return stride * (t - 1) + ks; }
 
 int conv16q_plan_tiles(ConvPlan* p, int ns) {
-  CSD_REQUIRE(conv16q_supported(*p, ns), "conv16q: unsupported shape (Cin=%d Cout=%d)", p->C0, p->Cout);
+  const bool up4 = p->up == 2;
+  CSD_REQUIRE(up4 ? conv16q_up4_supported(*p, ns) : conv16q_supported(*p, ns), "conv16q: unsupported shape (Cin=%d Cout=%d)", p->C0, p->Cout);
+  // (UP4 tiles the SOURCE image: one workgroup per (source tile, phase, cout group), 2x2 taps)
+  const int OHt = up4 ? p->IH : p->OH, OWt = up4 ? p->IW : p->OW, ks = up4 ? 2 : 3;
   p->KC = C16_KC;
   p->CoutPad = p->Cout;
   p->NT = q_ntq(p->Cout);
@@ -509,23 +573,23 @@ int conv16q_plan_tiles(ConvPlan* p, int ns) {
   const int spp = 2 * ns * 2;
   const int st = p->stride;
   const int nu = st == 2 ? (ns == 2 ? 10 : 5) : (ns == 2 ? 7 : 4);
-  auto pitch = [&](int tw) { return in_coord_q(tw, st) <= 24 ? 24 : 34; };
+  auto pitch = [&](int tw) { return in_coord_k(tw, st, ks) <= 24 ? 24 : 34; };
   int best_mq = 0, best_tw = 0, best_th = 0;
   for (int mq = 4; mq >= 2; mq >>= 1) {        // 128- or 64-pixel tiles
     const int npix = 2 * mq * 16;
     int btw = 0, bth = 0, blds = 1 << 30;
     double bcov = -1;
     bool bunm = false;
-    for (int tw = 1; tw <= 32 && tw <= p->OW; ++tw) {
-      if (p->OW % tw != 0 && !(tw == 32 && p->OW > 32)) continue;
-      if (in_coord_q(tw, st) > 34) continue;
+    for (int tw = 1; tw <= 32 && tw <= OWt; ++tw) {
+      if (OWt % tw != 0 && !(tw == 32 && OWt > 32)) continue;
+      if (in_coord_k(tw, st, ks) > 34) continue;
       // the tallest tile of this width that fits LDS and the staging slots (th * tw may be < npix: spare pixels are masked)
       for (int th = npix / tw; th >= 1; --th) {
-        const int patch = in_coord_q(th, st) * in_coord_q(tw, st);
-        const int lds = in_coord_q(th, st) * pitch(tw) * psb;
+        const int patch = in_coord_k(th, st, ks) * in_coord_k(tw, st, ks);
+        const int lds = in_coord_k(th, st, ks) * pitch(tw) * psb;
         if (lds > 72 * 1024 || patch * spp > nu * C16Q_THREADS) continue;
-        const double cov = (double)th * tw * p->OW / ((double)cdiv(p->OW, tw) * tw);
-        const bool unm = (p->OH % th) == 0;
+        const double cov = (double)th * tw * OWt / ((double)cdiv(OWt, tw) * tw);
+        const bool unm = (OHt % th) == 0;
         if (cov > bcov + 1e-9 || (cov > bcov - 1e-9 && ((unm && !bunm) || (unm == bunm && lds < blds)))) {
           bcov = cov; blds = lds; btw = tw; bth = th; bunm = unm;
         }
@@ -535,23 +599,23 @@ int conv16q_plan_tiles(ConvPlan* p, int ns) {
     if (btw == 0) continue;
     if (mq > 2 && bcov < 0.75 * npix) continue;        // a large tile that would be mostly masked: try the smaller one
     best_mq = mq; best_tw = btw; best_th = bth;
-    const long nwg = (long)cdiv(p->OW, btw) * cdiv(p->B * p->OH, bth) * p->n_groups;
+    const long nwg = (long)cdiv(OWt, btw) * cdiv(p->B * OHt, bth) * p->n_groups * (up4 ? 4 : 1);
     if (nwg >= 512 || mq == 2) break;
   }
   CSD_REQUIRE(best_tw > 0, "conv16q: no feasible tile for OW=%d", p->OW);
   p->TW = best_tw; p->TH = best_th;
-  p->PH = in_coord_q(p->TH, st); p->PW = in_coord_q(p->TW, st);
-  p->tiles_x = cdiv(p->OW, p->TW);
-  p->tiles_y = cdiv(p->B * p->OH, p->TH);
+  p->PH = in_coord_k(p->TH, st, ks); p->PW = in_coord_k(p->TW, st, ks);
+  p->tiles_x = cdiv(OWt, p->TW);
+  p->tiles_y = cdiv(p->B * OHt, p->TH);
   p->MT = best_mq;           // (field reused: 16-pixel tiles per wave)
   p->lds_bytes = (size_t)p->PH * pitch(p->TW) * psb + (size_t)3 * 2 * best_mq * 16 * sizeof(int) +
                  (size_t)2 * p->PH * p->PW * sizeof(int);
   return CSD_OK;
 }
 
-template <int MQ, int NS, bool MASK, int PWC, int S, int NTQ, bool F8 = false>
+template <int MQ, int NS, bool MASK, int PWC, int S, int NTQ, bool F8 = false, bool UP4 = false>
 static int launch_q(const Conv16KArgs& k, size_t lds, hipStream_t s) {
-  auto kern = conv_f16_q_kernel<MQ, NS, MASK, PWC, S, NTQ, F8>;
+  auto kern = conv_f16_q_kernel<MQ, NS, MASK, PWC, S, NTQ, F8, UP4>;
   static bool attr_set = false;
   if (!attr_set) {
     CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -564,7 +628,8 @@ static int launch_q(const Conv16KArgs& k, size_t lds, hipStream_t s) {
 }
 
 int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
-  CSD_REQUIRE(conv16q_supported(p, ns), "conv16q: unsupported layer");
+  const bool up4 = p.up == 2;
+  CSD_REQUIRE(up4 ? conv16q_up4_supported(p, ns) : conv16q_supported(p, ns), "conv16q: unsupported layer");
   CSD_REQUIRE(!a.out_nchw && a.nscale == nullptr && a.out_stride % 4 == 0 && a.out_coff % 4 == 0,
               "conv16q: NHWC fp32 output with 16-byte aligned rows, pre-normalised fp16 source");
   Conv16KArgs k;
@@ -588,11 +653,25 @@ int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) 
   k.stride = p.stride; k.pad = p.stride == 2 ? 0 : 1; k.up = p.up;
   k.TH = p.TH; k.TW = p.TW; k.PH = p.PH; k.PW = p.PW;
   k.tiles_x = p.tiles_x; k.n_groups = p.n_groups;
-  k.nblocks = p.tiles_x * p.tiles_y * p.n_groups;
+  k.nblocks = p.tiles_x * p.tiles_y * p.n_groups * (up4 ? 4 : 1);
+  if (up4) { k.OH = p.IH; k.OW = p.IW; k.up = 0; }      // the kernel tiles the source image
   k.nck = p.C0 / C16_KC;
   k.nw = 4;
   k.ntiles_n = p.Cout / 32;
-  const bool mask = (p.OH % p.TH) != 0;
+  const bool mask = ((up4 ? p.IH : p.OH) % p.TH) != 0;
+#define CSD_QU_CASE(MQ_, NS_, NTQ_)                                                              \
+  if (up4 && p.MT == MQ_ && ns == NS_ && p.NT == NTQ_) {                                        \
+    if (p.PW <= 24) {                                                                            \
+      if (mask) return launch_q<MQ_, NS_, true, 24, 1, NTQ_, false, true>(k, p.lds_bytes, s);    \
+      return launch_q<MQ_, NS_, false, 24, 1, NTQ_, false, true>(k, p.lds_bytes, s);             \
+    }                                                                                            \
+    if (mask) return launch_q<MQ_, NS_, true, 34, 1, NTQ_, false, true>(k, p.lds_bytes, s);      \
+    return launch_q<MQ_, NS_, false, 34, 1, NTQ_, false, true>(k, p.lds_bytes, s);               \
+  }
+  CSD_QU_CASE(4, 2, 3) CSD_QU_CASE(2, 2, 3) CSD_QU_CASE(4, 1, 3) CSD_QU_CASE(2, 1, 3)
+  CSD_QU_CASE(4, 2, 4) CSD_QU_CASE(2, 2, 4) CSD_QU_CASE(4, 1, 4) CSD_QU_CASE(2, 1, 4)
+#undef CSD_QU_CASE
+  CSD_REQUIRE(!up4, "conv16q: no phase kernel for MQ=%d ns=%d NT=%d", p.MT, ns, p.NT);
 #define CSD_Q_CASE(MQ_, NS_, NTQ_)                                                  \
   if (p.MT == MQ_ && ns == NS_ && p.NT == NTQ_ && p.stride == 1) {                  \
     if (p.PW <= 24) {                                                               \

@@ -91,6 +91,7 @@ struct PackedConv {
   bool pw = false;               // ns != 0 and the layer runs on the pointwise fp16 kernel (conv_pw16.hip)
   bool q = false;                // ns != 0 and the layer runs on the quad-wave fp16 kernel (conv_f16_q.hip)
   bool ff = false;               // ns != 0 and the layer runs on the fused-prologue kernel (conv_ff.hip): fp32 sources, no gn_apply16
+  bool up4 = false;              // q and the layer is the nearest-x2 Upsample conv in its phase-decomposed form (4 x 2x2 taps; conv_f16_q.hip UP4)
   struct Src { int param_w, param_b, layout, cout_src, cout_off, cin_src; };
   std::vector<Src> srcs;
 };
@@ -485,7 +486,7 @@ static int build_packed_layout(Net& n) {
   const bool fused_norm = getenv("CSD_FUSED_NORM") != nullptr;
   auto add_conv = [&](const std::string& key, int c0, int c1, int cout, int taps,
                       std::vector<PackedConv::Src> srcs, bool stride1 = true, bool normed = false,
-                      bool resample = false) -> int {
+                      bool resample = false, bool upsample = false) -> int {
     PackedConv pc;
     int rc = proto_conv(&pc.proto, c0, c1, cout, taps);
     if (rc) return rc;
@@ -512,7 +513,8 @@ static int build_packed_layout(Net& n) {
       pc.ns = (n.cfg.precision == CSD_PREC_F16F8 && net_ns == 2 && !resample && conv16q_supported(one, 3)) ? 3 : net_ns;
       pc.q = true;
       pc.proto.KC = 16;
-      pc.w_off = take(conv16q_packed_bytes(one, pc.ns) / sizeof(float) + 1);
+      pc.up4 = upsample && srcs.size() == 1 && conv16q_up4_supported(one, pc.ns);
+      pc.w_off = take((pc.up4 ? conv16q_up4_packed_bytes(one, pc.ns) : conv16q_packed_bytes(one, pc.ns)) / sizeof(float) + 1);
     } else if (net_ns && stride1 && conv16_supported(pc.proto)) {
       pc.ns = net_ns;
       if ((rc = conv16_plan_tiles(&pc.proto, pc.ns))) return rc;
@@ -597,7 +599,8 @@ static int build_packed_layout(Net& n) {
     return add_conv(std::to_string(m.idx) + ".Conv_0", m.cin, 0, m.cin, 9,
                     {{n.P(mname(m.idx, "Conv_0.weight")), n.P(mname(m.idx, "Conv_0.bias")), 0, m.cin, 0}},
                     /*stride1=*/true,    // (the fp16 kernel also covers the stride-2 Downsample)
-                    /*quad-eligible=*/true, /*resample=*/true);   // plain fp16 split of the source tensor + quad schedule (x2 addressing / stride 2)
+                    /*quad-eligible=*/true, /*resample=*/true,    // plain fp16 split of the source tensor + quad schedule (x2 addressing / stride 2)
+                    /*upsample=*/m.kind == M_UP);
   };
   auto is_attn = [&](int res) {
     for (int i = 0; i < c.n_attn; ++i) if (c.attn_resolutions[i] == res) return true;
@@ -847,6 +850,10 @@ struct Builder {
     } else if (pc.q) {
       if (external_nchw || (!norm && o.cp.C1 != 0) || (stride == 2 && (norm || up))) { set_error("quad fp16 conv on an unsupported layer"); rc = CSD_ERR_INVALID; return NONE; }
       o.cp.C0 = o.cp.C0 + o.cp.C1; o.cp.C1 = 0;
+      if (pc.up4) {
+        if (!up || stride != 1) { set_error("phase-decomposed Upsample packed for a layer that is not one"); rc = CSD_ERR_INVALID; return NONE; }
+        o.cp.up = 2;
+      }
       if (conv16q_plan_tiles(&o.cp, pc.ns)) { rc = CSD_ERR_INVALID; return NONE; }
     } else if (pc.pw) {
       if (act != CSD_ACT_NONE || temb_col != NONE || external_nchw) { set_error("pointwise fp16 layer with act/temb/NCHW"); rc = CSD_ERR_INVALID; return NONE; }
@@ -888,10 +895,13 @@ struct Builder {
     o.out_external = external_nchw ? 1 : 0;
     const size_t out_elems = (size_t)B * o.cp.OH * o.cp.OW * o.cp.Cout;
     o.out = external_nchw ? NONE : alloc_(out_elems);
-    if (!pc.pw && !external_nchw && o.cp.taps == 9 && o.cp.OH % o.cp.TH == 0 && !getenv("CSD_NO_FUSED_STATS")) {
+    const int oh_tiled = o.cp.up == 2 ? o.cp.IH : o.cp.OH;         // (the phase form tiles the SOURCE image, four workgroups per tile)
+    if (!pc.pw && !external_nchw && o.cp.taps == 9 && oh_tiled % o.cp.TH == 0 && !getenv("CSD_NO_FUSED_STATS") &&
+        o.cp.up != 2) {     // (phase-decomposed Upsample: its fp64 epilogue statistics cost more than the streaming pass over the output,
+                            // and their tile grouping would make a sample's bits depend on the batch size it is run in)
       // every tile lies inside one sample: the epilogue also leaves (sum, sumsq) per (tile, cout) for the next
       // GroupNorm (the fp32 kernel: per (tile, wave, cout))
-      const int tpi = (o.cp.OH / o.cp.TH) * o.cp.tiles_x * (pc.q ? 2 : (pc.ns ? 1 : 4));
+      const int tpi = (oh_tiled / o.cp.TH) * o.cp.tiles_x * (pc.q ? 2 : (pc.ns ? 1 : 4)) * (o.cp.up == 2 ? 4 : 1);
       o.stats = alloc_((size_t)B * tpi * o.cp.Cout * 2 * 2);      // doubles; never released (small)
       tile_stats[o.out] = TileStats{o.stats, tpi};
     }
@@ -1477,6 +1487,7 @@ static int pack_all(Net& n, float* pk, hipStream_t s) {
       one.C0 = pc.proto.C0 + pc.proto.C1; one.C1 = 0;
       rc = pc.ff ? convff_pack_weight(pc.proto, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
                                       src.cout_off, pk + pc.w_off, s)
+         : pc.up4 ? conv16q_pack_weight_up4(one, pc.ns, n.params[src.param_w].ptr, pk + pc.w_off, s)
          : pc.q ? conv16q_pack_weight(one, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
                                       src.cout_off, pk + pc.w_off, s)
          : pc.pw ? pw16_pack_weight(pc.proto, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
