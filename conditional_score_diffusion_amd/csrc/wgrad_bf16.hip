@@ -37,7 +37,7 @@ __device__ __forceinline__ unsigned pack_hi(float lo_elem, float hi_elem) {   //
 }
 __device__ __forceinline__ float trunc_bf16(float v) { return __uint_as_float(__float_as_uint(v) & 0xffff0000u); }
 
-template <int KS, bool STAGED>
+template <int KS, bool STAGED, bool FULL>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float* x, const float* dy, float* partial, int B, int IH,
                                                                  int IW, int Cin, int OH, int OW, int Cout, int per_split, int n_ci,
                                                                  int n_co) {
@@ -114,27 +114,53 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float* x,
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
+  // (VALU instructions are matrix-pipe time on this chip - tools/mfma_valu_overlap.hip - so everything wave-uniform is kept on the
+  // scalar unit: row bases in SGPRs, 32-bit element offsets, one 64-bit add per DMA)
+  const unsigned coq = (unsigned)(tz * 32 + sq) < (unsigned)Cout ? (unsigned)(tz * 32 + sq) : 0u;
+  const unsigned ciq = (unsigned)(ty * 32 + sq) < (unsigned)Cin ? (unsigned)(ty * 32 + sq) : 0u;
   auto stage = [&](unsigned r, int ox0) {                    // (row r is wave-uniform here: no pair mode)
-    const unsigned rc = r < r_end ? r : r_begin;
+    const unsigned rs = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+    const int oxs = __builtin_amdgcn_readfirstlane(ox0);
+    const unsigned rc = rs < r_end ? rs : r_begin;
     const unsigned b = rc / (unsigned)OH, oy = rc - b * (unsigned)OH;
-    const unsigned coq = (unsigned)(tz * 32 + sq) < (unsigned)Cout ? (unsigned)(tz * 32 + sq) : 0u;
-    const unsigned ciq = (unsigned)(ty * 32 + sq) < (unsigned)Cin ? (unsigned)(ty * 32 + sq) : 0u;
+    const float* const dyrow = dy + (size_t)rc * (unsigned)OW * (unsigned)Cout;          // scalar
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int ox = ox0 + sp + 8 * i;
+      int ox = oxs + sp + 8 * i;
       ox = ox < OW ? ox : OW - 1;
-      glds16(dy + (size_t)((rc * (unsigned)OW + (unsigned)ox) * (unsigned)Cout + coq), patch + i * 256);
+      glds16(dyrow + ((unsigned)ox * (unsigned)Cout + coq), patch + i * 256);
     }
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky) {
       int iy = (int)oy + ky - PAD;
       iy = iy < 0 ? 0 : (iy >= IH ? IH - 1 : iy);
+      const float* const xrow = x + (size_t)((b * (unsigned)IH + (unsigned)iy) * (unsigned)IW) * (unsigned)Cin;   // scalar
 #pragma unroll
       for (int i = 0; i < BPIX / 8; ++i) {
-        int ix = ox0 - PAD + sp + 8 * i;
+        int ix = oxs - PAD + sp + 8 * i;
         ix = ix < 0 ? 0 : (ix >= IW ? IW - 1 : ix);
-        glds16(x + (size_t)(((b * (unsigned)IH + (unsigned)iy) * (unsigned)IW + (unsigned)ix) * (unsigned)Cin + ciq),
-               patch + (16 + ky * BPIX) * 32 + i * 256);
+        glds16(xrow + ((unsigned)ix * (unsigned)Cin + ciq), patch + (16 + ky * BPIX) * 32 + i * 256);
+      }
+    }
+  };
+  // full channel tiles: instead of masking every gathered value in registers, the few out-of-image pixels of a step are zeroed in
+  // the wave's patch (wave-uniform ranges: scalar branches, a handful of ds_writes on border steps only) and the gather is plain
+  constexpr bool full_ch = FULL;                             // (host: Cout % 32 == 0 && Cin % 32 == 0, staged)
+  auto zero_oob = [&](unsigned r, int ox0) {
+    const unsigned rs = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+    const int oxs = __builtin_amdgcn_readfirstlane(ox0);
+    const unsigned b = rs / (unsigned)OH, oy = rs - b * (unsigned)OH;
+    // dY pixels j >= OW - ox0
+    for (int j = OW - oxs + kg; j < 16; j += 2) patch[j * 32 + m] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+      const int iy = (int)oy + ky - PAD;
+      float* const row = patch + (16 + ky * BPIX) * 32 + m;
+      if (iy < 0 || iy >= IH) {
+        for (int pp = kg; pp < 16 + KS - 1; pp += 2) row[pp * 32] = 0.f;
+      } else {
+        if (oxs - PAD < 0 && kg == 0) row[0] = 0.f;                                  // ix = -1
+        for (int pp = IW - oxs + PAD + kg; pp < 16 + KS - 1; pp += 2) row[pp * 32] = 0.f;     // ix >= IW
       }
     }
   };
@@ -179,7 +205,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float* x,
     if (pair_rows || oxn >= OW) { oxn = 0; rn = r + r_step; }
     if (STAGED) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this step's patch has landed
-      gather(r, ox0, a_c, x_c, am_c, xm_c);
+      if (full_ch) {
+        zero_oob(r, ox0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a_c[j] = patch[(8 * kg + j) * 32 + m];
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) x_c[ky][q] = patch[(16 + ky * BPIX + 8 * kg + q) * 32 + m];
+        am_c = 0xffu;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) xm_c[ky] = (1u << NQ) - 1u;
+      } else {
+        gather(r, ox0, a_c, x_c, am_c, xm_c);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // ... and is in registers: the patch may be overwritten
       stage(rn, oxn);                                           // next step's 11 loads fly under the conversions + MFMAs
     } else {
@@ -194,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float* x,
       float v[8], lo[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        v[j] = ((am_c >> j) & 1u) ? a_c[j] : 0.f;
+        v[j] = (FULL || ((am_c >> j) & 1u)) ? a_c[j] : 0.f;
         lo[j] = v[j] - trunc_bf16(v[j]);
       }
 #pragma unroll
@@ -209,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float* x,
       float v[NQ], lo[NQ];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        v[q] = ((xm_c[ky] >> q) & 1u) ? x_c[ky][q] : 0.f;
+        v[q] = (FULL || ((xm_c[ky] >> q) & 1u)) ? x_c[ky][q] : 0.f;
         lo[q] = v[q] - trunc_bf16(v[q]);
       }
       // even-aligned pairs P_i = (q = 2i, 2i+1) serve kx = 0 (P0..P3) and kx = 2 (P1..P4); odd-aligned Q_i = (2i+1, 2i+2) serve kx = 1
@@ -289,11 +328,12 @@ int wgrad_bf16_launch(const float* xh, const float* dyh, float* partial, int B, 
   const int n_ci = cdiv(Cin, 32), n_co = cdiv(Cout, 32);
   const dim3 grid((unsigned)S * n_ci * n_co);
   const bool staged = W > 8 && Cin % 4 == 0 && Cout % 4 == 0 && !getenv("CSD_WGRAD_GATHER");
-#define WG_LAUNCH(KS_, ST_)                                                                                                        \
-  hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS_, ST_>), grid, dim3(256), 0, s, xh, dyh, partial, B, H, W, Cin, H, W, Cout, per_split, \
-                     n_ci, n_co)
-  if (ksize == 3) { if (staged) WG_LAUNCH(3, true); else WG_LAUNCH(3, false); }
-  else { if (staged) WG_LAUNCH(1, true); else WG_LAUNCH(1, false); }
+  const bool full = staged && Cin % 32 == 0 && Cout % 32 == 0 && !getenv("CSD_WGRAD_MASKED");
+#define WG_LAUNCH(KS_, ST_, FU_)                                                                                                   \
+  hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS_, ST_, FU_>), grid, dim3(256), 0, s, xh, dyh, partial, B, H, W, Cin, H, W, Cout,   \
+                     per_split, n_ci, n_co)
+  if (ksize == 3) { if (full) WG_LAUNCH(3, true, true); else if (staged) WG_LAUNCH(3, true, false); else WG_LAUNCH(3, false, false); }
+  else { if (full) WG_LAUNCH(1, true, true); else if (staged) WG_LAUNCH(1, true, false); else WG_LAUNCH(1, false, false); }
 #undef WG_LAUNCH
   CSD_LAUNCH_CHECK();
   return CSD_OK;
