@@ -479,6 +479,9 @@ static int build_packed_layout(Net& n) {
     n.copy_off[pname] = cpy.off;
   };
   const int net_ns = precision_ns(n.cfg.precision);
+  // the 6 -> nf stem: with the input padded to 16 channels (zeros) it runs on the fp16 matrix cores like every other 3x3 (one K step
+  // per tap) instead of the fp32 ones (36 MFMAs of 64 cycles per 32 pixels: 380 us per evaluation at 160^2, B = 64, MFMA-bound)
+  if (n.cfg.arch == 0 && net_ns && !getenv("CSD_STEM_F32")) n.in_cpad = 16;
   // quad schedule: measured faster than the loader/consumer one in the split (3-MFMA) mode only
   const bool use_q = net_ns == 2 && !getenv("CSD_NO_Q");
   int cur_res = n.cfg.image_size;    // resolution of the layer being laid out
