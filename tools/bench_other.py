@@ -1,27 +1,60 @@
-"""Side measurements for DESIGN.md (not the driver's bench): BASELINE configs[2] (CMDE inpainting 128x128, `ddpm_paired`,
+"""Side measurements for DESIGN.md (not the driver's bench; imports nothing from oracle/): BASELINE configs[2] (CMDE inpainting 128x128, `ddpm_paired`,
 two SDEs, fused PC loop) and the operator-granular NCSN++ executor (forward only).  One JSON line each."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import numpy as np, torch
-import cases, score_oracle as so
+import bench                                   # config / random-init helpers of the bench (nothing here touches oracle/)
 from conditional_score_diffusion_amd import sde_lib
+from conditional_score_diffusion_amd.config_dict import ConfigDict
 from conditional_score_diffusion_amd.models import utils as mutils
-from conditional_score_diffusion_amd.sampling import conditional, correctors, predictors
+import conditional_score_diffusion_amd.models.ddpm      # noqa: F401  (registers the model names)
+import conditional_score_diffusion_amd.models.ncsnpp    # noqa: F401
 
 dev = torch.device('cuda:0')
-prec = sys.argv[1] if len(sys.argv) > 1 else 'fp16f8'
+prec = sys.argv[1] if (len(sys.argv) > 1 and __name__ == '__main__') else 'fp16f8'
+
+
+def cmde128_config():
+    """BASELINE configs[2]: configs/ve/inverse_problems/inpainting/celebA_ours_DV_128-like values that the hot path reads"""
+    c = bench.sr3_160_config()
+    S = 128
+    c.data = ConfigDict(image_size=S, effective_image_size=S, centered=False, shape_x=[3, S, S], shape_y=[3, S, S], num_channels=6)
+    c.model.name = 'ddpm_paired'
+    c.model.attn_resolutions = (16, 8, 4)
+    c.model.sigma_max_x = float(np.sqrt(3 * S * S))
+    c.model.sigma_max = c.model.sigma_max_x
+    c.model.sigma_max_y = 1.0
+    c.model.output_channels = 6
+    c.sampling.snr = 0.15
+    return c
+
+
+def ncsnpp_config(name):
+    c = ConfigDict()
+    S = 160
+    c.training = ConfigDict(continuous=True, sde='vesde', likelihood_weighting=False, reduce_mean=False)
+    c.sampling = ConfigDict(method='pc', predictor='reverse_diffusion', corrector='langevin', n_steps_each=1, noise_removal=True,
+                            probability_flow=False, snr=0.075)
+    c.data = ConfigDict(image_size=S, effective_image_size=S, centered=False, num_channels=6, shape_x=[3, S, S], shape_y=[3, S, S])
+    c.model = ConfigDict(name=name, nf=96, ch_mult=(1, 1, 2, 2, 3, 3), num_res_blocks=2, attn_resolutions=(20, 10, 5), dropout=0.1,
+                         resamp_with_conv=True, conditional=True, nonlinearity='swish', num_scales=1000, sigma_min=0.01, sigma_max=50.,
+                         fir=True, fir_kernel=[1, 3, 3, 1], skip_rescale=True, resblock_type='biggan', progressive='output_skip',
+                         progressive_input='input_skip', progressive_combine='sum', attention_type='ddpm', init_scale=0.,
+                         embedding_type='positional', fourier_scale=16, conv_size=3, scale_by_sigma=True)
+    return c
+
+
+def build(cfg):
+    cfg.model.csd_precision = prec
+    model = mutils.create_model(cfg)
+    model.load_state_dict(bench.synth_weights({k: tuple(v.shape) for k, v in model.state_dict().items()}, 0))
+    return model.to(dev).eval()
 
 
 def cmde128(B=64, steps=20):
-    cfg = cases.make_config(name='ddpm_paired', nf=96, ch_mult=(1, 1, 2, 2, 3, 3), num_res_blocks=2, attn_resolutions=(16, 8, 4),
-                            image_size=128, x_ch=3, y_ch=3, sigma_min_x=5e-3, sigma_max_x=float(np.sqrt(3 * 128 * 128)),
-                            sigma_min_y=5e-3, sigma_max_y=1.0, snr=0.15)
-    cfg.model.csd_precision = prec
-    model = mutils.create_model(cfg)
-    model.load_state_dict(so.synth_params(so.ddpm_param_shapes(so.NetCfg.from_config(cfg)), 0))
-    model = model.to(dev).eval()
+    cfg = cmde128_config()
+    model = build(cfg)
     sde = {'x': sde_lib.cVESDE(cfg.model.sigma_min_x, cfg.model.sigma_max_x, 1000), 'y': sde_lib.VESDE(5e-3, 1.0, 1000)}
     rs = np.random.RandomState(1)
     y = rs.uniform(0, 1, size=(B, 3, 128, 128)).astype(np.float32)
@@ -40,13 +73,7 @@ def cmde128(B=64, steps=20):
 
 
 def ncsnpp(name='ncsnpp_paired', B=8, reps=3):
-    cfg = cases.make_ncsnpp_config(name=name, channels=6, nf=96, ch_mult=(1, 1, 2, 2, 3, 3), num_res_blocks=2,
-                                   attn_resolutions=(20, 10, 5), image_size=160, embedding_type='positional')
-    cfg.model.csd_precision = prec
-    model = mutils.create_model(cfg)
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    model.load_state_dict(cases.ncsnpp_params(shapes, 1))
-    model = model.to(dev).eval()
+    model = build(ncsnpp_config(name))
     x = torch.randn(B, 3, 160, 160, device=dev)
     y = torch.rand(B, 3, 160, 160, device=dev)
     lab = torch.full((B,), 500., device=dev)

@@ -1,17 +1,17 @@
 import os
 import sys
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'oracle'))
-import torch, cases
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tools'))
+import torch
+import bench, bench_other
 from conditional_score_diffusion_amd import _lib
 from conditional_score_diffusion_amd.models import utils as mutils
 dev = torch.device('cuda:0')
-cfg = cases.make_ncsnpp_config(name='ncsnpp_paired', channels=6, nf=96, ch_mult=(1, 1, 2, 2, 3, 3), num_res_blocks=2,
-                               attn_resolutions=(20, 10, 5), image_size=160, embedding_type='positional')
+cfg = bench_other.ncsnpp_config('ncsnpp_paired')
 cfg.model.csd_precision = sys.argv[1] if len(sys.argv) > 1 else 'fp16x3'
 model = mutils.create_model(cfg)
 shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-model.load_state_dict(cases.ncsnpp_params(shapes, 1)); model = model.to(dev).eval()
+model.load_state_dict(bench.synth_weights(shapes, 1)); model = model.to(dev).eval()
 B = 64
 x = torch.randn(B, 3, 160, 160, device=dev); y = torch.rand(B, 3, 160, 160, device=dev); lab = torch.full((B,), 500., device=dev)
 with torch.no_grad():

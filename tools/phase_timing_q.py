@@ -2,15 +2,14 @@
 [start, tables, first stage in LDS, end of MFMAs of each stage ..., end]."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
 import numpy as np, torch
-import bench, score_oracle as so
+import bench
 from conditional_score_diffusion_amd import _lib
 from conditional_score_diffusion_amd.models import utils as mutils
 dev = torch.device('cuda:0')
 cfg = bench.sr3_160_config(); cfg.model.csd_precision = sys.argv[1] if len(sys.argv) > 1 else 'fp16x3'
 B = 64
-m = mutils.create_model(cfg); m.load_state_dict(so.synth_params(so.ddpm_param_shapes(so.NetCfg.from_config(cfg)), 0)); m = m.to(dev).eval()
+m = mutils.create_model(cfg); m.load_state_dict(bench.synth_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, 0)); m = m.to(dev).eval()
 x = torch.randn(B, 3, 160, 160, device=dev) * 50; y = bench.synth_y(B).to(dev); lab = torch.full((B,), 500., device=dev)
 L = 12
 buf = torch.zeros(L * 4096 * 8, dtype=torch.int64, device=dev)

@@ -48,7 +48,7 @@ side = []
 for f in ('side_x3.txt', 'side_x1.txt'):
     side += [json.loads(l) for l in open(os.path.join(G, f)) if l.strip()]
 side.append({'workload': 'BASELINE configs[4] shape: NCSN++ 256x256 (nf=128, ch_mult (1,1,2,2,2,2,2), attention at 16, Fourier embedding, '
-                         '65.57 M parameters), planned executor, forward only; rel. error vs the CPU oracle 2.1e-6 (tools/cfg5_check.py)',
+                         '65.57 M parameters), planned executor, forward only; rel. error vs the CPU oracle 2.1e-6 (tests/test_gpu_fullsize.py::test_config5_ncsnpp_256_vs_oracle)',
              'precision': 'fp16x3', 'batch': 8, 'ms_per_forward': 22.29, 'images_per_sec_per_nfe': 358.9})
 side.append({'note': 'tools/bench_other.py on one MI355X (ncsnpp_paired = planned graph executor, ncsnpp_paired_ops = operator-granular '
                      'executor); shader clock during the 160x160 conv launches 1.86-2.08 GHz (clock64 / wall_clock64, '
