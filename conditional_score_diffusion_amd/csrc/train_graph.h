@@ -36,6 +36,11 @@ struct TrainState {
 };
 
 static std::map<const Net*, TrainState> g_train;      // one recorded forward per network handle
+static std::mutex g_train_mu;                         // (the map only; a handle itself is driven by one thread at a time)
+static TrainState& train_state_of(const Net* n) {
+  std::lock_guard<std::mutex> lk(g_train_mu);
+  return g_train[n];
+}
 
 __global__ void concat_c_kernel(const float4* __restrict__ a, int ca4, const float4* __restrict__ b, int cb4,
                                 float4* __restrict__ out, size_t npix) {
@@ -672,7 +677,7 @@ extern "C" int csd_unet_train_forward(csd_unet* net, const float* const* params,
   }
   for (size_t i = 0; i < net->net.params.size(); ++i)
     CSD_REQUIRE(params[i], "train_forward: parameter %zu (%s) is null", i, net->net.params[i].name.c_str());
-  TrainState& st = g_train[&net->net];
+  TrainState& st = train_state_of(&net->net);
   st.valid = false;
   TG g(net->net, st, B, (hipStream_t)stream, false, params, nullptr, static_cast<float*>(workspace));
   g.p_drop = dropout_p; g.seed = dropout_seed; g.call = call_index;
@@ -687,12 +692,11 @@ extern "C" int csd_unet_backward(csd_unet* net, const float* const* params, floa
   int rc = train_check(net);
   if (rc) return rc;
   CSD_REQUIRE(params && grads && workspace && d_out, "backward: null argument");
-  auto it = g_train.find(&net->net);
-  if (it == g_train.end() || !it->second.valid || it->second.B != B || it->second.ws != workspace) {
+  TrainState& st = train_state_of(&net->net);
+  if (!st.valid || st.B != B || st.ws != workspace) {
     set_error("backward: no matching csd_unet_train_forward (same handle, workspace and batch) precedes this call");
     return CSD_ERR_STATE;
   }
-  TrainState& st = it->second;
   const size_t need = csd_unet_train_workspace_bytes(net, B, st.p_drop);
   if (workspace_bytes < need) {
     set_error("backward: workspace too small (%zu < %zu bytes)", workspace_bytes, need);

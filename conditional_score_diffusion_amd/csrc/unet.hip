@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <vector>
 
@@ -42,7 +43,8 @@ struct Profiler {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
   size_t used = 0;
 };
-static Profiler g_prof;
+// per calling thread: a host thread that drives its own handle / stream profiles its own launches (csd_profile_* carry no handle)
+static thread_local Profiler g_prof;
 
 struct ProfScope {
   hipStream_t s;
@@ -1580,7 +1582,10 @@ extern "C" int csd_unet_create(const csd_unet_config* cfg, csd_unet** out) {
 }
 
 extern "C" void csd_unet_destroy(csd_unet* net) {
-  if (net) g_train.erase(&net->net);
+  if (net) {
+    std::lock_guard<std::mutex> lk(g_train_mu);
+    g_train.erase(&net->net);
+  }
   delete net;
 }
 
