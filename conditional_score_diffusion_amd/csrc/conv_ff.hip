@@ -519,13 +519,14 @@ long long* g_ff_dbg = nullptr;      // tuning aid: per-workgroup phase stamps (c
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-static inline int ff_nt(int cout) { return 3; }      // (NT = 4, the nf = 128 nets: needs a register diet first - 256 VGPRs + spills today)
+// cout tiles per workgroup: 3 (96 couts: the nf = 96 nets) or 2 (64 couts: the nf = 128 nets - four tiles need 256 VGPRs + spills)
+static inline int ff_nt(int cout) { return cout % 96 == 0 ? 3 : 2; }
 
 bool convff_supported(const ConvPlan& p, int ns) {
   if (getenv("CSD_NO_FF")) return false;
   const int kc = ns == 1 ? 32 : 16;
   return (ns >= 1 && ns <= 3) && p.taps == 9 && p.stride == 1 && p.up == 0 && p.pad == 1 && p.C0 > 0 && p.C0 % kc == 0 &&
-         p.C1 % kc == 0 && p.Cout % 96 == 0 && p.OH % FF_TILE == 0 && p.OW % FF_TILE == 0 &&
+         p.C1 % kc == 0 && (p.Cout % 96 == 0 || (p.Cout % 64 == 0 && !getenv("CSD_FF_NO_NT2"))) && p.OH % FF_TILE == 0 && p.OW % FF_TILE == 0 &&
          p.IH == p.OH && p.IW == p.OW;
 }
 
@@ -641,11 +642,15 @@ int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
   k.abl = getenv("CSD_FF_ABL") ? atoi(getenv("CSD_FF_ABL")) : 0;
   k.a.dbg = (k.abl & 128) ? g_ff_dbg : nullptr;
   const int nt = ff_nt(p.Cout);
-  (void)nt;
   // the persistent producer / consumer schedule (conv_ffp.hip) is an opt-in experiment: measured 9-15 % SLOWER than this one
   // (its consumer waves have nobody to cover their epilogue and fragment-read latency)
   static const bool persistent = getenv("CSD_FF_PERSISTENT") != nullptr;
   if (persistent) return convffp_launch(k, ns, s);
+  if (nt == 2) {
+    if (ns == 1) return launch_ff<1, 2, false>(k, s);
+    if (ns == 3) return launch_ff<2, 2, true>(k, s);
+    return launch_ff<2, 2, false>(k, s);
+  }
   if (ns == 1) return launch_ff<1, 3, false>(k, s);
   if (ns == 3) return launch_ff<2, 3, true>(k, s);
   return launch_ff<2, 3, false>(k, s);
