@@ -38,7 +38,8 @@ class PCParams(ctypes.Structure):
                 ('std_x', ctypes.POINTER(ctypes.c_float)), ('G', ctypes.POINTER(ctypes.c_float)),
                 ('std_y', ctypes.POINTER(ctypes.c_float)), ('snr', ctypes.c_float),
                 ('denoise', ctypes.c_int32), ('noise_tape', ctypes.c_void_p), ('seed', ctypes.c_uint64),
-                ('record', ctypes.c_void_p)]
+                ('record', ctypes.c_void_p), ('predictor', ctypes.c_int32), ('corrector', ctypes.c_int32),
+                ('pred_coef', ctypes.POINTER(ctypes.c_float)), ('corr_coef', ctypes.POINTER(ctypes.c_float))]
 
 
 def build(verbose=False):

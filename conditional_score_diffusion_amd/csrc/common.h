@@ -208,6 +208,8 @@ int langevin_update_launch(float* x, float* x_mean, const float* net, int64_t ne
 int norm_sums_launch(const double* partial, int nchunk, float std, int B, float* sums, hipStream_t s);
 int langevin_update_global_launch(float* x, float* x_mean, const float* net, int64_t net_stride, const float* z,
                                   const float* sums, int Bg, float std, float snr, int B, int64_t per, hipStream_t s);
+int affine_net_update_launch(float* x, float* x_mean, const float* net, int64_t net_stride, const float* z, float std, float p,
+                             float a, float c, int B, int64_t per, hipStream_t s);
 int reverse_diffusion_update_launch(float* x, float* x_mean, const float* net, int64_t net_stride,
                                     const float* z, float std, float G, int B, int64_t per, hipStream_t s);
 int randn_launch(float* out, int64_t n, uint64_t seed, uint64_t stream_id, hipStream_t s);

@@ -286,6 +286,29 @@ int reverse_diffusion_update_launch(float* x, float* x_mean, const float* net, i
   return CSD_OK;
 }
 
+// x_mean = p*x + (a/std)*net, x = x_mean + c*z on the network's (row-strided) output: the affine update rules inside the fused loop
+__global__ __launch_bounds__(256) void affine_net_update_kernel(float* __restrict__ x, float* __restrict__ x_mean,
+                                                                const float* __restrict__ net, int64_t net_stride,
+                                                                const float* __restrict__ z, float std, float p, float a, float c,
+                                                                int64_t per, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / (size_t)per;
+    const float score = net[b * net_stride + (i - b * per)] / std;
+    const float xm = p * x[i] + a * score;
+    x_mean[i] = xm;
+    x[i] = xm + c * z[i];
+  }
+}
+
+int affine_net_update_launch(float* x, float* x_mean, const float* net, int64_t net_stride, const float* z, float std, float p,
+                             float a, float c, int B, int64_t per, hipStream_t s) {
+  const size_t total = (size_t)B * per;
+  hipLaunchKernelGGL(affine_net_update_kernel, dim3(ew_grid(total)), dim3(256), 0, s, x, x_mean, net, net_stride, z, std, p, a, c,
+                     per, total);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
 int affine_noise_update_launch(float* x, float* x_mean, const float* score, const float* z, float p, float a, float c,
                                size_t total, hipStream_t s) {
   hipLaunchKernelGGL(affine_noise_update_kernel, dim3(ew_grid(total)), dim3(256), 0, s, x, x_mean, score, z, p, a, c,

@@ -1696,14 +1696,19 @@ struct PCCtx {
   int64_t per, net_stride;
   bool perturb_y;
   hipStream_t s;
-  int draws_per_step() const { return perturb_y ? 4 : 2; }
-  // draw k (0-based) of step i: from the tape (reference order) or Philox stream 1 + i*draws + k (stream 0 is the prior)
+  // a phase whose rule is 'none' (csd_pc_params.corrector / .predictor == 2) evaluates nothing and draws nothing
+  bool has_phase(int phase) const { return (phase == 0 ? p->corrector : p->predictor) != 2; }
+  int draws_per_phase() const { return perturb_y ? 2 : 1; }
+  int draws_per_step() const { return draws_per_phase() * ((has_phase(0) ? 1 : 0) + (has_phase(1) ? 1 : 0)); }
+  // draw k (0-based, in the order of the phases that exist) of step i: from the tape (reference order) or Philox stream
+  // 1 + i*draws + k (stream 0 is the prior)
   const float* noise(int i, int k, float* dst, size_t n) const {
     if (p->noise_tape) {
-      // tape layout per step: [zy_c] z_c [zy_p] z_p
-      size_t off = (size_t)i * (2 * nx + (perturb_y ? 2 * ny : 0));
-      const size_t sizes[4] = {perturb_y ? ny : nx, perturb_y ? nx : nx, ny, nx};
-      for (int j = 0; j < k; ++j) off += sizes[j];
+      // tape layout per step and existing phase: [zy] z
+      const size_t per_phase = nx + (perturb_y ? ny : 0);
+      size_t off = (size_t)i * per_phase * (draws_per_step() / draws_per_phase());
+      off += (size_t)(k / draws_per_phase()) * per_phase;
+      if (perturb_y && (k % 2) == 1) off += ny;
       return p->noise_tape + off;
     }
     if (randn_launch(dst, (int64_t)n, p->seed, (uint64_t)1 + (uint64_t)i * draws_per_step() + k, s)) return nullptr;
@@ -1717,7 +1722,12 @@ static int pc_setup(PCCtx* c, csd_unet* net, const void* packed, void* workspace
   int rc = check_forward_args(net, packed, workspace, workspace_bytes, B, &pl);
   if (rc) return rc;
   CSD_REQUIRE(p && x && scratch, "pc_sample: null argument");
-  CSD_REQUIRE(p->n_steps >= 1 && p->labels && p->std_x && p->G, "pc_sample: per-step scalar arrays missing");
+  CSD_REQUIRE(p->n_steps >= 1 && p->labels && p->std_x, "pc_sample: per-step scalar arrays missing");
+  CSD_REQUIRE(p->predictor >= 0 && p->predictor <= 2 && p->corrector >= 0 && p->corrector <= 2, "pc_sample: bad predictor / corrector id");
+  CSD_REQUIRE(p->predictor != 0 || p->G, "pc_sample: the reverse-diffusion predictor needs G");
+  CSD_REQUIRE(p->predictor != 1 || p->pred_coef, "pc_sample: predictor table missing");
+  CSD_REQUIRE(p->corrector != 1 || p->corr_coef, "pc_sample: corrector table missing");
+  CSD_REQUIRE(p->predictor != 2 || p->corrector != 2, "pc_sample: predictor and corrector are both 'none'");
   const csd_unet_config& cf = net->net.cfg;
   CSD_REQUIRE((cf.y_channels == 0) == (y == nullptr), "pc_sample: y must be given iff y_channels > 0");
   CSD_REQUIRE(!(p->std_y && cf.y_channels == 0), "pc_sample: std_y given for an unconditional network");
@@ -1751,10 +1761,15 @@ static int pc_setup(PCCtx* c, csd_unet* net, const void* packed, void* workspace
 static int pc_phase(const PCCtx& c, int i, int phase, int part, float* sums_out, const float* sums_in, int Bg) {
   int rc;
   const csd_pc_params* p = c.p;
-  const int k0 = phase * (c.perturb_y ? 2 : 1);
+  if (!c.has_phase(phase)) {                       // 'none': x stays, x_mean = x (sampling/predictors.py:182-200, correctors.py:145-163)
+    if ((part & 2) && phase == 1 && i == p->n_steps - 1 && p->denoise)
+      CSD_CHECK_HIP(hipMemcpyAsync(c.x_mean, c.x, c.nx * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+    return CSD_OK;
+  }
+  const int k0 = (phase == 1 && c.has_phase(0) ? 1 : 0) * c.draws_per_phase();
   const float* zp = c.p->noise_tape ? c.noise(i, k0 + (c.perturb_y ? 1 : 0), nullptr, c.nx) : c.z;
   if (part & 1) {
-    if (phase == 0) {
+    if (phase == 0 || !c.has_phase(0)) {             // (once per step: by the first phase that evaluates the network)
       hipLaunchKernelGGL(fill_labels_kernel, dim3(cdiv(c.B, 256)), dim3(256), 0, c.s, c.labels, p->labels[i], c.B);
       CSD_LAUNCH_CHECK();
     }
@@ -1764,7 +1779,7 @@ static int pc_phase(const PCCtx& c, int i, int phase, int part, float* sums_out,
     if (rc) return rc;
     zp = c.noise(i, k0 + (c.perturb_y ? 1 : 0), c.z, c.nx);
     if (!zp) return CSD_ERR_HIP;
-    if (phase == 0) {
+    if (phase == 0 && p->corrector == 0) {
       ProfScope prof(CSD_PROF_SAMPLER, 0, 2.0 * c.nx * 4, c.s);
       if ((rc = sumsq_rows_launch(c.net_out, c.net_stride, zp, c.partial, c.B, c.per, c.nchunk, c.s))) return rc;
       if (sums_out && (rc = norm_sums_launch(c.partial, c.nchunk, p->std_x[i], c.B, sums_out, c.s))) return rc;
@@ -1772,7 +1787,11 @@ static int pc_phase(const PCCtx& c, int i, int phase, int part, float* sums_out,
   }
   if (part & 2) {
     ProfScope prof(CSD_PROF_SAMPLER, 0, 6.0 * c.nx * 4, c.s);
-    if (phase == 0) {
+    const int rule = phase == 0 ? p->corrector : p->predictor;
+    if (rule == 1) {                               // affine table: x_mean = p x + a score, x = x_mean + b z
+      const float* co = (phase == 0 ? p->corr_coef : p->pred_coef) + (size_t)i * 3;
+      rc = affine_net_update_launch(c.x, c.x_mean, c.net_out, c.net_stride, zp, p->std_x[i], co[0], co[1], co[2], c.B, c.per, c.s);
+    } else if (phase == 0) {
       rc = sums_in ? langevin_update_global_launch(c.x, c.x_mean, c.net_out, c.net_stride, zp, sums_in, Bg, p->std_x[i], p->snr,
                                                    c.B, c.per, c.s)
                    : langevin_update_launch(c.x, c.x_mean, c.net_out, c.net_stride, zp, c.partial, c.nchunk, p->std_x[i],

@@ -126,7 +126,8 @@ def get_pc_conditional_sampler(sde, shape, predictor, corrector, snr, p_steps, c
     def pc_conditional_sampler(model, y, show_evolution=False, noise_tape=None, seed=None, global_norm=None):
         if fused.fusable(model, sde, predictor, corrector, c_steps, probability_flow, continuous):
             x, rec, _ = fused.run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=noise_tape,
-                                  seed=seed, record=show_evolution, global_norm=global_norm)
+                                  seed=seed, record=show_evolution, global_norm=global_norm, predictor=predictor, corrector=corrector,
+                                  probability_flow=probability_flow)
             if show_evolution:
                 return x, {'evolution': {'x': rec.cpu(), 'y': None}}
             return x, {}

@@ -14,18 +14,80 @@ from .. import _lib, ops, sde_lib
 from .._lib import check, current_stream, lib, ptr
 
 
-def fusable(model, sde, predictor, corrector, c_steps, probability_flow, continuous, use_path=False):
-    """True when (model, sde, predictor, corrector) is the pair the fused loop implements."""
-    from ..models.ddpm import HipUNet
+def _rule_ids(predictor, corrector):
+    """(predictor id, corrector id) of csd_pc_params, or None for classes the device loop does not implement.
+    0 = the reverse-diffusion / Langevin pair, 1 = an affine rule with a per-step coefficient table, 2 = none."""
     from . import correctors as C, predictors as P
+    if predictor in (P.ReverseDiffusionPredictor, P.conditionalReverseDiffusionPredictor):
+        pid = 0
+    elif predictor in (P.EulerMaruyamaPredictor, P.conditionalEulerMaruyamaPredictor, P.AncestralSamplingPredictor,
+                       P.conditionalAncestralSamplingPredictor):
+        pid = 1
+    elif predictor in (P.NonePredictor, P.conditionalNonePredictor):
+        pid = 2
+    else:
+        return None
+    if corrector in (C.LangevinCorrector, C.conditionalLangevinCorrector):
+        cid = 0
+    elif corrector in (C.AnnealedLangevinDynamics, C.conditionalAnnealedLangevinDynamics):
+        cid = 1
+    elif corrector in (C.NoneCorrector, C.conditionalNoneCorrector):
+        cid = 2
+    else:
+        return None
+    return pid, cid
+
+
+def fusable(model, sde, predictor, corrector, c_steps, probability_flow, continuous, use_path=False):
+    """True when (model, sde, predictor, corrector) runs on the fused device loop: a VE SDE with any registered predictor
+    (reverse diffusion, Euler-Maruyama, ancestral sampling, none) and corrector (Langevin, annealed Langevin dynamics, none)."""
+    from ..models.ddpm import HipUNet
+    from . import predictors as P
     c_sde = sde['x'] if isinstance(sde, dict) else sde
     ok_sde = isinstance(c_sde, (sde_lib.VESDE, sde_lib.cVESDE))
     if isinstance(sde, dict):
         ok_sde = ok_sde and isinstance(sde.get('y'), sde_lib.VESDE) and len(sde) == 2
-    ok_pc = predictor in (P.ReverseDiffusionPredictor, P.conditionalReverseDiffusionPredictor) and \
-        corrector in (C.LangevinCorrector, C.conditionalLangevinCorrector)
-    return (isinstance(model, HipUNet) and ok_sde and ok_pc and c_steps == 1 and not probability_flow
-            and continuous and not use_path)
+    ids = _rule_ids(predictor, corrector)
+    if ids is None or ids == (2, 2):
+        return False
+    # the probability-flow drift exists for Euler-Maruyama only (the reverse-diffusion step kernel and ancestral sampling refuse it)
+    ok_pf = (not probability_flow) or predictor in (P.EulerMaruyamaPredictor, P.conditionalEulerMaruyamaPredictor)
+    return (isinstance(model, HipUNet) and ok_sde and c_steps == 1 and ok_pf and continuous and not use_path)
+
+
+def rule_tables(c_sde, ts, predictor, corrector, snr, probability_flow):
+    """Per-step (p, a, b) tables of the affine rules, evaluated exactly like the per-step classes evaluate their scalars
+    (sampling/predictors.py: _euler_maruyama, _ancestral; sampling/correctors.py: _ald): fp32 SDE quantities, python-float
+    arithmetic, one rounding to fp32 at the library boundary."""
+    from . import predictors as P
+    pid, cid = _rule_ids(predictor, corrector)
+    n = ts.numel()
+    pred = corr = None
+    if pid == 1:
+        pred = torch.empty(n, 3, dtype=torch.float32)
+        for i in range(n):
+            t1 = ts[i:i + 1].to(torch.float32)
+            if predictor in (P.EulerMaruyamaPredictor, P.conditionalEulerMaruyamaPredictor):
+                drift, diffusion = c_sde.sde(torch.ones(1, 1, 1, 1), t1)
+                phi, g = float(drift.flatten()[0]), float(diffusion.flatten()[0])
+                dt = -1.0 / c_sde.N
+                kappa = 0.5 if probability_flow else 1.0
+                co = (1.0 + phi * dt, -kappa * g * g * dt, 0.0 if probability_flow else g * (-dt) ** 0.5)
+            else:
+                k = int((t1 * (c_sde.N - 1) / c_sde.T).long()[0])
+                sig = c_sde.discrete_sigmas.to(torch.float32)
+                s2 = float(sig[k]) ** 2
+                a2 = float(sig[k - 1]) ** 2 if k > 0 else 0.0
+                co = (1.0, s2 - a2, (a2 * (s2 - a2) / s2) ** 0.5)
+            pred[i] = torch.tensor(co, dtype=torch.float64).to(torch.float32)
+    if cid == 1:
+        corr = torch.empty(n, 3, dtype=torch.float32)
+        for i in range(n):
+            t1 = ts[i:i + 1].to(torch.float32)
+            std = float(c_sde.marginal_prob(torch.zeros(1, 1, 1, 1), t1)[1].flatten()[0])
+            step = (snr * std) ** 2 * 2 * 1.0          # alpha = 1 for the VE SDEs
+            corr[i] = torch.tensor((1.0, step, (2 * step) ** 0.5), dtype=torch.float64).to(torch.float32)
+    return pid, cid, pred, corr
 
 
 def step_scalars(sde, p_steps, eps, unconditional_label=None):
@@ -54,8 +116,10 @@ def fresh_seed():
 
 
 def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=None, record=False,
-        unconditional_label=None, global_norm=None):
+        unconditional_label=None, global_norm=None, predictor=None, corrector=None, probability_flow=False):
     """Run the fused loop; returns (samples, record_or_None, timesteps).  ``seed=None``: a fresh key per call (fresh_seed).
+
+    ``predictor`` / ``corrector``: the registered classes (default: the reverse-diffusion / Langevin pair); see ``fusable``.
 
     ``global_norm``: None = the Langevin step size uses the batch means of THIS call's batch (the reference run on this batch;
     one library call enqueues the whole loop).  Otherwise ``(reduce_fn, global_batch)``: the batch is one shard of a larger one
@@ -71,6 +135,14 @@ def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=
         raise RuntimeError('the fused PC sampler runs on the MI355X only (model is on %s)' % dev)
     B = shape[0]
     ts, labels, std_x, G, std_y = step_scalars(sde, p_steps, eps, unconditional_label)
+    pid = cid = 0
+    pred_tab = corr_tab = None
+    if predictor is not None or corrector is not None:
+        from . import correctors as C_, predictors as P_
+        predictor = predictor or P_.ReverseDiffusionPredictor
+        corrector = corrector or C_.LangevinCorrector
+        pid, cid, pred_tab, corr_tab = rule_tables(c_sde, ts, predictor, corrector, float(snr), probability_flow)
+    n_phases = (pid != 2) + (cid != 2)
     # prior: N(0, sigma_max^2) (+ data mean) - drawn on the host like the reference (sde_lib.py:397-403)
     if noise_tape is not None:
         tape = [t.float() for t in noise_tape]
@@ -79,7 +151,7 @@ def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=
             x = x + c_sde.diffused_mean.unsqueeze(0)
         x = x.to(dev).contiguous()
         flat = torch.cat([t.reshape(-1) for t in tape[1:]]).to(dev).contiguous() if len(tape) > 1 else None
-        expected = 2 * p_steps * (2 if std_y is not None else 1)
+        expected = n_phases * p_steps * (2 if std_y is not None else 1)
         if len(tape) - 1 != expected:
             raise RuntimeError('noise tape holds %d draws after the prior, the loop needs %d' % (len(tape) - 1, expected))
     else:
@@ -102,6 +174,11 @@ def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=
     p.noise_tape = flat.data_ptr() if flat is not None else None
     p.seed = int(seed)
     p.record = rec.data_ptr() if rec is not None else None
+    p.predictor, p.corrector = pid, cid
+    p.pred_coef = _fp(pred_tab) if pred_tab is not None else None
+    p.corr_coef = _fp(corr_tab) if corr_tab is not None else None
+    if global_norm is not None and cid != 0:
+        global_norm = None                      # only the Langevin corrector couples the samples of a batch
     yy = y.contiguous() if y is not None else None
     if global_norm is None:
         check(lib().csd_pc_sample(model._h, ptr(model._packed), ptr(ws), ws.numel(), ptr(scratch), scratch.numel(),
@@ -117,5 +194,5 @@ def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=
             reduce_fn(sums)
             check(lib().csd_pc_step_end(*args, i, ptr(sums), int(global_batch), current_stream(dev)), 'pc_step_end')
     # keep the host arrays alive until the enqueue returned (they are read at enqueue time only)
-    del labels, std_x, G, std_y
+    del labels, std_x, G, std_y, pred_tab, corr_tab
     return x, rec, ts

@@ -158,7 +158,8 @@ def get_pc_sampler(sde, shape, predictor, corrector, snr, p_steps, c_steps, prob
         if fused.fusable(model, sde, predictor, corrector, c_steps, probability_flow, continuous):
             label = 'fourier' if getattr(model, 'embedding_type', 'positional') == 'fourier' else 'sigma'
             x, rec, ts = fused.run(model, sde, shape, None, p_steps, snr, eps, denoise, noise_tape=noise_tape,
-                                   seed=seed, record=show_evolution, unconditional_label=label, global_norm=global_norm)
+                                   seed=seed, record=show_evolution, unconditional_label=label, global_norm=global_norm,
+                                   predictor=predictor, corrector=corrector, probability_flow=probability_flow)
             info = {'times': ts, 'steps': steps}
             if show_evolution:
                 info['evolution'] = rec.cpu()

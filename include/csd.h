@@ -159,6 +159,13 @@ typedef struct csd_pc_params {
   const float* noise_tape;      /* draws in reference order, or NULL         */
   uint64_t seed;                /* Philox key when noise_tape == NULL                        */
   float* record;                /* optional [n_steps, B, C, S, S]: x after every step, or NULL*/
+  /* the other registered update rules on the same device loop (zero-initialised = the pair above).  They are all affine in
+   * (x, score, z) with per-step host scalars: x_mean = p*x + a*score, x = x_mean + b*z  (sampling/predictors.py:52-76 Euler-
+   * Maruyama, :105-135 ancestral sampling; sampling/correctors.py:111-142 annealed Langevin dynamics). */
+  int32_t predictor;            /* 0 reverse diffusion (G); 1 affine table pred_coef; 2 none (no evaluation, no draw) */
+  int32_t corrector;            /* 0 Langevin (snr, batch-mean norms); 1 affine table corr_coef; 2 none               */
+  const float* pred_coef;       /* [n_steps][3] = (p, a, b) when predictor == 1                                      */
+  const float* corr_coef;       /* [n_steps][3] when corrector == 1                                                  */
 } csd_pc_params;
 
 /* x: [B, x_channels, S, S] in: prior sample (already scaled by sigma_max); out: result.

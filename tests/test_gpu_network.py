@@ -211,6 +211,49 @@ def test_generic_per_step_path_matches_fused():
     assert rel(xm.cpu().numpy(), x_f.cpu().numpy(), floor=sde.sigma_max) < 1e-5
 
 
+@pytest.mark.parametrize('pred_name,corr_name,pf', [
+    ('conditional_euler_maruyama', 'conditional_langevin', False), ('conditional_ancestral_sampling', 'conditional_ald', False),
+    ('conditional_none', 'conditional_ald', False), ('conditional_euler_maruyama', 'conditional_none', True),
+    ('conditional_reverse_diffusion', 'conditional_none', False), ('conditional_ancestral_sampling', 'conditional_langevin', False)])
+def test_other_predictors_and_correctors_on_the_fused_loop(pred_name, corr_name, pf):
+    """Euler-Maruyama / ancestral sampling / annealed Langevin dynamics / none on the device-resident loop
+    (csd_pc_params.predictor / .corrector + coefficient tables) == the same classes driven step by step (reference protocol,
+    sampling/predictors.py:52-76,105-200, correctors.py:111-163), same noise"""
+    from conditional_score_diffusion_amd.models import utils as mutils
+    from conditional_score_diffusion_amd.sampling import fused
+    from conditional_score_diffusion_amd.sampling.correctors import get_corrector
+    from conditional_score_diffusion_amd.sampling.predictors import get_predictor
+    case, n = 'sr3_tiny', 4
+    cfg, nc, p, model = build(case)
+    sde = sdes_for(cfg)
+    B = cases.CASES[case][1]
+    y = cases.case_y(case).to(dev())
+    xs = (B,) + tuple(cfg.data.shape_x)
+    P, C = get_predictor(pred_name), get_corrector(corr_name)
+    assert fused.fusable(model, sde, P, C, 1, pf, True)
+    phases = (pred_name != 'conditional_none') + (corr_name != 'conditional_none')
+    tape = cases.tape([xs] * (1 + phases * n), 17)
+    x_f, _, _ = fused.run(model, sde, xs, y, n, cfg.sampling.snr, 1e-5, True, noise_tape=tape, predictor=P, corrector=C,
+                          probability_flow=pf)
+    it = iter(tape[1:])
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **k: next(it).to(t.device)
+    try:
+        sfn = mutils.get_conditional_score_fn(mutils.get_score_fn(sde, model, conditional=True, continuous=True), 'x')
+        pred, corr = P(sde, sfn, pf), C(sde, sfn, cfg.sampling.snr, 1)
+        x = (tape[0] * sde.sigma_max).to(dev())
+        ts = torch.linspace(sde.T, 1e-5, n)
+        for i in range(n):
+            vt = torch.ones(B, device=dev()) * ts[i]
+            x, xm = corr.update_fn(x, y, vt)
+            x, xm = pred.update_fn(x, y, vt)
+    finally:
+        torch.randn_like = orig
+    assert next(it, None) is None                          # both paths consumed the same number of draws
+    assert torch.isfinite(x_f).all()
+    assert rel(xm.cpu().numpy(), x_f.cpu().numpy(), floor=sde.sigma_max) < 1e-5
+
+
 @pytest.mark.parametrize('precision,tol', [('fp32', 2e-5), ('fp16x3', 2e-5), ('fp16f8', 2e-4), ('fp16', 3e-3)])
 def test_full_size_sr3_160_forward_vs_oracle(precision, tol):
     """cfg1/cfg2 network (nf=96, ch_mult (1,1,2,2,3,3), attention at 20/10/5) at 160x160, B=2, every precision mode
