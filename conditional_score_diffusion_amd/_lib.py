@@ -129,6 +129,7 @@ SIGNATURES = {
     'csd_zero_insert_odd_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'csd_sumpool2_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'csd_attention_nhwc': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'csd_attention_nhwc_prec': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'csd_attention_backward_nhwc': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'csd_adam_step': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _f, _vp]),
     'csd_global_norm_scratch_bytes': (_sz, []),

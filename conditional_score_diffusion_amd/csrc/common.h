@@ -132,6 +132,12 @@ size_t pw16_packed_bytes(const ConvPlan& p, int ns);
 int pw16_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int cin_src, int cout_src, int cout_off,
                      void* wpack, hipStream_t s);
 int pw16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s);
+// tap-partial form of a 3x3 convolution with <= 3 output channels: one pointwise contraction to 9*cout partial channels + a 9-tap gather
+bool pw16_taps_supported(int cin, int cout, int ns);
+int pw16_taps_cout(int cout);
+int pw16_pack_weight_taps(const ConvPlan& p, int ns, const float* w, int cout, void* wpack, hipStream_t s);
+int tapsum_launch(const float* part, const float* bias, float* out, int B, int H, int W, int cout, int nchw, float out_scale,
+                  hipStream_t s);
 // y16 = fp16 split of act(x*scale + shift): hi plane (and lo plane when ns == 2), NHWC halves [B*HW][C0+C1]
 int gn_apply16_launch(const float* src0, const float* src1, int C0, int C1, const float* nscale, const float* nshift,
                       void* hi, void* lo, int B, int HW, int act, hipStream_t s, int f8 = 0);
@@ -164,6 +170,8 @@ int gn_apply_launch(const float* x, const float* nscale, const float* nshift, fl
 // attention core on NHWC qkv (attention.hip): qkv [B, L, ld] with q at +0, k at +C, v at +2C
 // ---------------------------------------------------------------------------------------
 int attention_launch(const float* qkv, int ld, float* out, int B, int L, int C, hipStream_t s);
+// the same core on the fp16 matrix cores: ns = 2 split operands (3 MFMAs per product, fp32-class), ns = 1 plain fp16
+int attention16_launch(const float* qkv, int ld, float* out, int B, int L, int C, int ns, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // small kernels (elementwise.hip)

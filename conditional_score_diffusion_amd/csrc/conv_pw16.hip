@@ -18,6 +18,7 @@
 // the raw fp32 rows of the next TWO K steps always in flight (register ring of 2, re-issued right after the
 // fp32 -> fp16 conversion), across tile boundaries.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -81,6 +82,8 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
   const int total = nt_mine * k.ks;
   const bool has_norm = k.a.nscale != nullptr;
   const bool has_res = k.a.res != nullptr;
+  const bool has_act = k.a.act == CSD_ACT_SWISH;          // (only next to a GroupNorm: the tap-partial form of a tiny-Cout 3x3, below)
+  const int ntl = min(PW_NTL, (k.Cout - (int)blockIdx.y * (PW_NTL * 16) + 15) / 16);     // 16-cout tiles of this group that exist
 
   float4 raw[2][MTP][2];
   floatx4 acc[MTP][PW_NTL];
@@ -136,6 +139,10 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
             const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = fmaf(v[q], sc[q], sh[q]);     // same fma as the fp32 staging
+            if (has_act) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] = v[q] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[q]));     // SiLU as conv_ff / gn_apply16
+            }
           }
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
@@ -149,6 +156,7 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
         const char* wk = smem + (size_t)c_kk * PW_NTL * NS * 1024 + lane * 16;
 #pragma unroll
         for (int nt = 0; nt < PW_NTL; ++nt) {
+          if (nt >= ntl) continue;             // (uniform: a 28-cout layer runs 2 of the 6 tiles)
           const half8_t wh = *reinterpret_cast<const half8_t*>(wk + (nt * NS) * 1024);
           half8_t wl;
           if (NS == 2) wl = *reinterpret_cast<const half8_t*>(wk + (nt * NS + 1) * 1024);
@@ -265,6 +273,118 @@ int pw16_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int 
   return CSD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// tap-partial form of a 3x3 convolution with a handful of output channels (the networks' last layer: nf -> 3 channels,
+// reference models/ddpm.py:146, models/ncsnpp.py:234).  On the 3x3 kernels its 3 couts occupy one
+// 32-cout MFMA tile (90 % zeros) behind a gn_apply16 pass: 0.97 ms per evaluation at 160^2, B = 64, for 8.5 GFLOP.  Here
+//     P[b][y][x][tap*Co + co] = sum_ci act(GN(x))[b][y][x][ci] * W[co][ci][tap]       one POINTWISE contraction, nf -> 9*Co (27) couts,
+//                                                                                      GroupNorm + SiLU applied in its loader
+//     out[b][co][y][x] = bias[co] + sum_tap P[b][y+dy][x+dx][tap*Co + co]               9 shifted reads per output (zero padding =
+//                                                                                      skipped taps: the padding is of the ACTIVATED tensor)
+// so the activations are read once, as a stream.
+// ---------------------------------------------------------------------------------------------
+int pw16_taps_cout(int cout) { return (9 * cout + 3) / 4 * 4; }
+
+__global__ void pw16_pack_taps_kernel(const float* __restrict__ w, _Float16* __restrict__ wpack, int cin, int cout, int ks, int ns) {
+  // w: [cout][cin][3][3]; one thread per (virtual cout = tap * cout + co, cin)
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)9 * cout * cin) return;
+  const int cp = (int)(idx / cin), ci = (int)(idx % cin);
+  const int tap = cp / cout, co = cp % cout;
+  const float v = w[((size_t)co * cin + ci) * 9 + tap] * PW_WSCALE;
+  const int ng = cp / (PW_NTL * 16), nt = (cp % (PW_NTL * 16)) / 16, r = cp % 16;
+  const int kk = ci / 32, kq = (ci % 32) / 8, q = ci % 8;
+  _Float16* dst = wpack + ((((size_t)ng * ks + kk) * PW_NTL + nt) * ns) * 512 + (kq * 16 + r) * 8 + q;
+  const _Float16 hi = (_Float16)v;
+  dst[0] = hi;
+  if (ns == 2) dst[512] = (_Float16)(v - (float)hi);
+}
+
+int pw16_pack_weight_taps(const ConvPlan& p, int ns, const float* w, int cout, void* wpack, hipStream_t s) {
+  CSD_REQUIRE(p.C1 == 0 && p.Cout == pw16_taps_cout(cout) && p.Cout <= PW_NTL * 16, "pw16 tap pack: Cout %d for %d real couts", p.Cout, cout);
+  const int ks = p.C0 / 32;
+  const size_t n32 = pw16_packed_bytes(p, ns) / 4;
+  hipLaunchKernelGGL(pw16_zero_kernel, dim3((unsigned)cdiv64(n32, 256)), dim3(256), 0, s, (uint32_t*)wpack, n32);
+  CSD_LAUNCH_CHECK();
+  const size_t total = (size_t)9 * cout * p.C0;
+  hipLaunchKernelGGL(pw16_pack_taps_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w, (_Float16*)wpack, p.C0, cout, ks, ns);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+// out = (bias + sum over the 9 taps, in tap order) * out_scale.  A workgroup = one 16 x 16 output tile: the 18 x 18 partial records
+// (cp floats each, contiguous runs of 18 records per image row) go through LDS once - 9 float4 per thread, all in flight - and each
+// thread adds its pixel's 9 x CO values from there (zero records outside the image = the zero padding of the activated tensor).
+// (One thread per pixel gathering straight from global memory: 27 dword loads with a 112-byte lane stride, 183 us at 160^2, B = 64.)
+template <int CO>
+__global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                     float* __restrict__ out, int H, int W, int cp, int nchw, float out_scale) {
+  extern __shared__ __attribute__((aligned(16))) float ts_tile[];      // [18 * 18][cp]
+  const int tid = threadIdx.x;
+  const int tx0 = blockIdx.x * 16, ty0 = blockIdx.y * 16;
+  const size_t b = blockIdx.z;
+  const int cp4 = cp >> 2, total = 324 * cp4;
+  float4 v[9];
+#pragma unroll
+  for (int u = 0; u < 9; ++u) {
+    const int i = min(tid + u * 256, total - 1);
+    const int rec = i / cp4, q = i - rec * cp4;
+    const int pr = rec / 18, pc = rec - pr * 18;
+    const int y = ty0 - 1 + pr, x = tx0 - 1 + pc;
+    v[u] = (y >= 0 && y < H && x >= 0 && x < W) ? *reinterpret_cast<const float4*>(part + ((b * H + y) * W + x) * cp + q * 4)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int u = 0; u < 9; ++u) {
+    const int i = tid + u * 256;
+    if (i < total) *reinterpret_cast<float4*>(ts_tile + (size_t)i * 4) = v[u];      // (record-major, cp4 float4 per record: linear)
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  const int y = ty0 + ty, x = tx0 + tx;
+  if (y >= H || x >= W) return;
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const float* q = ts_tile + ((ty + tap / 3) * 18 + tx + tap % 3) * cp + tap * CO;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] += q[c];
+  }
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    const float r = (acc[c] + bias[c]) * out_scale;
+    if (nchw) out[((b * CO + c) * H + y) * W + x] = r;
+    else out[((b * H + y) * W + x) * CO + c] = r;
+  }
+}
+
+int tapsum_launch(const float* part, const float* bias, float* out, int B, int H, int W, int cout, int nchw, float out_scale,
+                  hipStream_t s) {
+  const int cp = pw16_taps_cout(cout);
+  CSD_REQUIRE(324 * (cp / 4) <= 9 * 256, "tapsum: %d partial channels exceed the staging slots", cp);
+  const dim3 grid(cdiv(W, 16), cdiv(H, 16), B), block(256);
+  const size_t lds = (size_t)324 * cp * sizeof(float);
+  switch (cout) {
+#define CSD_TS_CASE(CO) case CO: hipLaunchKernelGGL(tapsum_kernel<CO>, grid, block, lds, s, part, bias, out, H, W, cp, nchw, out_scale); break;
+    CSD_TS_CASE(1) CSD_TS_CASE(2) CSD_TS_CASE(3)
+#undef CSD_TS_CASE
+    default:
+      set_error("tapsum: %d output channels not instantiated", cout);
+      return CSD_ERR_INVALID;
+  }
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+bool pw16_taps_supported(int cin, int cout, int ns) {
+  ConvPlan p;
+  memset(&p, 0, sizeof(p));
+  p.taps = 1; p.stride = 1; p.C0 = cin; p.Cout = pw16_taps_cout(cout);
+  return cout >= 1 && cout <= 3 && pw16_supported(p, ns) && !getenv("CSD_NO_TAPSUM");
+}
+
 template <int NS, int MTP, int OCC>
 static int pw16_launch_t(const PwKArgs& k, const ConvPlan& p, hipStream_t s) {
   auto kern = pw16_kernel<NS, MTP, OCC>;
@@ -291,7 +411,8 @@ static int pw16_launch_t(const PwKArgs& k, const ConvPlan& p, hipStream_t s) {
 
 int pw16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
   CSD_REQUIRE(pw16_supported(p, ns), "pw16: unsupported layer (taps %d C0 %d C1 %d Cout %d)", p.taps, p.C0, p.C1, p.Cout);
-  CSD_REQUIRE(!a.temb && !a.out_nchw && a.act == CSD_ACT_NONE, "pw16: temb / NCHW output / activation are not supported");
+  CSD_REQUIRE(!a.temb && !a.out_nchw && (a.act == CSD_ACT_NONE || (a.act == CSD_ACT_SWISH && a.nscale)),
+              "pw16: temb / NCHW output / an activation without a GroupNorm are not supported");
   PwKArgs k;
   k.a = a;
   k.C0 = p.C0; k.C1 = p.C1; k.Cout = p.Cout;

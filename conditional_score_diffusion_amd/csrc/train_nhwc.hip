@@ -360,3 +360,12 @@ extern "C" int csd_attention_nhwc(const float* qkv, float* out, int B, int L, in
   CSD_REQUIRE(qkv && out, "attention_nhwc: null argument");
   return attention_launch(qkv, 3 * C, out, B, L, C, (hipStream_t)stream);
 }
+
+// the same core in the arithmetic of a precision mode: CSD_PREC_F32 -> the fp32 MFMA kernel; F16X3 / F16F8 -> split fp16 operands
+// (3 MFMAs per product, fp32-class); F16 -> plain fp16 operands (what csd_unet_forward runs in that mode)
+extern "C" int csd_attention_nhwc_prec(const float* qkv, float* out, int B, int L, int C, int precision, void* stream) {
+  CSD_REQUIRE(qkv && out, "attention_nhwc: null argument");
+  const int ns = precision_ns(precision);
+  if (!ns) return attention_launch(qkv, 3 * C, out, B, L, C, (hipStream_t)stream);
+  return attention16_launch(qkv, 3 * C, out, B, L, C, ns >= 2 ? 2 : 1, (hipStream_t)stream);
+}

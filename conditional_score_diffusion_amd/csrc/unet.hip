@@ -93,6 +93,8 @@ struct PackedConv {
   bool pw = false;               // ns != 0 and the layer runs on the pointwise fp16 kernel (conv_pw16.hip)
   bool q = false;                // ns != 0 and the layer runs on the quad-wave fp16 kernel (conv_f16_q.hip)
   bool ff = false;               // ns != 0 and the layer runs on the fused-prologue kernel (conv_ff.hip): fp32 sources, no gn_apply16
+  int tap_cout = 0;              // pw and the layer is a 3x3 convolution with tap_cout (<= 3) output channels in its tap-partial form (conv_pw16.hip):
+                                 // proto is the POINTWISE contraction to 9 * tap_cout partial channels, a 9-tap gather finishes it
   bool up4 = false;              // q and the layer is the nearest-x2 Upsample conv in its phase-decomposed form (4 x 2x2 taps; conv_f16_q.hip UP4)
   struct Src { int param_w, param_b, layout, cout_src, cout_off, cin_src; };
   std::vector<Src> srcs;
@@ -104,7 +106,7 @@ struct Net;
 // execution plan for one batch size
 // ---------------------------------------------------------------------------------------------
 enum OpKind { OP_ASSEMBLE, OP_TEMB, OP_FOURIER, OP_FIR, OP_GN_APPLY32, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_GN_FINAL_TILES, OP_GN_APPLY16, OP_CONV, OP_ATTN, OP_AVGPOOL,
-              OP_UPNEAR, OP_TO_NCHW };
+              OP_UPNEAR, OP_TO_NCHW, OP_TAPSUM };
 
 static const size_t NONE = (size_t)-1;
 
@@ -491,9 +493,24 @@ static int build_packed_layout(Net& n) {
   const bool fused_norm = getenv("CSD_FUSED_NORM") != nullptr;
   auto add_conv = [&](const std::string& key, int c0, int c1, int cout, int taps,
                       std::vector<PackedConv::Src> srcs, bool stride1 = true, bool normed = false,
-                      bool resample = false, bool upsample = false) -> int {
+                      bool resample = false, bool upsample = false, bool last = false) -> int {
     PackedConv pc;
-    int rc = proto_conv(&pc.proto, c0, c1, cout, taps);
+    int rc;
+    if (last && net_ns && taps == 9 && c1 == 0 && srcs.size() == 1 && srcs[0].layout == 0 && srcs[0].cout_off == 0 &&
+        (srcs[0].cin_src <= 0 || srcs[0].cin_src == c0) && pw16_taps_supported(c0, cout, net_ns)) {
+      // the network's last layer (nf -> 3 channels): one pointwise contraction to 27 tap-partial channels + a gather (conv_pw16.hip)
+      if ((rc = proto_conv(&pc.proto, c0, 0, pw16_taps_cout(cout), 1))) return rc;
+      pc.ns = net_ns;
+      pc.pw = true;
+      pc.tap_cout = cout;
+      pc.w_off = take(pw16_packed_bytes(pc.proto, pc.ns) / sizeof(float) + 1);
+      pc.b_off = take((size_t)pc.proto.CoutPad + 96);
+      pc.srcs = srcs;
+      n.pconv_by_name[key] = (int)n.pconvs.size();
+      n.pconvs.push_back(pc);
+      return CSD_OK;
+    }
+    rc = proto_conv(&pc.proto, c0, c1, cout, taps);
     if (rc) return rc;
     ConvPlan one = pc.proto;       // a GroupNorm-ed conv reads ONE fp16 tensor of c0 + c1 channels
     one.C0 = c0 + c1; one.C1 = 0;
@@ -638,9 +655,9 @@ static int build_packed_layout(Net& n) {
       n.dense_total += m.cout;
       return CSD_OK;
     };
-    auto conv3_layout = [&](Module& m, int cin_pad, bool normed) -> int {
+    auto conv3_layout = [&](Module& m, int cin_pad, bool normed, bool last = false) -> int {
       return add_conv(std::to_string(m.idx), cin_pad, 0, m.cout, 9,
-                      {{n.P(mname(m.idx, "weight")), n.P(mname(m.idx, "bias")), 0, m.cout, 0, m.cin}}, true, normed);
+                      {{n.P(mname(m.idx, "weight")), n.P(mname(m.idx, "bias")), 0, m.cout, 0, m.cin}}, true, normed, false, false, last);
     };
     auto gn_layout = [&](Module& m) {
       add_copy(mname(m.idx, "weight"));
@@ -704,7 +721,7 @@ static int build_packed_layout(Net& n) {
     }
     if (c.progressive != 1) {
       gn_layout(nextm());
-      if ((rc = conv3_layout(nextm(), ich, true))) return rc;
+      if ((rc = conv3_layout(nextm(), ich, true, /*last=*/true))) return rc;
     }
     CSD_REQUIRE(mj == n.mods.size(), "ncsnpp: internal module walk mismatch");
     n.dense_all_off = take((size_t)n.dense_total * 4 * c.nf);
@@ -748,7 +765,7 @@ static int build_packed_layout(Net& n) {
   {
     Module& m = next_mod();
     rc = add_conv(std::to_string(m.idx), m.cin, 0, m.cout, 9,
-                  {{n.P(mname(m.idx, "weight")), n.P(mname(m.idx, "bias")), 0, m.cout, 0}});
+                  {{n.P(mname(m.idx, "weight")), n.P(mname(m.idx, "bias")), 0, m.cout, 0}}, true, false, false, false, /*last=*/true);
     if (rc) return rc;
   }
   CSD_REQUIRE(mi == n.mods.size(), "unet: internal module walk mismatch");
@@ -830,6 +847,43 @@ struct Builder {
   size_t conv(const std::string& key, size_t src0, size_t src1, int ih, int iw, int stride, int pad, int up,
               bool norm, int act, size_t res, size_t temb_col, bool external_nchw, int real_cin = -1) {
     const PackedConv& pc = n.pconvs[n.pconv_by_name.at(key)];
+    if (pc.tap_cout) {
+      // tap-partial form (conv_pw16.hip): pointwise contraction of act(GN(x)) to 9 * cout partial channels, then the 9-tap gather
+      if (!norm || src1 != NONE || stride != 1 || up || pad != 1 || res != NONE || temb_col != NONE) {
+        set_error("tap-partial conv on an unsupported layer"); rc = CSD_ERR_INVALID; return NONE;
+      }
+      Op o;
+      o.kind = OP_CONV;
+      o.cp = pc.proto;
+      o.cp.B = B; o.cp.IH = o.cp.OH = ih; o.cp.IW = o.cp.OW = iw;
+      o.cp.stride = 1; o.cp.pad = 0; o.cp.up = 0;
+      o.i4 = pc.ns; o.i2 = 1;
+      o.a = src0; o.b = NONE; o.pk0 = pc.w_off; o.pk1 = NONE;          // (the bias joins in the gather)
+      o.d = nscale; o.e = nshift;
+      o.act = act;
+      o.temb_base = dense_all; o.temb_stride = n.dense_total;
+      const size_t part = alloc_((size_t)B * ih * iw * o.cp.Cout);
+      o.out = part;
+      o.cls = CSD_PROF_CONV3X3;
+      pl.ops.push_back(o);
+      const size_t out_elems = (size_t)B * ih * iw * pc.tap_cout;
+      count(2.0 * out_elems * o.cp.C0 * 9, ((double)B * ih * iw * o.cp.C0 + (double)out_elems) * 4);
+      pl.ops.back().bytes = (double)B * ih * iw * (o.cp.C0 + o.cp.Cout) * 4.0;
+      Op g;
+      g.kind = OP_TAPSUM;
+      g.a = part; g.pk1 = pc.b_off;
+      g.i0 = ih; g.i1 = iw; g.i2 = pc.tap_cout;
+      g.fscale = pending_scale;
+      pending_scale = 1.f;
+      g.out_external = external_nchw ? 1 : 0;
+      g.out = external_nchw ? NONE : alloc_(out_elems);
+      g.cls = CSD_PROF_CONV3X3;
+      g.bytes = (double)B * ih * iw * (o.cp.Cout + pc.tap_cout) * 4.0;
+      pl.ops.push_back(g);
+      pl.launches += 1;
+      ar.release(part);
+      return g.out;
+    }
     Op o;
     o.kind = OP_CONV;
     o.cp = pc.proto;
@@ -1416,7 +1470,7 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
       case OP_CONV: {
         ConvArgs a;
         a.src0 = W(o.a); a.src1 = W(o.b);
-        a.wpack = pk + o.pk0; a.bias = pk + o.pk1;
+        a.wpack = pk + o.pk0; a.bias = o.pk1 == NONE ? nullptr : pk + o.pk1;
         a.temb = o.temb_col == NONE ? nullptr : ws + o.temb_base + o.temb_col;
         a.res = W(o.c);
         a.nscale = W(o.d);
@@ -1435,13 +1489,19 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         break;
       }
       case OP_ATTN:
-        rc = attention_launch(W(o.a), 3 * o.i1, W(o.out), B, o.i0, o.i1, s);
+        // fp16 arithmetic modes: the split-operand kernel on the fp16 matrix cores (fp32-class in the split modes); fp32 mode: the fp32 MFMA one
+        rc = (precision_ns(c.precision) && !getenv("CSD_ATTN_F32"))
+                 ? attention16_launch(W(o.a), 3 * o.i1, W(o.out), B, o.i0, o.i1, precision_ns(c.precision) >= 2 ? 2 : 1, s)
+                 : attention_launch(W(o.a), 3 * o.i1, W(o.out), B, o.i0, o.i1, s);
         break;
       case OP_AVGPOOL:
         rc = avgpool2_launch(W(o.a), W(o.out), B, o.i0, o.i0, o.i1, s);
         break;
       case OP_UPNEAR:
         rc = nearest_up2_nhwc_launch(W(o.a), W(o.out), B, o.i0, o.i0, o.i1, s);
+        break;
+      case OP_TAPSUM:
+        rc = tapsum_launch(W(o.a), pk + o.pk1, o.out_external ? out : W(o.out), B, o.i0, o.i1, o.i2, o.out_external, o.fscale, s);
         break;
       default:
         set_error("unet: unknown op");
@@ -1495,6 +1555,7 @@ static int pack_all(Net& n, float* pk, hipStream_t s) {
          : pc.up4 ? conv16q_pack_weight_up4(one, pc.ns, n.params[src.param_w].ptr, pk + pc.w_off, s)
          : pc.q ? conv16q_pack_weight(one, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
                                       src.cout_off, pk + pc.w_off, s)
+         : pc.tap_cout ? pw16_pack_weight_taps(pc.proto, pc.ns, n.params[src.param_w].ptr, pc.tap_cout, pk + pc.w_off, s)
          : pc.pw ? pw16_pack_weight(pc.proto, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
                                     src.cout_off, pk + pc.w_off, s)
          : pc.ns ? conv16_pack_weight(pc.proto, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,

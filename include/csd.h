@@ -367,6 +367,9 @@ int csd_sumpool2_nhwc(const float* in, float* out, int B, int h, int w, int C, v
 /* attention core and its backward on the packed qkv tensor [B, L, 3C] (q | k | v per pixel); out, dout [B, L, C];
  * scratch of the backward: csd_attention_backward_scratch_bytes(B, C, L, 1) */
 int csd_attention_nhwc(const float* qkv, float* out, int B, int L, int C, void* stream);
+/* the same forward core in the arithmetic csd_unet_forward uses in precision mode `precision` (CSD_PREC_*): F32 = the call above;
+ * F16X3 / F16F8 = operands split hi + lo on the fp16 matrix cores (fp32-class); F16 = plain fp16 operands */
+int csd_attention_nhwc_prec(const float* qkv, float* out, int B, int L, int C, int precision, void* stream);
 int csd_attention_backward_nhwc(const float* qkv, const float* dout, float* dqkv, int B, int L, int C, void* scratch,
                                 void* stream);
 

@@ -118,6 +118,25 @@ def test_attention_peaked_softmax():
     assert rel(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize('precision,tol', [('fp16x3', 1e-5), ('fp16f8', 1e-5), ('fp16', 3e-3), ('fp32', 1e-5)])
+@pytest.mark.parametrize('B,L,C', [(3, 400, 192), (2, 100, 288), (2, 25, 288), (2, 256, 128), (1, 64, 256), (2, 37, 32), (1, 129, 96),
+                                   (1, 160, 64)])
+def test_attention_core_in_every_precision_mode(B, L, C, precision, tol):
+    """csd_attention_nhwc_prec (what the planned network runs in each arithmetic mode) on the packed [B, L, 3C] tensor: ragged key
+    tiles (L % 32 != 0), every instantiated width, a dominating late key (online-softmax rescale)"""
+    from conditional_score_diffusion_amd import _lib
+    qkv = rnd(B, L, 3 * C, seed=L + C) * 2
+    qkv[:, L - 1, C:2 * C] = qkv[:, 0, :C] * 3          # the last key dominates query 0
+    q, k, v = qkv[..., :C].double(), qkv[..., C:2 * C].double(), qkv[..., 2 * C:].double()
+    w = torch.softmax(torch.einsum('bqc,bkc->bqk', q, k) * (int(C) ** (-0.5)), dim=-1)
+    ref = torch.einsum('bqk,bkc->bqc', w, v)
+    g = qkv.to(dev())
+    out = torch.empty(B, L, C, device=dev())
+    _lib.check(_lib.lib().csd_attention_nhwc_prec(_lib.ptr(g), _lib.ptr(out), B, L, C, _lib.PREC_IDS[precision],
+                                                  _lib.current_stream(g.device)), 'attention_nhwc_prec')
+    assert rel(out, ref) < tol
+
+
 @pytest.mark.parametrize('up,down,pad', [(2, 1, (2, 1)), (1, 2, (1, 1)), (1, 1, (1, 2)), (2, 2, (0, 0))])
 def test_upfirdn2d(up, down, pad):
     from conditional_score_diffusion_amd import ops

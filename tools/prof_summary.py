@@ -52,7 +52,27 @@ def counters(path, filt='conv_f'):
         print('%-34s wgs=%-6d %-28s avg=%.4g (n=%d)' % (k + (v[1] / v[0], v[0])))
 
 
+def timeline(path, marker='assemble_input_kernel'):
+    """the launches of the LAST complete network evaluation in start order: index, kernel, workgroups, us, gap to the previous end"""
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r['Start_Timestamp']))
+    starts = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
+    lo, hi = starts[-2], starts[-1]
+    prev = None
+    tot = 0
+    for i, r in enumerate(rows[lo:hi]):
+        n = demangle(r['Kernel_Name']).split('(')[0].replace('void csd::', '').replace('csd::', '')
+        s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        tot += e - s
+        print('%3d %-58s wgs=%-6d lds=%-6s %8.1f us  gap %6.1f' % (i, n, int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']),
+                                                               r['LDS_Block_Size'], (e - s) / 1e3, 0. if prev is None else (s - prev) / 1e3))
+        prev = e
+    print('kernel time %.1f us, span %.1f us' % (tot / 1e3, (int(rows[hi - 1]['End_Timestamp']) - int(rows[lo]['Start_Timestamp'])) / 1e3))
+
+
 if __name__ == '__main__':
     kind, path = sys.argv[1], sys.argv[2]
     filt = sys.argv[3] if len(sys.argv) > 3 else 'conv_f'
-    (trace if kind == 'trace' else counters)(path, filt)
+    if kind == 'timeline':
+        timeline(path)
+    else:
+        (trace if kind == 'trace' else counters)(path, filt)
