@@ -177,9 +177,9 @@ int attention16_launch(const float* qkv, int ld, float* out, int B, int L, int C
 // small kernels (elementwise.hip)
 // ---------------------------------------------------------------------------------------
 int timestep_embedding_launch(const float* t, float* out, int B, int dim, hipStream_t s);
-// out[b][n] = sum_k f(in[b][k]) * W[n][k] + bias[n];  f = act_in
+// out[b][n] = g(sum_k f(in[b][k]) * W[n][k] + bias[n]);  f = act_in, g = act_out
 int linear_launch(const float* in, const float* W, const float* bias, float* out, int B, int K, int N,
-                  int act_in, hipStream_t s);
+                  int act_in, hipStream_t s, int act_out = 0);
 // NCHW x (+ y (+ sigma*noise)) -> NHWC [B,H,W,Cpad], v -> 2v-1 unless centered
 int assemble_input_launch(const float* x, const float* y, const float* y_noise, float y_sigma,
                           float* out, int B, int Cx, int Cy, int HW, int Cpad, int centered,

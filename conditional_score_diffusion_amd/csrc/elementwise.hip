@@ -52,9 +52,13 @@ int timestep_embedding_launch(const float* t, float* out, int B, int dim, hipStr
 // fp32 sum over k - the same bits whatever the batch size.  (The first version ran one wave per (feature, sample): 405 k waves for the
 // 6336 Dense_0 columns of SR3-160 at B = 64, 168 us per evaluation.)
 #define LIN_KC 256
+// VEC: K % 4 == 0 (rows 16-byte aligned: every net of the reference) - float4 loads; else four clamped dword loads per item.
+// Straight-line staging: clamped addresses + selects, no branch around a load (a guarded load sits in its own basic block behind an
+// s_waitcnt: the 20 loads of a chunk would run one round trip each instead of all in flight).
+template <bool VEC>
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ in, const float* __restrict__ W,
                                                      const float* __restrict__ bias, float* __restrict__ out,
-                                                     int B, int K, int N, int act_in) {
+                                                     int B, int K, int N, int act_in, int act_out) {
   __shared__ float xs[LIN_KC][65];                               // [k][sample] (+1: the transposing store is conflict-free)
   __shared__ __attribute__((aligned(16))) float ws[16][LIN_KC];  // [feature][k]: read as wave-wide broadcasts
   const int tid = threadIdx.x;
@@ -62,45 +66,50 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ i
   const int n0 = blockIdx.x * 16;
   const int b0 = blockIdx.y * 64;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  auto load4 = [&](const float* row, int k, int kc) __attribute__((always_inline)) {      // row[k .. k+3], zeros from kc on
+    float4 v;
+    if (VEC) {
+      v = *reinterpret_cast<const float4*>(row + (k < kc ? k : 0));
+    } else {
+      v.x = row[min(k, kc - 1)]; v.y = row[min(k + 1, kc - 1)]; v.z = row[min(k + 2, kc - 1)]; v.w = row[min(k + 3, kc - 1)];
+    }
+    v.x = k < kc ? v.x : 0.f; v.y = k + 1 < kc ? v.y : 0.f; v.z = k + 2 < kc ? v.z : 0.f; v.w = k + 3 < kc ? v.w : 0.f;
+    return v;
+  };
   for (int k0 = 0; k0 < K; k0 += LIN_KC) {
     const int kc = min(LIN_KC, K - k0);
     __syncthreads();
-    // ALL the chunk's loads in flight at once (16 + 4 float4 per thread): with one workgroup of four waves per CU nothing else covers
-    // the L2 / HBM round trip - a loop of load -> store trips ran at one round trip per trip (47 us for the 384 -> 384 layer)
-    const bool vec = (K & 3) == 0;                  // rows 16-byte aligned (every net of the reference); else dword loads
     float4 xv[16], wv4[4];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int i = tid + u * 256;                  // float4 index: sample bb, k4 (k fastest)
       const int bb = i / (LIN_KC / 4), k = (i % (LIN_KC / 4)) * 4;
-      const float* src = in + (size_t)(b0 + bb) * K + k0 + k;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b0 + bb < B) {
-        if (vec && k + 3 < kc) v = *reinterpret_cast<const float4*>(src);
-        else { if (k < kc) v.x = src[0]; if (k + 1 < kc) v.y = src[1]; if (k + 2 < kc) v.z = src[2]; if (k + 3 < kc) v.w = src[3]; }
-      }
-      xv[u] = v;
+      xv[u] = load4(in + (size_t)min(b0 + bb, B - 1) * K + k0, k, kc);      // (samples past B: a valid row, never stored)
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = tid + u * 256;
       const int f = i / (LIN_KC / 4), k = (i % (LIN_KC / 4)) * 4;
-      const float* src = W + (size_t)(n0 + f) * K + k0 + k;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);   // (zero tail: the k loop runs in fours)
-      if (n0 + f < N) {
-        if (vec && k + 3 < kc) v = *reinterpret_cast<const float4*>(src);
-        else { if (k < kc) v.x = src[0]; if (k + 1 < kc) v.y = src[1]; if (k + 2 < kc) v.z = src[2]; if (k + 3 < kc) v.w = src[3]; }
+      wv4[u] = load4(W + (size_t)min(n0 + f, N - 1) * K + k0, k, kc);
+    }
+    if (act_in == CSD_ACT_SWISH) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        xv[u].x = ew_act(xv[u].x, CSD_ACT_SWISH); xv[u].y = ew_act(xv[u].y, CSD_ACT_SWISH);
+        xv[u].z = ew_act(xv[u].z, CSD_ACT_SWISH); xv[u].w = ew_act(xv[u].w, CSD_ACT_SWISH);
       }
-      wv4[u] = v;
+    } else if (act_in != CSD_ACT_NONE) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        xv[u].x = ew_act(xv[u].x, act_in); xv[u].y = ew_act(xv[u].y, act_in);
+        xv[u].z = ew_act(xv[u].z, act_in); xv[u].w = ew_act(xv[u].w, act_in);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int i = tid + u * 256;
       const int bb = i / (LIN_KC / 4), k = (i % (LIN_KC / 4)) * 4;
-      xs[k][bb] = k < kc ? ew_act(xv[u].x, act_in) : 0.f;
-      xs[k + 1][bb] = k + 1 < kc ? ew_act(xv[u].y, act_in) : 0.f;
-      xs[k + 2][bb] = k + 2 < kc ? ew_act(xv[u].z, act_in) : 0.f;
-      xs[k + 3][bb] = k + 3 < kc ? ew_act(xv[u].w, act_in) : 0.f;
+      xs[k][bb] = xv[u].x; xs[k + 1][bb] = xv[u].y; xs[k + 2][bb] = xv[u].z; xs[k + 3][bb] = xv[u].w;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -127,14 +136,16 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ i
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = n0 + wave * 4 + q;
-      if (n < N) out[(size_t)b * N + n] = acc[q] + (bias ? bias[n] : 0.f);
+      if (n < N) out[(size_t)b * N + n] = ew_act(acc[q] + (bias ? bias[n] : 0.f), act_out);
     }
   }
 }
 
 int linear_launch(const float* in, const float* W, const float* bias, float* out, int B, int K, int N,
-                  int act_in, hipStream_t s) {
-  hipLaunchKernelGGL(linear_kernel, dim3(cdiv(N, 16), cdiv(B, 64)), dim3(256), 0, s, in, W, bias, out, B, K, N, act_in);
+                  int act_in, hipStream_t s, int act_out) {
+  const dim3 grid(cdiv(N, 16), cdiv(B, 64));
+  if (K % 4 == 0) hipLaunchKernelGGL(linear_kernel<true>, grid, dim3(256), 0, s, in, W, bias, out, B, K, N, act_in, act_out);
+  else hipLaunchKernelGGL(linear_kernel<false>, grid, dim3(256), 0, s, in, W, bias, out, B, K, N, act_in, act_out);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
