@@ -590,8 +590,15 @@ extern "C" size_t csd_conv_wgrad_scratch_bytes(int B, int Cin, int Cout, int H, 
   const int OH = (H << (up2 ? 1 : 0)) / stride, OW = (W << (up2 ? 1 : 0)) / stride;
   int per;
   const int S = wgrad_splits(B, OH, OW, Cin, Cout, ksize, &per);
-  return (al64((size_t)B * H * W * Cin) + al64((size_t)B * OH * OW * Cout) +
-          al64((size_t)S * Cout * Cin * ksize * ksize)) * sizeof(float) + 1024;
+  size_t ext = 0, S2 = 0;
+  if (ksize == 3 && (stride == 2 || up2)) {      // resampling convs in the split-bf16 modes: operands rebuilt on the fine grid (wgrad_impl)
+    const int FH = H << (up2 ? 1 : 0), FW = W << (up2 ? 1 : 0);
+    int per2;
+    S2 = (size_t)wgrad_splits(B, FH, FW, Cin, Cout, 3, &per2);
+    ext = al64((size_t)B * FH * FW * (up2 ? Cin : Cout));
+  }
+  return (al64((size_t)B * H * W * Cin) + al64((size_t)B * OH * OW * Cout) + ext +
+          al64(std::max((size_t)S, S2) * Cout * Cin * ksize * ksize)) * sizeof(float) + 1024;
 }
 
 // layout bit 0: x is NHWC [B,H,W,Cin]; bit 1: dy is NHWC [B,OH,OW,Cout]; bit 2: split-bf16 arithmetic allowed (else exact fp32)
@@ -624,6 +631,27 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin
   else if ((rc = nchw_to_nhwc_launch(x, xh, B, Cin, H * W, Cin, Cin, s))) return rc;
   if (layout & 2) dyh = const_cast<float*>(dy);
   else if ((rc = nchw_to_nhwc_launch(dy, dyh, B, Cout, OH * OW, Cout, Cout, s))) return rc;
+  if ((layout & 4) && ksize == 3 && (stride == 2 || up) && Cin % 4 == 0 && Cout % 4 == 0 && !wgrad_wide(Cin) && !getenv("CSD_WGRAD_FP32") &&
+      !getenv("CSD_WGRAD_RESAMPLE_FP32")) {
+    // resampling convs on the bf16 kernel too (it knows stride 1 only): rebuild ONE operand on the fine grid.
+    //   Upsample (nearest x2, then 3x3): x' = nearest_up2(x), the plain stride-1 gradient of (x', dy).
+    //   Downsample (pad (0,1,0,1), stride 2): y[p] = sum_k W[k] x[2p + k]  ->  dW[k] = sum_q dy'[q] x[q + k - 1] with dy'[2p + 1] = dy[p],
+    //   zeros elsewhere: the stride-1, pad-1 gradient of (x, dy') (x[H] = 0 is that gradient's own padding).
+    // 4x the matrix work of a direct kernel (3/4 zeros / repeats), still half the time of the fp32 one (322 us -> ~150 us per layer
+    // of the 64 x 64 training net).
+    const int FH = H << up, FW = W << up;
+    int per2;
+    const int S2 = wgrad_splits(B, FH, FW, Cin, Cout, 3, &per2);
+    float* ext = partial;
+    float* partial2 = ext + al64((size_t)B * FH * FW * (up ? Cin : Cout));
+    if (up) { if ((rc = nearest_up2_nhwc_launch(xh, ext, B, H, W, Cin, s))) return rc; }
+    else if ((rc = csd_zero_insert_odd_nhwc(dyh, ext, B, OH, OW, Cout, s))) return rc;
+    if ((rc = wgrad_bf16_launch(up ? ext : xh, up ? dyh : ext, partial2, B, FH, FW, Cin, Cout, 3, S2, per2, s))) return rc;
+    const size_t n = (size_t)Cout * Cin * 9;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(n)), dim3(256), 0, s, partial2, dw, n, S2);
+    CSD_LAUNCH_CHECK();
+    return CSD_OK;
+  }
   if ((layout & 4) && stride == 1 && !up && !wgrad_wide(Cin) && !getenv("CSD_WGRAD_FP32")) {
     // split-bf16 operands on the bf16 matrix cores (wgrad_bf16.hip): the fp16 precision modes of the training step
     if ((rc = wgrad_bf16_launch(xh, dyh, partial, B, H, W, Cin, Cout, ksize, S, per, s))) return rc;

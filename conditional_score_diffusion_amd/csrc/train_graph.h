@@ -270,7 +270,7 @@ struct TG {
       top = mk;
     }
     float* a = alloc(act_n(H, C));
-    TG_RUN(csd_attention_nhwc(qkv, a, B, H * H, C, s));
+    TG_RUN(csd_attention_nhwc_prec(qkv, a, B, H * H, C, prec, s));      // (the arithmetic of the mode, as csd_unet_forward)
     const int out = new_tensor(H, C);
     float* o = st.t[out].p;
     rc = conv(a, W(m.idx, "NIN_3.W"), W(m.idx, "NIN_3.b"), o, C, C, H, 1, 1, 0, 0, 3 | 4, h);      // + h in the epilogue

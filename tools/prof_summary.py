@@ -60,7 +60,7 @@ def timeline(path, marker='assemble_input_kernel'):
     prev = None
     tot = 0
     for i, r in enumerate(rows[lo:hi]):
-        n = demangle(r['Kernel_Name']).split('(')[0].replace('void csd::', '').replace('csd::', '')
+        n = demangle(r['Kernel_Name']).replace('(anonymous namespace)::', '').split('(')[0].replace('void csd::', '').replace('csd::', '').replace('void ', '')
         s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
         tot += e - s
         print('%3d %-58s wgs=%-6d lds=%-6s %8.1f us  gap %6.1f' % (i, n, int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']),
@@ -73,6 +73,6 @@ if __name__ == '__main__':
     kind, path = sys.argv[1], sys.argv[2]
     filt = sys.argv[3] if len(sys.argv) > 3 else 'conv_f'
     if kind == 'timeline':
-        timeline(path)
+        timeline(path, sys.argv[3] if len(sys.argv) > 3 else 'assemble_input_kernel')
     else:
         (trace if kind == 'trace' else counters)(path, filt)
