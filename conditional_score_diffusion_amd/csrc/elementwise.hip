@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ i
       *reinterpret_cast<float4*>(&ws[i / (LIN_KC / 4)][(i % (LIN_KC / 4)) * 4]) = wv4[u];
     }
     __syncthreads();
+#pragma unroll 4
     for (int k = 0; k < kc; k += 4) {
       float4 wv[4];
 #pragma unroll

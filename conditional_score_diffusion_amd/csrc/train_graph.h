@@ -32,7 +32,7 @@ struct TrainState {
   float p_drop = 0.f;
   std::vector<TT> t;
   std::vector<TStep> steps;
-  float *xin = nullptr, *emb = nullptr, *temb1 = nullptr, *temb2 = nullptr;
+  float *xin = nullptr, *emb = nullptr, *temb1 = nullptr, *temb2 = nullptr, *temb2_act = nullptr;
 };
 
 static std::map<const Net*, TrainState> g_train;      // one recorded forward per network handle
@@ -206,7 +206,8 @@ struct TG {
       float* d = nullptr;
       if (c.conditional) {                           // the time-embedding row rides in Conv_0's epilogue
         d = alloc((size_t)B * cout);
-        TG_RUN(csd_linear(st.temb2, W(m.idx, "Dense_0.weight"), W(m.idx, "Dense_0.bias"), d, B, 4 * c.nf, cout, act, s));
+        // (act(temb) is computed once per forward: every block's Dense_0 used to redo it inside its own latency-bound launch)
+        TG_RUN(csd_linear(st.temb2_act, W(m.idx, "Dense_0.weight"), W(m.idx, "Dense_0.bias"), d, B, 4 * c.nf, cout, CSD_ACT_NONE, s));
       }
       rc = conv(a0, W(m.idx, "Conv_0.weight"), W(m.idx, "Conv_0.bias"), c0, cin, cout, H, 3, 1, 0, 0, 3, nullptr, d);
       if (rc) return rc;
@@ -318,6 +319,8 @@ struct TG {
       TG_RUN(csd_timestep_embedding(labels, st.emb, B, nf, s));
       TG_RUN(csd_linear(st.emb, W(0, "weight"), W(0, "bias"), st.temb1, B, nf, 4 * nf, CSD_ACT_NONE, s));
       TG_RUN(csd_linear(st.temb1, W(1, "weight"), W(1, "bias"), st.temb2, B, 4 * nf, 4 * nf, act, s));
+      st.temb2_act = alloc((size_t)B * 4 * nf);
+      TG_RUN(csd_act(st.temb2, nullptr, st.temb2_act, act, (int64_t)B * 4 * nf, s));
       mi = 2;
     }
     int rc;
@@ -453,7 +456,7 @@ struct TG {
       rc = sum_pixels(d1, dd, cout, H); if (rc) return rc;
       TG_RUN(csd_sum_rows(dd, DW(m.idx, "Conv_0.bias"), B, cout, s));
       if (c.conditional) {
-        rc = linear_bwd(st.temb2, act, W(m.idx, "Dense_0.weight"), dd, DW(m.idx, "Dense_0.weight"), DW(m.idx, "Dense_0.bias"), dtemb_act,
+        rc = linear_bwd(st.temb2_act, CSD_ACT_NONE, W(m.idx, "Dense_0.weight"), dd, DW(m.idx, "Dense_0.weight"), DW(m.idx, "Dense_0.bias"), dtemb_act,
                         4 * c.nf, cout);
         if (rc) return rc;
       }
