@@ -37,7 +37,7 @@ namespace csd {
 // tap t+1 (lanes 32-63).  MFMA cycles per 16-channel stage: 54 x 32 + 30 x 64 = 3648 against 162 x 32 = 5184; measured
 // network error 2e-5 norm-wise / 8e-5 element-wise (oracle/fp8_correction_study.py) against 1.2e-6 / 4.5e-6 of the full split.
 // LDS formats: pixel record [hi fp16 x16 | lo*2^11 e4m3 x16 | hi e4m3 x16] (64 B, as NS = 2); weight step [cout tile][plane]
-// with plane 0 = fp16 A fragments, plane 1 = [cout row][hi e4m3 x16 | lo*2^11 e4m3 x16] (32 B per row).
+// with plane 0 = fp16 A fragments, plane 1 = [hi e4m3 | lo*2^11 e4m3][cout row][16 channels] (16 B per row and half).
 template <int NS, int NT, bool F8>
 __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __restrict__ g_wpack, const ConvFFArgs k) {
   static_assert(!F8 || NS == 2, "the fp8-correction form shares the two-plane layouts");
@@ -326,11 +326,11 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
       const int t1 = pair ? tap + 1 : tap;
       const int o0 = (tap / 3) * FF_RS + (tap % 3) * FF_PSB, o1 = (t1 / 3) * FF_RS + (t1 % 3) * FF_PSB;
       const int sl1 = pair ? (sl + 1 == R ? 0 : sl + 1) : sl;
-      const char* const wb = ring + (kh ? sl1 : sl) * GB + p32 * 32;
+      const char* const wb = ring + (kh ? sl1 : sl) * GB + p32 * 16;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const uint4f a = *reinterpret_cast<const uint4f*>(wb + (nt * 2 + 1) * 1024);
-        const uint4f c = *reinterpret_cast<const uint4f*>(wb + (nt * 2 + 1) * 1024 + 16);
+        const uint4f c = *reinterpret_cast<const uint4f*>(wb + (nt * 2 + 1) * 1024 + 512);
         const bool z = !pair && kh;
         wa8[nt] = int8v{z ? 0 : (int)a.x, z ? 0 : (int)a.y, z ? 0 : (int)a.z, z ? 0 : (int)a.w,
                         z ? 0 : (int)c.x, z ? 0 : (int)c.y, z ? 0 : (int)c.z, z ? 0 : (int)c.w};
@@ -559,12 +559,14 @@ __global__ void convff_pack_kernel(const float* __restrict__ w, _Float16* __rest
   const _Float16 hi = (_Float16)v;
   dst[0] = hi;
   if (ns == 2) dst[512] = (_Float16)(v - (float)hi);
-  if (ns == 3) {                                      // [cout row][hi e4m3 x16 | lo * 2^11 e4m3 x16]
+  if (ns == 3) {                                      // [hi e4m3 | lo * 2^11 e4m3][cout row][16 channels]: a lane's two 16-byte halves sit 512 bytes
+                                                      // apart, rows 16 bytes apart - conflict-free ds_read_b128 (32-byte rows: 2-way conflicts,
+                                                      // SQ_LDS_BANK_CONFLICT = 29 % of the kernel's LDS cycles)
     const float hf = fminf(fmaxf((float)hi, -448.f), 448.f), lf = fminf(fmaxf((v - (float)hi) * 2048.f, -448.f), 448.f);
     const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(hf, lf, 0, false);
-    unsigned char* c8 = reinterpret_cast<unsigned char*>(wpack + ((step * nt + t) * (size_t)planes + 1) * 512) + row * 32 + (cin % 16);
+    unsigned char* c8 = reinterpret_cast<unsigned char*>(wpack + ((step * nt + t) * (size_t)planes + 1) * 512) + row * 16 + (cin % 16);
     c8[0] = (unsigned char)(pk & 255);
-    c8[16] = (unsigned char)((pk >> 8) & 255);
+    c8[512] = (unsigned char)((pk >> 8) & 255);
   }
 }
 

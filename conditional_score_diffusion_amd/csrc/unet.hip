@@ -864,7 +864,7 @@ struct Builder {
       o.temb_base = dense_all; o.temb_stride = n.dense_total;
       const size_t part = alloc_((size_t)B * ih * iw * o.cp.Cout);
       o.out = part;
-      o.cls = CSD_PROF_CONV3X3;
+      o.cls = CSD_PROF_CONV1X1;                  // (profiler classes follow the kernels: a pointwise contraction + a small gather)
       pl.ops.push_back(o);
       const size_t out_elems = (size_t)B * ih * iw * pc.tap_cout;
       count(2.0 * out_elems * o.cp.C0 * 9, ((double)B * ih * iw * o.cp.C0 + (double)out_elems) * 4);
@@ -877,7 +877,7 @@ struct Builder {
       pending_scale = 1.f;
       g.out_external = external_nchw ? 1 : 0;
       g.out = external_nchw ? NONE : alloc_(out_elems);
-      g.cls = CSD_PROF_CONV3X3;
+      g.cls = CSD_PROF_OTHER;
       g.bytes = (double)B * ih * iw * (o.cp.Cout + pc.tap_cout) * 4.0;
       pl.ops.push_back(g);
       pl.launches += 1;
