@@ -66,6 +66,7 @@ struct ConvPlan {
   int n_groups;             // Cout tiles / NT
   int CoutPad;              // n_groups*NT*32
   size_t lds_bytes;
+  int qnt;                  // quad schedule (conv_f16_q.hip): 16-cout tiles per N half; 0 = by Cout (3: Cout % 96 == 0, else 4); 1: 32-cout groups
 };
 
 struct ConvArgs {

@@ -430,7 +430,8 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
 // ---------------------------------------------------------------------------------------------
 bool conv16q_supported(const ConvPlan& p, int ns) {
   return (ns >= 1 && ns <= 3) && p.taps == 9 && ((p.stride == 1 && (p.up == 0 || p.up == 1)) || (p.stride == 2 && p.up == 0)) &&
-         p.C1 == 0 && p.C0 % 32 == 0 && (p.Cout % 96 == 0 || (p.Cout % 128 == 0 && ns != 3));
+         p.C1 == 0 && p.C0 % 32 == 0 &&
+         (p.qnt == 1 ? (p.Cout % 32 == 0 && ns >= 2 && p.stride == 1 && p.up == 0) : (p.Cout % 96 == 0 || (p.Cout % 128 == 0 && ns != 3)));
 }
 
 // ConvPlan.up == 2 selects the phase-decomposed Upsample (UP4): same source / output sizes as up == 1
@@ -486,12 +487,14 @@ int conv16q_pack_weight_up4(const ConvPlan& p, int ns, const float* w, void* wpa
 }
 
 // 16-cout tiles per N half: groups of 96 couts where that divides (the layout the nf = 96 nets have always had), else of 128
-static inline int q_ntq(int cout) { return cout % 96 == 0 ? 3 : 4; }
+// (ConvPlan.qnt = 1: groups of 32 couts - the 5 x 5 level, where 96-cout groups leave 81 workgroups for 256 CUs and the weight
+// stream of a layer goes through 81 texture paths; 243 workgroups of a third of the weights each run the level's convs 2x faster)
+static inline int q_ntq(const ConvPlan& p) { return p.qnt ? p.qnt : (p.Cout % 96 == 0 ? 3 : 4); }
 
 // ns = 3 (fp16 + fp8 corrections): two planes like ns = 2, the second one holds e4m3 byte pairs
 size_t conv16q_packed_bytes(const ConvPlan& p, int ns) {
   if (ns == 3) ns = 2;
-  const int ntq = q_ntq(p.Cout);
+  const int ntq = q_ntq(p);
   return (size_t)(p.Cout / (32 * ntq)) * 2 * (p.C0 / 32) * 9 * ntq * ns * 1024 + (size_t)4 * ntq * ns * 1024;   // + prefetch slack
 }
 
@@ -549,7 +552,7 @@ int conv16q_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, i
   }
   const size_t total = (size_t)cout_src * p.C0 * 9;
   hipLaunchKernelGGL(conv16q_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w, (_Float16*)wpack, layout,
-                     cin_src, cout_src, cout_off, p.C0, p.Cout, ns, q_ntq(p.Cout), f8);
+                     cin_src, cout_src, cout_off, p.C0, p.Cout, ns, q_ntq(p), f8);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
@@ -564,7 +567,7 @@ int conv16q_plan_tiles(ConvPlan* p, int ns) {
   const int OHt = up4 ? p->IH : p->OH, OWt = up4 ? p->IW : p->OW, ks = up4 ? 2 : 3;
   p->KC = C16_KC;
   p->CoutPad = p->Cout;
-  p->NT = q_ntq(p->Cout);
+  p->NT = q_ntq(*p);
   p->n_groups = p->Cout / (32 * p->NT);
   p->KCS = 2;
   p->LC = 0;
@@ -575,7 +578,7 @@ int conv16q_plan_tiles(ConvPlan* p, int ns) {
   const int nu = st == 2 ? (ns == 2 ? 10 : 5) : (ns == 2 ? 7 : 4);
   auto pitch = [&](int tw) { return in_coord_k(tw, st, ks) <= 24 ? 24 : 34; };
   int best_mq = 0, best_tw = 0, best_th = 0;
-  for (int mq = 4; mq >= 2; mq >>= 1) {        // 128- or 64-pixel tiles
+  for (int mq = p->qnt == 1 ? 2 : 4; mq >= 2; mq >>= 1) {        // 128- or 64-pixel tiles (32-cout groups: 64-pixel tiles only)
     const int npix = 2 * mq * 16;
     int btw = 0, bth = 0, blds = 1 << 30;
     double bcov = -1;
@@ -600,7 +603,11 @@ int conv16q_plan_tiles(ConvPlan* p, int ns) {
     if (mq > 2 && bcov < 0.75 * npix) continue;        // a large tile that would be mostly masked: try the smaller one
     best_mq = mq; best_tw = btw; best_th = bth;
     const long nwg = (long)cdiv(OWt, btw) * cdiv(p->B * OHt, bth) * p->n_groups * (up4 ? 4 : 1);
-    if (nwg >= 512 || mq == 2) break;
+    // (the weight fragments come through the CU's texture path once per WAVE: what a layer costs is the weight traffic of its busiest
+    // CU.  128-pixel tiles halve that traffic as soon as they still put a workgroup on every CU: measured at the 20^2 level (B = 64:
+    // 400 instead of 800 workgroups) -0.6 ms per PC step; at 10^2 (162 workgroups) the 64-pixel tiles stay ahead.)
+    static const long min_wg = getenv("CSD_Q_MINWG") ? atol(getenv("CSD_Q_MINWG")) : 300;
+    if (nwg >= min_wg || mq == 2) break;
   }
   CSD_REQUIRE(best_tw > 0, "conv16q: no feasible tile for OW=%d", p->OW);
   p->TW = best_tw; p->TH = best_th;
@@ -706,9 +713,9 @@ int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) 
     if (mask) return launch_q<MQ_, 2, true, 34, 2, NTQ_, true>(k, p.lds_bytes, s);    \
     return launch_q<MQ_, 2, false, 34, 2, NTQ_, true>(k, p.lds_bytes, s);             \
   }
-  CSD_Q8_CASE(4, 3) CSD_Q8_CASE(2, 3)      // (Cout % 96 == 0 only: with four cout tiles the 128-pixel form spills; those nets run the full split)
+  CSD_Q8_CASE(4, 3) CSD_Q8_CASE(2, 3) CSD_Q8_CASE(2, 1)      // (Cout % 96 == 0 only: with four cout tiles the 128-pixel form spills; those nets run the full split)
 #undef CSD_Q8_CASE
-  CSD_Q_CASE(4, 2, 3) CSD_Q_CASE(2, 2, 3) CSD_Q_CASE(4, 1, 3) CSD_Q_CASE(2, 1, 3)
+  CSD_Q_CASE(4, 2, 3) CSD_Q_CASE(2, 2, 3) CSD_Q_CASE(4, 1, 3) CSD_Q_CASE(2, 1, 3) CSD_Q_CASE(2, 2, 1)
   CSD_Q_CASE(4, 2, 4) CSD_Q_CASE(2, 2, 4) CSD_Q_CASE(4, 1, 4) CSD_Q_CASE(2, 1, 4)
 #undef CSD_Q_CASE
   set_error("conv16q: no kernel for MQ=%d ns=%d NT=%d", p.MT, ns, p.NT);

@@ -512,6 +512,9 @@ static int build_packed_layout(Net& n) {
     }
     rc = proto_conv(&pc.proto, c0, c1, cout, taps);
     if (rc) return rc;
+    // the 5 x 5 level on the quad schedule: 32-cout groups (conv_f16_q.hip: q_ntq)
+    static const int nt1_res = getenv("CSD_Q_NT1_RES") ? atoi(getenv("CSD_Q_NT1_RES")) : 5;      // tuning aid (0 disables)
+    if (net_ns == 2 && normed && stride1 && !resample && cur_res <= nt1_res) pc.proto.qnt = 1;
     ConvPlan one = pc.proto;       // a GroupNorm-ed conv reads ONE fp16 tensor of c0 + c1 channels
     one.C0 = c0 + c1; one.C1 = 0;
     // high-resolution GroupNorm-ed convs run the loader/consumer schedule with the norm fused into its loader
