@@ -118,6 +118,30 @@ def test_attention_peaked_softmax():
     assert rel(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize('B,K,N,act', [(64, 384, 6336, 'swish'), (1, 96, 384, 'none'), (70, 300, 37, 'swish'), (3, 258, 16, 'none'),
+                                       (130, 7, 5, 'swish'), (5, 512, 130, 'relu')])
+def test_linear_ragged_shapes(B, K, N, act):
+    """csd_linear (lane = sample, LDS-staged operands): batches over 64 (two sample blocks), K not a multiple of 4 (dword path) and of the
+    256-wide chunk, N not a multiple of the 16 features of a workgroup, the input activation - against fp64"""
+    from conditional_score_diffusion_amd import ops
+    x, w, b = rnd(B, K, seed=K + B), rnd(N, K, seed=N) * (K ** -0.5), rnd(N, seed=3)
+    xa = {'swish': F.silu, 'relu': F.relu, 'none': (lambda t: t)}[act](x.double())
+    ref = xa @ w.double().t() + b.double()
+    out = ops.linear(x.to(dev()), w.to(dev()), b.to(dev()), act_in=act)
+    assert rel(out, ref) < 1e-5
+    out_nb = ops.linear(x.to(dev()), w.to(dev()), None, act_in=act)
+    assert rel(out_nb, ref - b.double()) < 1e-5
+
+
+def test_linear_same_bits_for_any_batch():
+    """one sequential fp32 sum per output: row 17 of a B = 64 call equals the B = 1 call bit for bit"""
+    from conditional_score_diffusion_amd import ops
+    x, w, b = rnd(64, 384, seed=1), rnd(200, 384, seed=2) * 0.05, rnd(200, seed=3)
+    full = ops.linear(x.to(dev()), w.to(dev()), b.to(dev()), act_in='swish')
+    one = ops.linear(x[17:18].contiguous().to(dev()), w.to(dev()), b.to(dev()), act_in='swish')
+    assert torch.equal(full[17:18], one)
+
+
 @pytest.mark.parametrize('precision,tol', [('fp16x3', 1e-5), ('fp16f8', 1e-5), ('fp16', 3e-3), ('fp32', 1e-5)])
 @pytest.mark.parametrize('B,L,C', [(3, 400, 192), (2, 100, 288), (2, 25, 288), (2, 256, 128), (1, 64, 256), (2, 37, 32), (1, 129, 96),
                                    (1, 160, 64)])
