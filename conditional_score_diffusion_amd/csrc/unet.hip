@@ -122,6 +122,7 @@ struct Op {
   GNPlan gp;
   int act = 0;
   int out_external = 0;               // conv writes to the caller's NCHW output
+  int side = 0;                       // 1: launched on the side stream (after the main stream's work so far); 2: the main stream waits for it first
   float fscale = 1.f;                 // conv: epilogue out_scale
   size_t temb_col = NONE;             // column offset inside dense_all
   int temb_stride = 0;
@@ -201,6 +202,26 @@ struct Net {
   bool packed_once = false;
   std::map<int, std::unique_ptr<Plan>> plans;
   int in_cpad = 8;
+  // second stream for the ResnetBlock shortcut contraction (independent of the block's GroupNorm -> conv chain until the second conv
+  // adds it): an HBM-bound pointwise kernel that fills the CUs a 3x3 launch leaves idle in its last round
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_ready() {
+    if (side) return true;
+    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
+    if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipStreamDestroy(side);
+      side = nullptr;
+      return false;
+    }
+    return true;
+  }
+  ~Net() {
+    if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+  }
 
   int add_param(const std::string& name, std::initializer_list<int64_t> shape) {
     Param p;
@@ -983,20 +1004,26 @@ struct Builder {
   size_t res_block(const Module& m, size_t x0, size_t x1, int c0, int c1, int hw_side) {
     const std::string k = std::to_string(m.idx);
     const int hw = hw_side * hw_side;
-    gn(x0, x1, c0, c1, hw, mname(m.idx, "GroupNorm_0.weight"), mname(m.idx, "GroupNorm_0.bias"));
-    const size_t tcol = n.cfg.conditional ? (size_t)n.dense_col.at(m.idx) : NONE;
-    const size_t h1 = conv(k + ".Conv_0", x0, x1, hw_side, hw_side, 1, 1, 0, true, n.cfg.act, NONE, tcol, false);
-    gn(h1, NONE, m.cout, 0, hw, mname(m.idx, "GroupNorm_1.weight"), mname(m.idx, "GroupNorm_1.bias"));
+    // the shortcut contraction first, on the side stream (it only depends on the block's input; Conv_1 joins it)
+    static const bool side_on = !getenv("CSD_NO_SIDE_STREAM");
     size_t shortcut = x0, sc_buf = NONE;
     if (m.cin != m.cout) {
+      const size_t op0 = pl.ops.size();
       sc_buf = conv(k + (n.cfg.arch == 1 ? ".Conv_2" : ".NIN_0"), x0, x1, hw_side, hw_side, 1, 0, 0, false, 0, NONE, NONE, false);
       shortcut = sc_buf;
+      if (side_on)
+        for (size_t i = op0; i < pl.ops.size(); ++i) pl.ops[i].side = 1;
     } else if (x1 != NONE) {
       set_error("res block %d: identity shortcut on a concatenated input is not supported", m.idx);
       rc = CSD_ERR_INVALID;
     }
+    gn(x0, x1, c0, c1, hw, mname(m.idx, "GroupNorm_0.weight"), mname(m.idx, "GroupNorm_0.bias"));
+    const size_t tcol = n.cfg.conditional ? (size_t)n.dense_col.at(m.idx) : NONE;
+    const size_t h1 = conv(k + ".Conv_0", x0, x1, hw_side, hw_side, 1, 1, 0, true, n.cfg.act, NONE, tcol, false);
+    gn(h1, NONE, m.cout, 0, hw, mname(m.idx, "GroupNorm_1.weight"), mname(m.idx, "GroupNorm_1.bias"));
     pending_scale = skip_scale();
     const size_t out = conv(k + ".Conv_1", h1, NONE, hw_side, hw_side, 1, 1, 0, true, n.cfg.act, shortcut, NONE, false);
+    if (side_on && sc_buf != NONE && rc == CSD_OK && out != NONE) pl.ops.back().side = 2;
     ar.release(h1);
     ar.release(sc_buf);
     return out;
@@ -1436,9 +1463,20 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
   const csd_unet_config& c = n.cfg;
   const int B = pl.B, S = c.image_size;
   auto W = [&](size_t off) -> float* { return off == NONE ? nullptr : ws + off; };
+  bool side_pending = false;
   for (const Op& o : pl.ops) {
     int rc = CSD_OK;
-    ProfScope prof(o.cls, o.flops, o.bytes, s);
+    // side-stream ops: fork after everything enqueued so far, join before the op that consumes the result
+    hipStream_t so = s;
+    if (o.side == 1 && n.side_ready()) {
+      CSD_CHECK_HIP(hipEventRecord(n.ev_fork, s));
+      CSD_CHECK_HIP(hipStreamWaitEvent(n.side, n.ev_fork, 0));
+      so = n.side;
+    } else if (o.side == 2 && side_pending) {
+      CSD_CHECK_HIP(hipStreamWaitEvent(s, n.ev_join, 0));
+      side_pending = false;
+    }
+    ProfScope prof(o.cls, o.flops, o.bytes, so);
     switch (o.kind) {
       case OP_ASSEMBLE:
         rc = assemble_input_launch(x, y, y_noise, y_sigma, W(o.out), B, c.x_channels, c.y_channels, S * S,
@@ -1490,9 +1528,13 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         a.out_scale = o.fscale;
         a.dbg = nullptr;
         a.stats = reinterpret_cast<double*>(W(o.stats));
-        rc = o.i2 == 3 ? convff_launch(o.cp, o.i4, a, s)
-           : o.i2 == 2 ? conv16q_launch(o.cp, o.i4, a, s)
-           : o.i2 ? pw16_launch(o.cp, o.i4, a, s) : (o.i4 ? conv16_launch(o.cp, o.i4, a, s, o.i3 != 0) : conv_launch(o.cp, a, s));
+        rc = o.i2 == 3 ? convff_launch(o.cp, o.i4, a, so)
+           : o.i2 == 2 ? conv16q_launch(o.cp, o.i4, a, so)
+           : o.i2 ? pw16_launch(o.cp, o.i4, a, so) : (o.i4 ? conv16_launch(o.cp, o.i4, a, so, o.i3 != 0) : conv_launch(o.cp, a, so));
+        if (so != s && rc == CSD_OK) {
+          CSD_CHECK_HIP(hipEventRecord(n.ev_join, n.side));
+          side_pending = true;
+        }
         break;
       }
       case OP_ATTN:
