@@ -1004,8 +1004,10 @@ struct Builder {
   size_t res_block(const Module& m, size_t x0, size_t x1, int c0, int c1, int hw_side) {
     const std::string k = std::to_string(m.idx);
     const int hw = hw_side * hw_side;
-    // the shortcut contraction first, on the side stream (it only depends on the block's input; Conv_1 joins it)
-    static const bool side_on = !getenv("CSD_NO_SIDE_STREAM");
+    // the shortcut contraction first; with CSD_SIDE_STREAM=1 on the side stream (it only depends on the block's input; Conv_1 joins it).
+    // Opt-in: -0.35 ms per PC step in a same-box A/B, but the per-launch durations of the overlapped 3x3 launches (what the bench's
+    // roofline object and the rocprofv3 summaries report) then include the time they share the CUs with it
+    static const bool side_on = getenv("CSD_SIDE_STREAM") != nullptr && atoi(getenv("CSD_SIDE_STREAM")) != 0;
     size_t shortcut = x0, sc_buf = NONE;
     if (m.cin != m.cout) {
       const size_t op0 = pl.ops.size();
