@@ -39,7 +39,8 @@ class PCParams(ctypes.Structure):
                 ('std_y', ctypes.POINTER(ctypes.c_float)), ('snr', ctypes.c_float),
                 ('denoise', ctypes.c_int32), ('noise_tape', ctypes.c_void_p), ('seed', ctypes.c_uint64),
                 ('record', ctypes.c_void_p), ('predictor', ctypes.c_int32), ('corrector', ctypes.c_int32),
-                ('pred_coef', ctypes.POINTER(ctypes.c_float)), ('corr_coef', ctypes.POINTER(ctypes.c_float))]
+                ('pred_coef', ctypes.POINTER(ctypes.c_float)), ('corr_coef', ctypes.POINTER(ctypes.c_float)),
+                ('path_coef', ctypes.POINTER(ctypes.c_float)), ('path_std0', ctypes.c_float)]
 
 
 def build(verbose=False):

@@ -200,6 +200,8 @@ int bias_add_nchw_launch(const float* x, const float* bias, float* out, int B, i
                          hipStream_t s);
 int nchw_to_nhwc_launch(const float* in, float* out, int B, int C, int HW, int Cw, int ld, hipStream_t s);
 int nhwc_to_nchw_launch(const float* in, float* out, int B, int C, int HW, int Cstride, hipStream_t s);
+int bridge_update_launch(const float* y0, float* state, const float* z, float w0, float w1, float sd, int has_prev, size_t n,
+                         hipStream_t s);
 int avgpool2_launch(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 int nearest_up2_nhwc_launch(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 

@@ -9,6 +9,8 @@
 //   reverse diffusion (sampling/predictors.py:84-89,97-102 with sde_lib.py:135-140,410-418):
 //       x_mean = x + G^2*score ; x = x_mean + G*z
 // fp contraction is disabled so that mul/add round exactly like the reference's separate torch ops.
+#include <algorithm>
+
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -332,6 +334,23 @@ int scale_rows_launch(float* out, const float* in, const float* scale, int divid
   if (total == 0) return CSD_OK;
   hipLaunchKernelGGL(scale_rows_kernel, dim3(ew_grid(total)), dim3(256), 0, s, out, in, scale, divide,
                      (size_t)per, total);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+// use_path bridge (sde_lib.py:323-339): y_t = w0 * y0 + w1 * y_{t+tau} + std * z, in place on the state; prev == nullptr: w1 term absent
+__global__ void bridge_update_kernel(const float* __restrict__ y0, float* __restrict__ state, const float* __restrict__ z, float w0,
+                                     float w1, float sd, int has_prev, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float m = has_prev ? y0[i] * w0 + state[i] * w1 : y0[i] * w0;      // (the host path: axpby(axpby(y, y_prev, w0, w1), z, 1, std))
+    state[i] = m * 1.0f + z[i] * sd;
+  }
+}
+
+int bridge_update_launch(const float* y0, float* state, const float* z, float w0, float w1, float sd, int has_prev, size_t n,
+                         hipStream_t s) {
+  const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(bridge_update_kernel, dim3(grid), dim3(256), 0, s, y0, state, z, w0, w1, sd, has_prev, n);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }

@@ -1788,6 +1788,7 @@ extern "C" size_t csd_pc_scratch_bytes(const csd_unet* net, int B) {
   fl += 2 * align_up((size_t)B * c.x_channels * hw, 64);
   fl += align_up((size_t)B * std::max(c.y_channels, 1) * hw, 64);
   fl += align_up((size_t)B, 64);
+  fl += align_up((size_t)B * std::max(c.y_channels, 1) * hw, 64);      // y_t of the use_path bridge
   return fl * sizeof(float) + (size_t)B * 64 * 2 * sizeof(double) + 256;
 }
 
@@ -1799,8 +1800,9 @@ __global__ void fill_labels_kernel(float* dst, float v, int B) {
 // one validated view of a csd_pc_* call: scratch carved up, noise bookkeeping per step
 struct PCCtx {
   Net* n; Plan* pl; const float* pk; float* ws;
-  float *net_out, *x_mean, *z, *zy, *labels;
+  float *net_out, *x_mean, *z, *zy, *labels, *ystate;
   double* partial;
+  bool path = false;                                 // use_path: y_t follows the bridge (csd_pc_params.path_coef)
   const csd_pc_params* p;
   float* x; const float* y;
   int B, nchunk;
@@ -1814,6 +1816,18 @@ struct PCCtx {
   int draws_per_step() const { return draws_per_phase() * ((has_phase(0) ? 1 : 0) + (has_phase(1) ? 1 : 0)); }
   // draw k (0-based, in the order of the phases that exist) of step i: from the tape (reference order) or Philox stream
   // 1 + i*draws + k (stream 0 is the prior)
+  // use_path draws: -1 = z_y0 (before the loop); step i: 0 = z_y, 1 .. = the existing phases in the order predictor, corrector
+  const float* noise_path(int i, int k, float* dst, size_t n) const {
+    const int nph = (has_phase(0) ? 1 : 0) + (has_phase(1) ? 1 : 0);
+    if (p->noise_tape) {
+      if (i < 0) return p->noise_tape;
+      const size_t off = ny + (size_t)i * (ny + (size_t)nph * nx) + (k == 0 ? 0 : ny + (size_t)(k - 1) * nx);
+      return p->noise_tape + off;
+    }
+    const uint64_t stream = i < 0 ? 1 : (uint64_t)2 + (uint64_t)i * (1 + nph) + k;
+    if (randn_launch(dst, (int64_t)n, p->seed, stream, s)) return nullptr;
+    return dst;
+  }
   const float* noise(int i, int k, float* dst, size_t n) const {
     if (p->noise_tape) {
       // tape layout per step and existing phase: [zy] z
@@ -1859,7 +1873,10 @@ static int pc_setup(PCCtx* c, csd_unet* net, const void* packed, void* workspace
   c->z = f; f += align_up(c->nx, 64);
   c->zy = f; f += align_up(std::max(c->ny, (size_t)B * hw), 64);
   c->labels = f; f += align_up((size_t)B, 64);
+  c->ystate = f; f += align_up(std::max(c->ny, (size_t)B * hw), 64);
   c->partial = reinterpret_cast<double*>(f);
+  c->path = p->path_coef != nullptr;
+  CSD_REQUIRE(!c->path || (cf.y_channels > 0 && !p->std_y), "pc_sample: use_path needs a conditioning image and no marginal std_y");
   c->per = (int64_t)cf.x_channels * hw;
   c->nchunk = sumsq_nchunk(c->per);
   c->perturb_y = p->std_y != nullptr;
@@ -1874,22 +1891,24 @@ static int pc_phase(const PCCtx& c, int i, int phase, int part, float* sums_out,
   int rc;
   const csd_pc_params* p = c.p;
   if (!c.has_phase(phase)) {                       // 'none': x stays, x_mean = x (sampling/predictors.py:182-200, correctors.py:145-163)
-    if ((part & 2) && phase == 1 && i == p->n_steps - 1 && p->denoise)
+    if ((part & 2) && phase == (c.path ? 0 : 1) && i == p->n_steps - 1 && p->denoise)      // (the step's LAST phase)
       CSD_CHECK_HIP(hipMemcpyAsync(c.x_mean, c.x, c.nx * sizeof(float), hipMemcpyDeviceToDevice, c.s));
     return CSD_OK;
   }
   const int k0 = (phase == 1 && c.has_phase(0) ? 1 : 0) * c.draws_per_phase();
-  const float* zp = c.p->noise_tape ? c.noise(i, k0 + (c.perturb_y ? 1 : 0), nullptr, c.nx) : c.z;
+  const int kp = 1 + (phase == 0 && c.has_phase(1) ? 1 : 0);       // use_path: the predictor draws first
+  const float* zp = c.p->noise_tape ? (c.path ? c.noise_path(i, kp, nullptr, c.nx) : c.noise(i, k0 + (c.perturb_y ? 1 : 0), nullptr, c.nx))
+                                    : c.z;
   if (part & 1) {
-    if (phase == 0 || !c.has_phase(0)) {             // (once per step: by the first phase that evaluates the network)
+    if (c.path ? (phase == 1 || !c.has_phase(1)) : (phase == 0 || !c.has_phase(0))) {      // (once per step: by the first phase that evaluates the network)
       hipLaunchKernelGGL(fill_labels_kernel, dim3(cdiv(c.B, 256)), dim3(256), 0, c.s, c.labels, p->labels[i], c.B);
       CSD_LAUNCH_CHECK();
     }
     const float* zyp = nullptr;
     if (c.perturb_y) { zyp = c.noise(i, k0, c.zy, c.ny); if (!zyp) return CSD_ERR_HIP; }
-    rc = run_plan(*c.n, *c.pl, c.pk, c.ws, c.x, c.y, c.labels, c.net_out, zyp, c.perturb_y ? p->std_y[i] : 0.f, c.s);
+    rc = run_plan(*c.n, *c.pl, c.pk, c.ws, c.x, c.path ? c.ystate : c.y, c.labels, c.net_out, zyp, c.perturb_y ? p->std_y[i] : 0.f, c.s);
     if (rc) return rc;
-    zp = c.noise(i, k0 + (c.perturb_y ? 1 : 0), c.z, c.nx);
+    zp = c.path ? c.noise_path(i, kp, c.z, c.nx) : c.noise(i, k0 + (c.perturb_y ? 1 : 0), c.z, c.nx);
     if (!zp) return CSD_ERR_HIP;
     if (phase == 0 && p->corrector == 0) {
       ProfScope prof(CSD_PROF_SAMPLER, 0, 2.0 * c.nx * 4, c.s);
@@ -1931,10 +1950,24 @@ extern "C" int csd_pc_sample(csd_unet* net, const void* packed, void* workspace,
   PCCtx c;
   int rc = pc_setup(&c, net, packed, workspace, workspace_bytes, scratch, scratch_bytes, x, y, B, p, stream);
   if (rc) return rc;
+  if (c.path) {                                 // y_{T+tau} = y + sigma_y(T+tau) z (sampling/conditional.py:146-149)
+    const float* z0 = c.noise_path(-1, 0, c.zy, c.ny);
+    if (!z0) return CSD_ERR_HIP;
+    if ((rc = bridge_update_launch(c.y, c.ystate, z0, 1.f, 0.f, p->path_std0, 0, c.ny, c.s))) return rc;
+  }
   for (int i = 0; i < p->n_steps; ++i) {
     g_prof.step_on = (i % g_prof.step_stride) == 0;
-    for (int phase = 0; phase < 2; ++phase)     // corrector, then predictor (sampling/conditional.py:208-211)
-      if ((rc = pc_phase(c, i, phase, 3, nullptr, nullptr, 0))) return rc;
+    if (c.path) {                               // y_t from the bridge, predictor, then corrector on the same y_t (:151-170)
+      const float* zy = c.noise_path(i, 0, c.zy, c.ny);
+      if (!zy) return CSD_ERR_HIP;
+      const float* co = p->path_coef + (size_t)i * 3;
+      if ((rc = bridge_update_launch(c.y, c.ystate, zy, co[0], co[1], co[2], 1, c.ny, c.s))) return rc;
+      for (int phase = 1; phase >= 0; --phase)
+        if ((rc = pc_phase(c, i, phase, 3, nullptr, nullptr, 0))) return rc;
+    } else {
+      for (int phase = 0; phase < 2; ++phase)     // corrector, then predictor (sampling/conditional.py:208-211)
+        if ((rc = pc_phase(c, i, phase, 3, nullptr, nullptr, 0))) return rc;
+    }
     if ((rc = pc_step_tail(c, i))) return rc;
   }
   g_prof.step_on = true;
@@ -1948,6 +1981,7 @@ extern "C" int csd_pc_step_begin(csd_unet* net, const void* packed, void* worksp
   int rc = pc_setup(&c, net, packed, workspace, workspace_bytes, scratch, scratch_bytes, x, y, B, p, stream);
   if (rc) return rc;
   CSD_REQUIRE(norm_sums && step >= 0 && step < p->n_steps, "pc_step_begin: bad step %d / null norm_sums", step);
+  CSD_REQUIRE(!c.path, "pc_step_begin: use_path runs through csd_pc_sample only");
   return pc_phase(c, step, 0, 1, norm_sums, nullptr, 0);
 }
 

@@ -121,7 +121,17 @@ def get_pc_conditional_sampler(sde, shape, predictor, corrector, snr, p_steps, c
             return out, {}
 
     if use_path:
-        return path_sampler
+        def pc_path_sampler(model, y, show_evolution=False, noise_tape=None, seed=None):
+            """the bridge sampler on the fused device loop (csd_pc_params.path_coef) when the pair is fusable and no y_t evolution is
+            asked for; else step by step (path_sampler above)"""
+            if not show_evolution and fused.fusable(model, sde, predictor, corrector, c_steps, probability_flow, continuous, use_path=True):
+                x, _, _ = fused.run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=noise_tape, seed=seed,
+                                    predictor=predictor, corrector=corrector, probability_flow=probability_flow, use_path=True)
+                return x, {}
+            if noise_tape is not None:
+                raise NotImplementedError('noise_tape is only available on the fused path')
+            return path_sampler(model, y, show_evolution)
+        return pc_path_sampler
 
     def pc_conditional_sampler(model, y, show_evolution=False, noise_tape=None, seed=None, global_norm=None):
         if fused.fusable(model, sde, predictor, corrector, c_steps, probability_flow, continuous):

@@ -52,7 +52,9 @@ def fusable(model, sde, predictor, corrector, c_steps, probability_flow, continu
         return False
     # the probability-flow drift exists for Euler-Maruyama only (the reverse-diffusion step kernel and ancestral sampling refuse it)
     ok_pf = (not probability_flow) or predictor in (P.EulerMaruyamaPredictor, P.conditionalEulerMaruyamaPredictor)
-    return (isinstance(model, HipUNet) and ok_sde and c_steps == 1 and ok_pf and continuous and not use_path)
+    # use_path (the bridge for y_t): two-SDE setting only
+    ok_path = (not use_path) or isinstance(sde, dict)
+    return (isinstance(model, HipUNet) and ok_sde and c_steps == 1 and ok_pf and continuous and ok_path)
 
 
 def rule_tables(c_sde, ts, predictor, corrector, snr, probability_flow):
@@ -115,8 +117,23 @@ def fresh_seed():
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
+def path_tables(sy, ts):
+    """use_path: per-step bridge coefficients (w0, w1, std) of p(y_t | y_0, y_{t+tau}) and sigma_y(T + tau), evaluated in fp32 with the
+    torch expressions of sde_lib.compute_backward_kernel / marginal_prob (sampling/conditional.py:143-160)"""
+    tau = ts[0] - ts[1] if len(ts) > 1 else ts[0] * 0
+    one, zero = torch.ones(1, 1, 1, 1), torch.zeros(1, 1, 1, 1)
+    std0 = float(sy.marginal_prob(zero, (ts[0] + tau).reshape(1))[1].flatten()[0])
+    rows = []
+    for i in range(len(ts)):
+        t1 = ts[i].reshape(1)
+        m0, sd = sy.compute_backward_kernel(one, zero, t1, tau.reshape(1))
+        m1, _ = sy.compute_backward_kernel(zero, one, t1, tau.reshape(1))
+        rows.append([float(m0.flatten()[0]), float(m1.flatten()[0]), float(sd.flatten()[0])])
+    return torch.tensor(rows, dtype=torch.float32).contiguous(), std0
+
+
 def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=None, record=False,
-        unconditional_label=None, global_norm=None, predictor=None, corrector=None, probability_flow=False):
+        unconditional_label=None, global_norm=None, predictor=None, corrector=None, probability_flow=False, use_path=False):
     """Run the fused loop; returns (samples, record_or_None, timesteps).  ``seed=None``: a fresh key per call (fresh_seed).
 
     ``predictor`` / ``corrector``: the registered classes (default: the reverse-diffusion / Langevin pair); see ``fusable``.
@@ -143,6 +160,14 @@ def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=
         corrector = corrector or C_.LangevinCorrector
         pid, cid, pred_tab, corr_tab = rule_tables(c_sde, ts, predictor, corrector, float(snr), probability_flow)
     n_phases = (pid != 2) + (cid != 2)
+    path_tab, path_std0 = None, 0.0
+    if use_path:
+        if not isinstance(sde, dict):
+            raise NotImplementedError('use_path needs the two-SDE (CMDE / VS-CMDE) setting: sde = {"x": ..., "y": ...}')
+        if global_norm is not None:
+            raise NotImplementedError('use_path is not provided in the global-norm sharded mode')
+        path_tab, path_std0 = path_tables(sde['y'], ts)
+        std_y = None                            # y_t comes from the bridge, not from the marginal
     # prior: N(0, sigma_max^2) (+ data mean) - drawn on the host like the reference (sde_lib.py:397-403)
     if noise_tape is not None:
         tape = [t.float() for t in noise_tape]
@@ -152,6 +177,8 @@ def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=
         x = x.to(dev).contiguous()
         flat = torch.cat([t.reshape(-1) for t in tape[1:]]).to(dev).contiguous() if len(tape) > 1 else None
         expected = n_phases * p_steps * (2 if std_y is not None else 1)
+        if use_path:                            # z_y0 | per step: z_y, z_predictor, z_corrector
+            expected = 1 + p_steps * (1 + n_phases)
         if len(tape) - 1 != expected:
             raise RuntimeError('noise tape holds %d draws after the prior, the loop needs %d' % (len(tape) - 1, expected))
     else:
@@ -177,6 +204,8 @@ def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=
     p.predictor, p.corrector = pid, cid
     p.pred_coef = _fp(pred_tab) if pred_tab is not None else None
     p.corr_coef = _fp(corr_tab) if corr_tab is not None else None
+    p.path_coef = _fp(path_tab) if path_tab is not None else None
+    p.path_std0 = float(path_std0)
     if global_norm is not None and cid != 0:
         global_norm = None                      # only the Langevin corrector couples the samples of a batch
     yy = y.contiguous() if y is not None else None
@@ -194,5 +223,5 @@ def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=
             reduce_fn(sums)
             check(lib().csd_pc_step_end(*args, i, ptr(sums), int(global_batch), current_stream(dev)), 'pc_step_end')
     # keep the host arrays alive until the enqueue returned (they are read at enqueue time only)
-    del labels, std_x, G, std_y, pred_tab, corr_tab
+    del labels, std_x, G, std_y, pred_tab, corr_tab, path_tab
     return x, rec, ts

@@ -166,6 +166,12 @@ typedef struct csd_pc_params {
   int32_t corrector;            /* 0 Langevin (snr, batch-mean norms); 1 affine table corr_coef; 2 none               */
   const float* pred_coef;       /* [n_steps][3] = (p, a, b) when predictor == 1                                      */
   const float* corr_coef;       /* [n_steps][3] when corrector == 1                                                  */
+  /* `use_path` of the two-SDE samplers (sampling/conditional.py:85-100,124-178; sde_lib.py:323-339): y_t is not redrawn from the
+   * marginal for every evaluation but follows the bridge p(y_t | y_0, y_{t+tau}): once per step y_t = w0*y + w1*y_{t+tau} + s*z,
+   * the PREDICTOR runs first, then the corrector, both on that y_t.  path_coef != NULL selects it (std_y must be NULL);
+   * y_{T+tau} = y + path_std0 * z.  Draw order: prior | z_y0 | per step: z_y, z_predictor, z_corrector (existing phases only). */
+  const float* path_coef;       /* [n_steps][3] = (w0, w1, s), or NULL                                                */
+  float path_std0;              /* sigma_y(T + tau)                                                                    */
 } csd_pc_params;
 
 /* x: [B, x_channels, S, S] in: prior sample (already scaled by sigma_max); out: result.

@@ -358,6 +358,74 @@ def test_use_path_sampler_vs_golden(golden_dir):
     assert np.abs(out.cpu().numpy() - g['out']).max() / smax < 2e-4
 
 
+def test_use_path_on_the_fused_loop_vs_golden(golden_dir):
+    """SURVEY.md 8(f) rank 2: the same bridge sampler as ONE device-resident loop (csd_pc_params.path_coef: y_t = w0 y + w1 y_{t+tau}
+    + s z once per step, predictor first, corrector on the same y_t) against the reference's own run (tests/golden/use_path.npz), and
+    against the step-by-step path on the same noise"""
+    from conditional_score_diffusion_amd.sampling import conditional, correctors, fused, predictors
+    g = np.load(os.path.join(golden_dir, 'use_path.npz'))
+    cfg, nc, p, model = build('cmde_tiny')
+    sde = sdes_for(cfg)
+    y = cases.case_y('cmde_tiny').to(dev())
+    B = y.shape[0]
+    xs, ys = (B,) + tuple(cfg.data.shape_x), (B,) + tuple(cfg.data.shape_y)
+    P = 4
+    tp = cases.tape([xs, ys] + [ys, xs, xs] * P, seed=7)
+    Pr, Co = predictors.get_predictor('conditional_reverse_diffusion'), correctors.get_corrector('conditional_langevin')
+    assert fused.fusable(model, sde, Pr, Co, 1, False, True, use_path=True)
+    fn = conditional.get_pc_conditional_sampler(sde, xs, Pr, Co, snr=cfg.sampling.snr, p_steps=P, c_steps=1, continuous=True,
+                                                denoise=True, use_path=True, eps=1e-5)
+    out, info = fn(model, y, noise_tape=tp)
+    smax = float(sde['x'].sigma_max)
+    assert info == {}
+    assert np.abs(out.cpu().numpy() - g['out']).max() / smax < 2e-4
+    # step by step on the same tape (the generic path draws through torch.randn / randn_like)
+    it = iter(tp)
+    o_randn, o_like = torch.randn, torch.randn_like
+    torch.randn = lambda *s, **k: next(it)
+    torch.randn_like = lambda t, **k: next(it).to(t.device)
+    try:
+        ref, _ = fn(model, y, show_evolution=True)
+    finally:
+        torch.randn, torch.randn_like = o_randn, o_like
+    assert np.abs(out.cpu().numpy() - ref.cpu().numpy()).max() / smax < 1e-5
+    # on-device noise: reproducible per seed, different across seeds
+    a, _ = fn(model, y, seed=5)
+    b, _ = fn(model, y, seed=5)
+    c, _ = fn(model, y, seed=6)
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
+
+
+@pytest.mark.parametrize('pred_name,corr_name', [('conditional_euler_maruyama', 'conditional_none'),
+                                                 ('conditional_none', 'conditional_ald'),
+                                                 ('conditional_ancestral_sampling', 'conditional_langevin')])
+def test_use_path_other_pairs_fused_vs_step_by_step(pred_name, corr_name):
+    """the bridge mode with the other registered update rules (phases that do not exist draw nothing; the corrector is the LAST phase)"""
+    from conditional_score_diffusion_amd.sampling import conditional, correctors, predictors
+    cfg, nc, p, model = build('cmde_tiny')
+    sde = sdes_for(cfg)
+    y = cases.case_y('cmde_tiny').to(dev())
+    B = y.shape[0]
+    xs, ys = (B,) + tuple(cfg.data.shape_x), (B,) + tuple(cfg.data.shape_y)
+    P = 3
+    phases = (pred_name != 'conditional_none') + (corr_name != 'conditional_none')
+    tp = cases.tape([xs, ys] + ([ys] + [xs] * phases) * P, seed=11)
+    fn = conditional.get_pc_conditional_sampler(sde, xs, predictors.get_predictor(pred_name), correctors.get_corrector(corr_name),
+                                                snr=cfg.sampling.snr, p_steps=P, c_steps=1, continuous=True, denoise=True,
+                                                use_path=True, eps=1e-5)
+    out, _ = fn(model, y, noise_tape=tp)
+    it = iter(tp)
+    o_randn, o_like = torch.randn, torch.randn_like
+    torch.randn = lambda *s, **k: next(it)
+    torch.randn_like = lambda t, **k: next(it).to(t.device)
+    try:
+        ref, _ = fn(model, y, show_evolution=True)
+    finally:
+        torch.randn, torch.randn_like = o_randn, o_like
+    assert next(it, None) is None
+    assert np.abs(out.cpu().numpy() - ref.cpu().numpy()).max() / float(sde['x'].sigma_max) < 1e-5
+
+
 @pytest.mark.parametrize('precision,tol', [('fp16x3', 3e-5), ('fp16f8', 3e-4), ('fp16', 5e-3), ('fp32', 3e-5)])
 def test_nf128_network_vs_oracle(precision, tol):
     """nf = 128 (the VS-CMDE edges2shoes and NCSN++-256 widths): Cout = 128 / 256 run the quad schedule with four 16-cout
