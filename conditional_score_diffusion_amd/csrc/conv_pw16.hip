@@ -40,7 +40,6 @@ struct PwKArgs {
   int hw;          // pixels per sample (row of the GroupNorm scale/shift table)
   int ks;          // K steps of 32 channels
   int ntiles;      // pixel tiles
-  int G;           // 16-cout tiles per cout group: PW_NTL (96 couts), or 3 (48 couts) when the group's weights would not fit LDS
 };
 
 __device__ __forceinline__ float4 pw_gload4(const float* p) {
@@ -64,8 +63,7 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
   const int Cin = k.C0 + k.C1;
 
   // ---- this cout group's weights -> LDS, once per workgroup ----
-  const int G = k.G;
-  const int wbytes = k.ks * G * NS * 1024;
+  const int wbytes = k.ks * PW_NTL * NS * 1024;
   {
     const char* wsrc = g_wpack + (size_t)ng * wbytes;
     for (int i = tid * 16; i < wbytes; i += PW_THREADS * 16)
@@ -73,11 +71,11 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
   }
   // bias of this group's 96 couts behind the weights (zero where the cout does not exist)
   float* const lds_bias = reinterpret_cast<float*>(smem + wbytes);
-  if (tid < G * 16) {
-    const int c = ng * (G * 16) + tid;
+  if (tid < PW_NTL * 16) {
+    const int c = ng * (PW_NTL * 16) + tid;
     lds_bias[tid] = (k.a.bias && c < k.Cout) ? k.a.bias[c] : 0.f;
   }
-  const int col_base = ng * (G * 16) + kq * 4;            // this lane's first cout of tile 0
+  const int col_base = ng * (PW_NTL * 16) + kq * 4;       // this lane's first cout of tile 0
   __syncthreads();
 
   const int nt_mine = (k.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -85,7 +83,7 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
   const bool has_norm = k.a.nscale != nullptr;
   const bool has_res = k.a.res != nullptr;
   const bool has_act = k.a.act == CSD_ACT_SWISH;          // (only next to a GroupNorm: the tap-partial form of a tiny-Cout 3x3, below)
-  const int ntl = min(G, (k.Cout - (int)blockIdx.y * (G * 16) + 15) / 16);     // 16-cout tiles of this group that exist
+  const int ntl = min(PW_NTL, (k.Cout - (int)blockIdx.y * (PW_NTL * 16) + 15) / 16);     // 16-cout tiles of this group that exist
 
   float4 raw[2][MTP][2];
   floatx4 acc[MTP][PW_NTL];
@@ -155,7 +153,7 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
         }
         issue(raw[u]);                       // this slot is free again: request K step it+u+2
         // ---- MFMAs: 6 cout tiles x MTP pixel tiles ----
-        const char* wk = smem + (size_t)c_kk * G * NS * 1024 + lane * 16;
+        const char* wk = smem + (size_t)c_kk * PW_NTL * NS * 1024 + lane * 16;
 #pragma unroll
         for (int nt = 0; nt < PW_NTL; ++nt) {
           if (nt >= ntl) continue;             // (uniform: a 28-cout layer runs 2 of the 6 tiles)
@@ -190,20 +188,20 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
 #pragma unroll
             for (int nt = 0; nt < PW_NTL; ++nt) {
               const int col0 = col_base + nt * 16;
-              const unsigned off = (pv && has_res && nt < ntl && col0 < k.Cout) ? (unsigned)(pl * k.Cout + col0) * 4u : OOB;
+              const unsigned off = (pv && has_res && col0 < k.Cout) ? (unsigned)(pl * k.Cout + col0) * 4u : OOB;
               rv[nt] = __builtin_amdgcn_raw_buffer_load_b128(res_r, off, 0, 0);
             }
 #pragma unroll
             for (int nt = 0; nt < PW_NTL; ++nt) {
               const int col0 = col_base + nt * 16;
-              const float4 b = *reinterpret_cast<const float4*>(lds_bias + (nt < ntl ? nt : 0) * 16 + kq * 4);
+              const float4 b = *reinterpret_cast<const float4*>(lds_bias + nt * 16 + kq * 4);
               uint4_t ov;
               // (acc*2^-8 + bias) + residual, then the skip_rescale factor: association of the reference
               ov.x = __float_as_uint(((acc[j][nt][0] * unscale + b.x) + __uint_as_float(rv[nt].x)) * k.a.out_scale);
               ov.y = __float_as_uint(((acc[j][nt][1] * unscale + b.y) + __uint_as_float(rv[nt].y)) * k.a.out_scale);
               ov.z = __float_as_uint(((acc[j][nt][2] * unscale + b.z) + __uint_as_float(rv[nt].z)) * k.a.out_scale);
               ov.w = __float_as_uint(((acc[j][nt][3] * unscale + b.w) + __uint_as_float(rv[nt].w)) * k.a.out_scale);
-              const unsigned off = (pv && nt < ntl && col0 < k.Cout) ? (unsigned)(pl * k.a.out_stride + col0) * 4u : OOB;
+              const unsigned off = (pv && col0 < k.Cout) ? (unsigned)(pl * k.a.out_stride + col0) * 4u : OOB;
               __builtin_amdgcn_raw_buffer_store_b128(ov, out_r, off, 0, 0);
               acc[j][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
             }
@@ -219,11 +217,7 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-// 16-cout tiles per cout group: 6 (96 couts) while that group's weights fit LDS, else 3 (Cin = 576 in the split mode: 216 KB -> 108 KB)
-static int pw16_group_tiles(const ConvPlan& p, int ns) {
-  return (size_t)((p.C0 + p.C1) / 32) * PW_NTL * ns * 1024 + PW_NTL * 16 * sizeof(float) <= 150 * 1024 ? PW_NTL : PW_NTL / 2;
-}
-static size_t pw16_w_bytes(const ConvPlan& p, int ns) { return (size_t)((p.C0 + p.C1) / 32) * pw16_group_tiles(p, ns) * ns * 1024; }
+static size_t pw16_w_bytes(const ConvPlan& p, int ns) { return (size_t)((p.C0 + p.C1) / 32) * PW_NTL * ns * 1024; }
 static size_t pw16_lds_bytes(const ConvPlan& p, int ns) { return pw16_w_bytes(p, ns) + PW_NTL * 16 * sizeof(float); }
 
 bool pw16_supported(const ConvPlan& p, int ns) {
@@ -232,12 +226,12 @@ bool pw16_supported(const ConvPlan& p, int ns) {
 }
 
 size_t pw16_packed_bytes(const ConvPlan& p, int ns) {
-  const int n_groups = cdiv(p.Cout, pw16_group_tiles(p, ns) * 16);
+  const int n_groups = cdiv(p.Cout, PW_NTL * 16);
   return (size_t)n_groups * pw16_w_bytes(p, ns);
 }
 
 __global__ void pw16_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ wpack, int layout, int cin_src,
-                                 int cout_src, int cout_off, int ks, int ns, int cout_pad, int G) {
+                                 int cout_src, int cout_off, int ks, int ns, int cout_pad) {
   // one thread per (padded cout, cin) inside [cout_off, cout_off + cout_src) rounded out to whole 16-tiles
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int cin_tot = ks * 32;
@@ -248,10 +242,10 @@ __global__ void pw16_pack_kernel(const float* __restrict__ w, _Float16* __restri
   const int cout = cp - cout_off;
   if (cp >= cout_pad || cout < 0 || cout >= cout_src || cin >= cin_src) return;   // padding stays zero
   const float v = ((layout == 0) ? w[(size_t)cout * cin_src + cin] : w[(size_t)cin * cout_src + cout]) * PW_WSCALE;   // (layout 2 == 1 for 1x1)
-  const int ng = cp / (G * 16), nt = (cp % (G * 16)) / 16, r = cp % 16;
+  const int ng = cp / (PW_NTL * 16), nt = (cp % (PW_NTL * 16)) / 16, r = cp % 16;
   const int kk = cin / 32, kq = (cin % 32) / 8, q = cin % 8;
   const int lane = kq * 16 + r;
-  _Float16* dst = wpack + ((((size_t)ng * ks + kk) * G + nt) * ns) * 512 + lane * 8 + q;
+  _Float16* dst = wpack + ((((size_t)ng * ks + kk) * PW_NTL + nt) * ns) * 512 + lane * 8 + q;
   const _Float16 hi = (_Float16)v;
   dst[0] = hi;
   if (ns == 2) dst[512] = (_Float16)(v - (float)hi);
@@ -266,8 +260,7 @@ int pw16_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int 
                      void* wpack, hipStream_t s) {
   CSD_REQUIRE(cout_off % 16 == 0, "pw16 pack: cout offset %d is not a multiple of 16", cout_off);
   const int ks = (p.C0 + p.C1) / 32;
-  const int G = pw16_group_tiles(p, ns);
-  const int cout_pad = cdiv(p.Cout, G * 16) * G * 16;
+  const int cout_pad = cdiv(p.Cout, PW_NTL * 16) * PW_NTL * 16;
   if (cout_off == 0) {
     const size_t n32 = pw16_packed_bytes(p, ns) / 4;
     hipLaunchKernelGGL(pw16_zero_kernel, dim3((unsigned)cdiv64(n32, 256)), dim3(256), 0, s, (uint32_t*)wpack, n32);
@@ -275,7 +268,7 @@ int pw16_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int 
   }
   const size_t total = (size_t)(cdiv(cout_off + cout_src, 16) - cout_off / 16) * 16 * ks * 32;
   hipLaunchKernelGGL(pw16_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w, (_Float16*)wpack, layout,
-                     cin_src, cout_src, cout_off, ks, ns, cout_pad, G);
+                     cin_src, cout_src, cout_off, ks, ns, cout_pad);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
@@ -308,8 +301,7 @@ __global__ void pw16_pack_taps_kernel(const float* __restrict__ w, _Float16* __r
 }
 
 int pw16_pack_weight_taps(const ConvPlan& p, int ns, const float* w, int cout, void* wpack, hipStream_t s) {
-  CSD_REQUIRE(p.C1 == 0 && p.Cout == pw16_taps_cout(cout) && p.Cout <= PW_NTL * 16 && pw16_group_tiles(p, ns) == PW_NTL,
-              "pw16 tap pack: Cout %d for %d real couts", p.Cout, cout);
+  CSD_REQUIRE(p.C1 == 0 && p.Cout == pw16_taps_cout(cout) && p.Cout <= PW_NTL * 16, "pw16 tap pack: Cout %d for %d real couts", p.Cout, cout);
   const int ks = p.C0 / 32;
   const size_t n32 = pw16_packed_bytes(p, ns) / 4;
   hipLaunchKernelGGL(pw16_zero_kernel, dim3((unsigned)cdiv64(n32, 256)), dim3(256), 0, s, (uint32_t*)wpack, n32);
@@ -406,7 +398,7 @@ static int pw16_launch_t(const PwKArgs& k, const ConvPlan& p, hipStream_t s) {
     }
     attr_lds = 160 * 1024;
   }
-  const int n_groups = cdiv(p.Cout, k.G * 16);
+  const int n_groups = cdiv(p.Cout, PW_NTL * 16);
   // persistent: two workgroups per CU (register bound) share the tiles of one cout group
   int gx = (OCC * 256) / n_groups;
   if (gx < 1) gx = 1;
@@ -427,7 +419,6 @@ int pw16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
   k.npix = p.B * p.OH * p.OW;
   k.hw = p.OH * p.OW;
   k.ks = (p.C0 + p.C1) / 32;
-  k.G = pw16_group_tiles(p, ns);
   // big layers: 128-pixel tiles (2 x 16 pixels per wave) - 150 registers, three workgroups per CU measured
   // fastest (more waves in flight beat more bytes per wave); small layers: 64-pixel tiles to fill the chip
   const bool big = cdiv(k.npix, 128) >= 768;
