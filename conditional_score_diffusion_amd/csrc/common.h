@@ -133,7 +133,7 @@ size_t pw16_packed_bytes(const ConvPlan& p, int ns);
 int pw16_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int cin_src, int cout_src, int cout_off,
                      void* wpack, hipStream_t s);
 int pw16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s);
-// tap-partial form of a 3x3 convolution with <= 3 output channels: one pointwise contraction to 9*cout partial channels + a 9-tap gather
+// tap-partial form of a 3x3 convolution with <= 6 output channels: one pointwise contraction to 9*cout partial channels + a 9-tap gather
 bool pw16_taps_supported(int cin, int cout, int ns);
 int pw16_taps_cout(int cout);
 int pw16_pack_weight_taps(const ConvPlan& p, int ns, const float* w, int cout, void* wpack, hipStream_t s);

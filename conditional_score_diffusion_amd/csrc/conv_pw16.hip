@@ -274,7 +274,7 @@ int pw16_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// tap-partial form of a 3x3 convolution with a handful of output channels (the networks' last layer: nf -> 3 channels,
+// tap-partial form of a 3x3 convolution with a handful of output channels (the networks' last layer: nf -> 3 or 6 channels,
 // reference models/ddpm.py:146, models/ncsnpp.py:234).  On the 3x3 kernels its 3 couts occupy one
 // 32-cout MFMA tile (90 % zeros) behind a gn_apply16 pass: 0.97 ms per evaluation at 160^2, B = 64, for 8.5 GFLOP.  Here
 //     P[b][y][x][tap*Co + co] = sum_ci act(GN(x))[b][y][x][ci] * W[co][ci][tap]       one POINTWISE contraction, nf -> 9*Co (27) couts,
@@ -324,9 +324,10 @@ __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ p
   const int tx0 = blockIdx.x * 16, ty0 = blockIdx.y * 16;
   const size_t b = blockIdx.z;
   const int cp4 = cp >> 2, total = 324 * cp4;
-  float4 v[9];
+  constexpr int NV = (324 * (((9 * CO + 3) / 4 * 4) / 4) + 255) / 256;      // float4 per thread: 9 for 3 couts, 18 for 6
+  float4 v[NV];
 #pragma unroll
-  for (int u = 0; u < 9; ++u) {
+  for (int u = 0; u < NV; ++u) {
     const int i = min(tid + u * 256, total - 1);
     const int rec = i / cp4, q = i - rec * cp4;
     const int pr = rec / 18, pc = rec - pr * 18;
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ p
                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
-  for (int u = 0; u < 9; ++u) {
+  for (int u = 0; u < NV; ++u) {
     const int i = tid + u * 256;
     if (i < total) *reinterpret_cast<float4*>(ts_tile + (size_t)i * 4) = v[u];      // (record-major, cp4 float4 per record: linear)
   }
@@ -363,12 +364,21 @@ __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ p
 int tapsum_launch(const float* part, const float* bias, float* out, int B, int H, int W, int cout, int nchw, float out_scale,
                   hipStream_t s) {
   const int cp = pw16_taps_cout(cout);
-  CSD_REQUIRE(324 * (cp / 4) <= 9 * 256, "tapsum: %d partial channels exceed the staging slots", cp);
   const dim3 grid(cdiv(W, 16), cdiv(H, 16), B), block(256);
   const size_t lds = (size_t)324 * cp * sizeof(float);
   switch (cout) {
-#define CSD_TS_CASE(CO) case CO: hipLaunchKernelGGL(tapsum_kernel<CO>, grid, block, lds, s, part, bias, out, H, W, cp, nchw, out_scale); break;
-    CSD_TS_CASE(1) CSD_TS_CASE(2) CSD_TS_CASE(3)
+#define CSD_TS_CASE(CO)                                                                                                              \
+  case CO: {                                                                                                                         \
+    static bool attr_set = false;                                                                                                    \
+    if (!attr_set && lds > 64 * 1024) {      /* 6 couts (the paired networks' score_x | score_y): 72.6 KB */                         \
+      CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tapsum_kernel<CO>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        160 * 1024));                                                                               \
+      attr_set = true;                                                                                                               \
+    }                                                                                                                                \
+    hipLaunchKernelGGL(tapsum_kernel<CO>, grid, block, lds, s, part, bias, out, H, W, cp, nchw, out_scale);                          \
+    break;                                                                                                                           \
+  }
+    CSD_TS_CASE(1) CSD_TS_CASE(2) CSD_TS_CASE(3) CSD_TS_CASE(4) CSD_TS_CASE(5) CSD_TS_CASE(6)
 #undef CSD_TS_CASE
     default:
       set_error("tapsum: %d output channels not instantiated", cout);
@@ -382,7 +392,7 @@ bool pw16_taps_supported(int cin, int cout, int ns) {
   ConvPlan p;
   memset(&p, 0, sizeof(p));
   p.taps = 1; p.stride = 1; p.C0 = cin; p.Cout = pw16_taps_cout(cout);
-  return cout >= 1 && cout <= 3 && pw16_supported(p, ns) && !getenv("CSD_NO_TAPSUM");
+  return cout >= 1 && cout <= 6 && pw16_supported(p, ns) && !getenv("CSD_NO_TAPSUM");
 }
 
 template <int NS, int MTP, int OCC>

@@ -93,7 +93,7 @@ struct PackedConv {
   bool pw = false;               // ns != 0 and the layer runs on the pointwise fp16 kernel (conv_pw16.hip)
   bool q = false;                // ns != 0 and the layer runs on the quad-wave fp16 kernel (conv_f16_q.hip)
   bool ff = false;               // ns != 0 and the layer runs on the fused-prologue kernel (conv_ff.hip): fp32 sources, no gn_apply16
-  int tap_cout = 0;              // pw and the layer is a 3x3 convolution with tap_cout (<= 3) output channels in its tap-partial form (conv_pw16.hip):
+  int tap_cout = 0;              // pw and the layer is a 3x3 convolution with tap_cout (<= 6) output channels in its tap-partial form (conv_pw16.hip):
                                  // proto is the POINTWISE contraction to 9 * tap_cout partial channels, a 9-tap gather finishes it
   bool up4 = false;              // q and the layer is the nearest-x2 Upsample conv in its phase-decomposed form (4 x 2x2 taps; conv_f16_q.hip UP4)
   struct Src { int param_w, param_b, layout, cout_src, cout_off, cin_src; };
