@@ -137,8 +137,8 @@ int pw16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s);
 bool pw16_taps_supported(int cin, int cout, int ns);
 int pw16_taps_cout(int cout);
 int pw16_pack_weight_taps(const ConvPlan& p, int ns, const float* w, int cout, void* wpack, hipStream_t s);
-int tapsum_launch(const float* part, const float* bias, float* out, int B, int H, int W, int cout, int nchw, float out_scale,
-                  hipStream_t s);
+int tapsum_launch(const float* part, const float* bias, const float* res, float* out, int B, int H, int W, int cout, int nchw,
+                  float out_scale, hipStream_t s);
 // y16 = fp16 split of act(x*scale + shift): hi plane (and lo plane when ns == 2), NHWC halves [B*HW][C0+C1]
 int gn_apply16_launch(const float* src0, const float* src1, int C0, int C1, const float* nscale, const float* nshift,
                       void* hi, void* lo, int B, int HW, int act, hipStream_t s, int f8 = 0);

@@ -318,7 +318,8 @@ int pw16_pack_weight_taps(const ConvPlan& p, int ns, const float* w, int cout, v
 // (One thread per pixel gathering straight from global memory: 27 dword loads with a 112-byte lane stride, 183 us at 160^2, B = 64.)
 template <int CO>
 __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ part, const float* __restrict__ bias,
-                                                     float* __restrict__ out, int H, int W, int cp, int nchw, float out_scale) {
+                                                     const float* __restrict__ res, float* __restrict__ out, int H, int W, int cp,
+                                                     int nchw, float out_scale) {
   extern __shared__ __attribute__((aligned(16))) float ts_tile[];      // [18 * 18][cp]
   const int tid = threadIdx.x;
   const int tx0 = blockIdx.x * 16, ty0 = blockIdx.y * 16;
@@ -355,14 +356,16 @@ __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ p
   }
 #pragma unroll
   for (int c = 0; c < CO; ++c) {
-    const float r = (acc[c] + bias[c]) * out_scale;
+    // ((conv + bias) + residual) * out_scale: the association of the convolution kernels' epilogues (residual: NHWC, CO channels -
+    // the coarser levels' upsampled sum of an NCSN++ output pyramid)
+    const float r = ((acc[c] + bias[c]) + (res ? res[((b * H + y) * W + x) * CO + c] : 0.f)) * out_scale;
     if (nchw) out[((b * CO + c) * H + y) * W + x] = r;
     else out[((b * H + y) * W + x) * CO + c] = r;
   }
 }
 
-int tapsum_launch(const float* part, const float* bias, float* out, int B, int H, int W, int cout, int nchw, float out_scale,
-                  hipStream_t s) {
+int tapsum_launch(const float* part, const float* bias, const float* res, float* out, int B, int H, int W, int cout, int nchw,
+                  float out_scale, hipStream_t s) {
   const int cp = pw16_taps_cout(cout);
   const dim3 grid(cdiv(W, 16), cdiv(H, 16), B), block(256);
   const size_t lds = (size_t)324 * cp * sizeof(float);
@@ -375,7 +378,7 @@ int tapsum_launch(const float* part, const float* bias, float* out, int B, int H
                                         160 * 1024));                                                                               \
       attr_set = true;                                                                                                               \
     }                                                                                                                                \
-    hipLaunchKernelGGL(tapsum_kernel<CO>, grid, block, lds, s, part, bias, out, H, W, cp, nchw, out_scale);                          \
+    hipLaunchKernelGGL(tapsum_kernel<CO>, grid, block, lds, s, part, bias, res, out, H, W, cp, nchw, out_scale);                     \
     break;                                                                                                                           \
   }
     CSD_TS_CASE(1) CSD_TS_CASE(2) CSD_TS_CASE(3) CSD_TS_CASE(4) CSD_TS_CASE(5) CSD_TS_CASE(6)

@@ -734,9 +734,9 @@ static int build_packed_layout(Net& n) {
         ich = m.cout;
       }
       if (is_attn(res)) { if ((rc = attn_layout(nextm()))) return rc; }
-      if (c.progressive == 1) {
+      if (c.progressive == 1) {                  // (the output pyramid's convs: a handful of couts each, like the last layer)
         gn_layout(nextm());
-        if ((rc = conv3_layout(nextm(), ich, true))) return rc;
+        if ((rc = conv3_layout(nextm(), ich, true, /*last=*/true))) return rc;
       }
       if (l != 0) {
         cur_res = res << 1;
@@ -873,7 +873,7 @@ struct Builder {
     const PackedConv& pc = n.pconvs[n.pconv_by_name.at(key)];
     if (pc.tap_cout) {
       // tap-partial form (conv_pw16.hip): pointwise contraction of act(GN(x)) to 9 * cout partial channels, then the 9-tap gather
-      if (!norm || src1 != NONE || stride != 1 || up || pad != 1 || res != NONE || temb_col != NONE) {
+      if (!norm || src1 != NONE || stride != 1 || up || pad != 1 || temb_col != NONE) {
         set_error("tap-partial conv on an unsupported layer"); rc = CSD_ERR_INVALID; return NONE;
       }
       Op o;
@@ -895,7 +895,7 @@ struct Builder {
       pl.ops.back().bytes = (double)B * ih * iw * (o.cp.C0 + o.cp.Cout) * 4.0;
       Op g;
       g.kind = OP_TAPSUM;
-      g.a = part; g.pk1 = pc.b_off;
+      g.a = part; g.pk1 = pc.b_off; g.c = res;
       g.i0 = ih; g.i1 = iw; g.i2 = pc.tap_cout;
       g.fscale = pending_scale;
       pending_scale = 1.f;
@@ -1552,7 +1552,7 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         rc = nearest_up2_nhwc_launch(W(o.a), W(o.out), B, o.i0, o.i0, o.i1, s);
         break;
       case OP_TAPSUM:
-        rc = tapsum_launch(W(o.a), pk + o.pk1, o.out_external ? out : W(o.out), B, o.i0, o.i1, o.i2, o.out_external, o.fscale, s);
+        rc = tapsum_launch(W(o.a), pk + o.pk1, W(o.c), o.out_external ? out : W(o.out), B, o.i0, o.i1, o.i2, o.out_external, o.fscale, s);
         break;
       default:
         set_error("unet: unknown op");
