@@ -1,6 +1,5 @@
-// conv_ff.h - definitions shared by the two schedules of the fused-prologue block convolution (conv_ff.hip: 4-wave workgroups, two per
-// CU; conv_ffp.hip: persistent 8-wave producer / consumer workgroups, one per CU): tile geometry, LDS patch layout, ring
-// configuration, kernel arguments, the LDS hand-over barrier.
+// conv_ff.h - definitions of the fused-prologue block convolution (conv_ff.hip: 4-wave workgroups, two per CU): tile geometry,
+// LDS patch layout, ring configuration, kernel arguments, the LDS hand-over barrier.
 #pragma once
 #include <stdlib.h>
 
@@ -12,6 +11,7 @@ namespace csd {
 
 typedef unsigned int uint4f __attribute__((ext_vector_type(4)));
 typedef int int8v __attribute__((ext_vector_type(8)));
+typedef short short2v __attribute__((ext_vector_type(2)));
 
 #define FF_THREADS 256
 #define FF_TILE 16
@@ -66,8 +66,5 @@ struct FFCfg {
   static constexpr int PPJ = LOADERS / G4;                    // patch pixels between a thread's consecutive slots
   static constexpr size_t LDS = 2 * (size_t)FF_PATCH_BYTES + (size_t)R * GB + 2 * FF_NPATCH * sizeof(int);
 };
-
-// conv_ffp.hip: the persistent producer / consumer schedule (opt-in experiment: CSD_FF_PERSISTENT)
-int convffp_launch(const ConvFFArgs& k, int ns, hipStream_t s);
 
 }  // namespace csd

@@ -38,7 +38,23 @@ namespace csd {
 // network error 2e-5 norm-wise / 8e-5 element-wise (oracle/fp8_correction_study.py) against 1.2e-6 / 4.5e-6 of the full split.
 // LDS formats: pixel record [hi fp16 x16 | lo*2^11 e4m3 x16 | hi e4m3 x16] (64 B, as NS = 2); weight step [cout tile][plane]
 // with plane 0 = fp16 A fragments, plane 1 = [hi e4m3 | lo*2^11 e4m3][cout row][16 channels] (16 B per row and half).
-template <int NS, int NT, bool F8>
+// two f32 -> one dword of two fp16 (round to nearest even: v_cvt_pk_f16_f32)
+__device__ __forceinline__ int ff_pack_f16(float a, float b) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(int, __builtin_convertvector(f2{a, b}, h2));
+}
+// lo = v - (float)half: ONE v_fma_mix_f32 that reads the fp16 half of the packed dword directly (exact: fp32 fma)
+template <bool HIGH>
+__device__ __forceinline__ float ff_lo(int hp, float v) {
+  float r;
+  if constexpr (HIGH) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(v));
+  else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(v));
+  return r;
+}
+
+// NORM: the operand is act(GroupNorm(x)) (per-(sample, channel) scale / shift + SiLU); false: the raw tensor
+template <int NS, int NT, bool F8, bool NORM>
 __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __restrict__ g_wpack, const ConvFFArgs k) {
   static_assert(!F8 || NS == 2, "the fp8-correction form shares the two-plane layouts");
   using C = FFCfg<NS, NT>;
@@ -71,6 +87,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kh = lane >> 5, p32 = lane & 31;
+  if constexpr (F8) __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);      // MODE.FP16_OVFL = 1: fp8 (and fp16) conversions saturate instead of NaN / inf
 #ifdef CSD_FF_TUNE
 #ifdef CSD_FF_CONST_ABL
 #define FF_ABL(bit) ((CSD_FF_CONST_ABL) & (bit))      // compile-time ablation: the tested code is really gone
@@ -103,7 +120,6 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
   const int tin = tile - b * k_tpi;
   const int ty0 = (tin / k_tiles_x) * FF_TILE, tx0 = (tin - (tin / k_tiles_x) * k_tiles_x) * FF_TILE;
   const int Cin = kC0 + kC1;
-  const bool norm = a_nscale != nullptr;
 
   // ---- loader state (waves 1-3): slot j of thread t = 4-channel group (t % G4) of patch pixel j*PPJ + t/G4 ----
   const int lt = tid - 64 * NDMA;
@@ -131,58 +147,66 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
       }
       pf[j] = gload4f(src + (size_t)(sp >= 0 ? sp : 0) * Cs);
     }
-    if (norm) {
+    if constexpr (NORM) {
       n_sc = gload4f(a_nscale + (size_t)b * Cin + cb + lg * 4);
       n_sh = gload4f(a_nshift + (size_t)b * Cin + cb + lg * 4);
     }
   };
-  // convert + write the prefetched stage: the arithmetic of gn_apply16_kernel with the SiLU inline (the host routes
-  // other activations - none of the reference's configs uses one - to the older schedules)
+  // SiLU in the exp2 domain: with u = -log2(e) (x s + t) the activated value is act = -ln2 * u / (1 + 2^u).  The staged operand is
+  // a = u / (1 + 2^u) (one v_exp_f32 + one v_rcp_f32, no argument scaling); the factor -ln2 is linear and rides on the accumulators:
+  // they start at (bias + temb + residual) * 2^8 / -ln2 and the epilogue's one multiply restores it (acc_in / acc_out).
+  constexpr float FF_NLOG2E = -1.4426950408889634f;
+  constexpr float acc_in = NORM ? C16_WSCALE * FF_NLOG2E : C16_WSCALE;         // = 2^8 / -ln2
+  constexpr float acc_out = NORM ? -0.6931471805599453f / C16_WSCALE : 1.0f / C16_WSCALE;
+  // convert + write the prefetched stage: GroupNorm affine + SiLU + split, ~40 vector instructions per 4 channels (every one of
+  // them is matrix-pipe time on this chip: tools/mfma_valu_overlap.hip, tools/mfma_valu_prio.hip - a partner wave's VALU stream
+  // overlaps a dense MFMA stream by 15-20 % whatever the age / s_setprio of the two waves).  Per element: fma, v_exp, add, v_rcp,
+  // mul (SiLU), select (zero padding of the ACTIVATED tensor), half a packed f32 -> f16 conversion, ONE mixed-precision fma for
+  // lo = v - hi (reads the fp16 half directly), and in the F8 form half an e4m3 conversion each for lo * 2^11 and for v.
+  // (the host routes activations other than SiLU - none of the reference's configs uses one - to the older schedules)
   auto store_patch = [&](char* buf) __attribute__((always_inline)) {
+    float4 m_sc, m_sh;
+    if constexpr (NORM) {
+      m_sc = make_float4(n_sc.x * FF_NLOG2E, n_sc.y * FF_NLOG2E, n_sc.z * FF_NLOG2E, n_sc.w * FF_NLOG2E);
+      m_sh = make_float4(n_sh.x * FF_NLOG2E, n_sh.y * FF_NLOG2E, n_sh.z * FF_NLOG2E, n_sh.w * FF_NLOG2E);
+    }
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
-      const int pixr = j * PPJ + lp0;
-      const int pix = min(pixr, FF_NPATCH - 1);
-      const bool in = stab[pix] >= 0;
+      // (slots past the patch - possible in the last j only - repeat patch pixel 323: same data to the same address)
+      const int pix = (j * PPJ + PPJ - 1 < FF_NPATCH) ? j * PPJ + lp0 : min(j * PPJ + lp0, FF_NPATCH - 1);
+      const int dt = dtab[pix];                      // LDS byte offset of the pixel record; bit 31: the pixel lies outside the image
+      const bool in = dt >= 0;
       float h[4] = {pf[j].x, pf[j].y, pf[j].z, pf[j].w};
-      if (norm) {
-        h[0] = h[0] * n_sc.x + n_sh.x; h[1] = h[1] * n_sc.y + n_sh.y;
-        h[2] = h[2] * n_sc.z + n_sh.z; h[3] = h[3] * n_sc.w + n_sh.w;
+      if constexpr (NORM) {
+        h[0] = h[0] * m_sc.x + m_sh.x; h[1] = h[1] * m_sc.y + m_sh.y;
+        h[2] = h[2] * m_sc.z + m_sh.z; h[3] = h[3] * m_sc.w + m_sh.w;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) h[q] = h[q] * __builtin_amdgcn_rcpf(1.0f + __expf(-h[q]));      // (v_rcp_f32: 1 ulp)
+        for (int q = 0; q < 4; ++q) h[q] = h[q] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(h[q]));      // (v_exp_f32, v_rcp_f32: 1 ulp)
       }
-      // VALU instructions are NOT free next to MFMAs on this chip (tools/mfma_valu_overlap.hip: a second wave's VALU stream overlaps a
-      // wave's MFMA stream by ~15 %): every instruction here is matrix-pipe time.  hi by packed conversion; lo = v - hi as ONE mixed-
-      // precision fma on the fp16 value (no conversion back); the e4m3 "hi" operand is taken from v itself (3 mantissa bits either way)
-      half4 hi, lo;
-      float lof[4], hif[4];
+      float v[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float v = in ? h[q] : 0.f;             // padding is applied to the ACTIVATED tensor: exactly 0
-        hi[q] = (_Float16)v;
+      for (int q = 0; q < 4; ++q) v[q] = in ? h[q] : 0.f;            // padding is applied to the ACTIVATED tensor: exactly 0
+      char* const rec = buf + (dt & 0x7fffffff);
+      const int hp0 = ff_pack_f16(v[0], v[1]), hp1 = ff_pack_f16(v[2], v[3]);
+      *reinterpret_cast<int2*>(rec + lg * 8) = make_int2(hp0, hp1);
+      if constexpr (NS == 2) {
+        const float l0 = ff_lo<false>(hp0, v[0]), l1 = ff_lo<true>(hp0, v[1]), l2 = ff_lo<false>(hp1, v[2]), l3 = ff_lo<true>(hp1, v[3]);
         if constexpr (F8) {
-          // e4m3 saturates at 448 and turns larger inputs into NaN: clamp (|lo| * 2^11 <= |hi| by construction)
-          hif[q] = __builtin_amdgcn_fmed3f(v, -448.f, 448.f);
-          lof[q] = __builtin_amdgcn_fmed3f(__builtin_fmaf((float)hi[q], -2048.f, v * 2048.f), -448.f, 448.f);
+          // e4m3 has no infinity: beyond 448 a conversion produces NaN - unless MODE.FP16_OVFL is set (kernel entry), which makes
+          // every fp8 conversion saturate at +-448 (tools/cvt_probe.hip): no clamp instructions.  The 2^11 scaling of the lo part
+          // is the scale operand of v_cvt_scalef32_pk_fp8_f32 (it divides by the scale); the e4m3 "hi" operand is taken from v
+          // itself (3 mantissa bits either way).  The conversions' pass-through operand is dead data (both halves are written).
+          short2v l8 = __builtin_bit_cast(short2v, __float_as_int(h[0]));
+          l8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l8, l0, l1, 1.0f / 2048.0f, false);
+          l8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l8, l2, l3, 1.0f / 2048.0f, true);
+          int h8 = __float_as_int(h[1]);
+          h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], h8, false);
+          h8 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], h8, true);
+          *reinterpret_cast<int*>(rec + 32 + lg * 4) = __builtin_bit_cast(int, l8);
+          *reinterpret_cast<int*>(rec + 48 + lg * 4) = h8;
         } else {
-          lo[q] = (_Float16)__builtin_fmaf((float)hi[q], -1.0f, v);
+          *reinterpret_cast<int2*>(rec + 32 + lg * 8) = make_int2(ff_pack_f16(l0, l1), ff_pack_f16(l2, l3));
         }
-      }
-      // (slots past the patch - possible in the last j only - land in the 16 pad bytes at the end of patch row 17)
-      const bool real = (j * PPJ + PPJ - 1 < FF_NPATCH) || pixr < FF_NPATCH;
-      char* dst = buf + (real ? dtab[pix] + lg * 8 : FF_PATCH_BYTES - 16);
-      *reinterpret_cast<half4*>(dst) = hi;
-      if constexpr (F8) {
-        int l8 = 0, h8 = 0;
-        l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lof[0], lof[1], l8, false);
-        l8 = __builtin_amdgcn_cvt_pk_fp8_f32(lof[2], lof[3], l8, true);
-        h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hif[0], hif[1], h8, false);
-        h8 = __builtin_amdgcn_cvt_pk_fp8_f32(hif[2], hif[3], h8, true);
-        char* d8 = buf + (real ? dtab[pix] + 32 + lg * 4 : FF_PATCH_BYTES - 8);
-        *reinterpret_cast<int*>(d8) = l8;
-        *reinterpret_cast<int*>(d8 + (real ? 16 : 4)) = h8;
-      } else if (NS == 2) {
-        *reinterpret_cast<half4*>(dst + (real ? 32 : 8)) = lo;
       }
     }
   };
@@ -215,7 +239,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
     const int pr = pix / FF_PW, pc = pix - pr * FF_PW;
     const int y = ty0 - 1 + pr, x = tx0 - 1 + pc;
     stab[pix] = (y >= 0 && y < kH && x >= 0 && x < kW) ? y * kW + x : -1;      // zero padding outside THIS sample
-    dtab[pix] = pr * FF_RS + pc * FF_PSB;
+    dtab[pix] = (pr * FF_RS + pc * FF_PSB) | (stab[pix] < 0 ? (int)0x80000000 : 0);
   }
 
 
@@ -244,8 +268,8 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          acc[mt][nt][q * 4 + 0] = bv[nt * 4 + q].x * C16_WSCALE; acc[mt][nt][q * 4 + 1] = bv[nt * 4 + q].y * C16_WSCALE;
-          acc[mt][nt][q * 4 + 2] = bv[nt * 4 + q].z * C16_WSCALE; acc[mt][nt][q * 4 + 3] = bv[nt * 4 + q].w * C16_WSCALE;
+          acc[mt][nt][q * 4 + 0] = bv[nt * 4 + q].x * acc_in; acc[mt][nt][q * 4 + 1] = bv[nt * 4 + q].y * acc_in;
+          acc[mt][nt][q * 4 + 2] = bv[nt * 4 + q].z * acc_in; acc[mt][nt][q * 4 + 3] = bv[nt * 4 + q].w * acc_in;
         }
   }
   // the residual (the block's shortcut) joins the accumulators HERE, not in the epilogue: its loads travel under the first
@@ -270,10 +294,10 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          acc[mt][nt][q * 4 + 0] += __uint_as_float(rv[nt][q].x) * C16_WSCALE;
-          acc[mt][nt][q * 4 + 1] += __uint_as_float(rv[nt][q].y) * C16_WSCALE;
-          acc[mt][nt][q * 4 + 2] += __uint_as_float(rv[nt][q].z) * C16_WSCALE;
-          acc[mt][nt][q * 4 + 3] += __uint_as_float(rv[nt][q].w) * C16_WSCALE;
+          acc[mt][nt][q * 4 + 0] += __uint_as_float(rv[nt][q].x) * acc_in;
+          acc[mt][nt][q * 4 + 1] += __uint_as_float(rv[nt][q].y) * acc_in;
+          acc[mt][nt][q * 4 + 2] += __uint_as_float(rv[nt][q].z) * acc_in;
+          acc[mt][nt][q * 4 + 3] += __uint_as_float(rv[nt][q].w) * acc_in;
         }
     }
   }
@@ -414,7 +438,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
   }
 
   // ---- epilogue ----
-  const float wunscale = 1.0f / C16_WSCALE;
+  const float wunscale = acc_out;
   const __amdgpu_buffer_rsrc_t out_r =
       __builtin_amdgcn_make_buffer_rsrc(a_out + tile_pix * a_out_stride + a_out_coff, 0, OOB, RSRC_FLAGS);
   if (FF_ABL(16)) return;
@@ -607,9 +631,9 @@ int convff_plan_tiles(ConvPlan* p, int ns) {
   return CSD_OK;
 }
 
-template <int NS, int NT, bool F8>
+template <int NS, int NT, bool F8, bool NORM>
 static int launch_ff(const ConvFFArgs& k, hipStream_t s) {
-  auto kern = conv_ff_kernel<NS, NT, F8>;
+  auto kern = conv_ff_kernel<NS, NT, F8, NORM>;
   static bool attr_set = false;
   if (!attr_set) {
     CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -644,18 +668,14 @@ int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
   k.abl = getenv("CSD_FF_ABL") ? atoi(getenv("CSD_FF_ABL")) : 0;
   k.a.dbg = (k.abl & 128) ? g_ff_dbg : nullptr;
   const int nt = ff_nt(p.Cout);
-  // the persistent producer / consumer schedule (conv_ffp.hip) is an opt-in experiment: measured 9-15 % SLOWER than this one
-  // (its consumer waves have nobody to cover their epilogue and fragment-read latency)
-  static const bool persistent = getenv("CSD_FF_PERSISTENT") != nullptr;
-  if (persistent) return convffp_launch(k, ns, s);
-  if (nt == 2) {
-    if (ns == 1) return launch_ff<1, 2, false>(k, s);
-    if (ns == 3) return launch_ff<2, 2, true>(k, s);
-    return launch_ff<2, 2, false>(k, s);
-  }
-  if (ns == 1) return launch_ff<1, 3, false>(k, s);
-  if (ns == 3) return launch_ff<2, 3, true>(k, s);
-  return launch_ff<2, 3, false>(k, s);
+  const bool norm = a.nscale != nullptr;
+#define FF_DISPATCH(NT_)                                                                                            \
+  if (ns == 1) return norm ? launch_ff<1, NT_, false, true>(k, s) : launch_ff<1, NT_, false, false>(k, s);       \
+  if (ns == 3) return norm ? launch_ff<2, NT_, true, true>(k, s) : launch_ff<2, NT_, true, false>(k, s);         \
+  return norm ? launch_ff<2, NT_, false, true>(k, s) : launch_ff<2, NT_, false, false>(k, s);
+  if (nt == 2) { FF_DISPATCH(2) }
+  FF_DISPATCH(3)
+#undef FF_DISPATCH
 }
 
 }  // namespace csd
