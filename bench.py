@@ -151,7 +151,11 @@ def main():
         sys.exit('bench.py needs an MI355X: the HIP path has no CPU fallback')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    # one process per GPU under torch.distributed.run: the RCCL process group exists whenever the launcher set RANK - also for a
+    # world of ONE (`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`), so that the barrier / all_gather / MAX-reduce
+    # branch below is the SAME code at N = 1 and at N = 8
+    grouped = 'RANK' in os.environ and 'MASTER_PORT' in os.environ
+    if grouped:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
@@ -197,7 +201,7 @@ def main():
                                             ctypes.byref(p), _lib.current_stream(dev)), 'pc_sample')
 
     def barrier():
-        if world > 1:
+        if grouped:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -214,7 +218,7 @@ def main():
         _lib.profile_start()
     t0 = time.perf_counter()
     run_steps(W, K, 2000 + rank)
-    if world > 1:   # the one collective of the sampling path: gather the finished samples
+    if grouped:     # the one collective of the sampling path: gather the finished samples
         out = torch.empty((world * B, 3, 160, 160), dtype=torch.float32, device=dev)
         torch.distributed.all_gather_into_tensor(out, x)
     barrier()
@@ -234,7 +238,7 @@ def main():
         prof_all = _lib.profile_stop()
         prof_all = {k: dict(v, ms=v['ms'] * K / n2, launches=v['launches'] * K // n2, flops=v['flops'] * K / n2,
                             bytes=v['bytes'] * K / n2) for k, v in prof_all.items()}
-    if world > 1:
+    if grouped:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
@@ -373,7 +377,8 @@ def main():
             except Exception as e:
                 res['side_benches'] = {'error': str(e)[:200]}
         print(json.dumps(res))
-    if world > 1:
+    if grouped:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

@@ -40,7 +40,8 @@ class PCParams(ctypes.Structure):
                 ('denoise', ctypes.c_int32), ('noise_tape', ctypes.c_void_p), ('seed', ctypes.c_uint64),
                 ('record', ctypes.c_void_p), ('predictor', ctypes.c_int32), ('corrector', ctypes.c_int32),
                 ('pred_coef', ctypes.POINTER(ctypes.c_float)), ('corr_coef', ctypes.POINTER(ctypes.c_float)),
-                ('path_coef', ctypes.POINTER(ctypes.c_float)), ('path_std0', ctypes.c_float)]
+                ('path_coef', ctypes.POINTER(ctypes.c_float)), ('path_std0', ctypes.c_float),
+                ('corr_alpha', ctypes.POINTER(ctypes.c_float))]
 
 
 def build(verbose=False):
@@ -87,7 +88,7 @@ SIGNATURES = {
     'csd_unet_train_forward': (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _i, _f, ctypes.c_uint64, ctypes.c_uint64, _vp]),
     'csd_unet_backward': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _i, _vp]),
     'csd_update_scratch_bytes': (_sz, [_i]),
-    'csd_langevin_step': (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i64, _vp, _vp]),
+    'csd_langevin_step': (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _i64, _vp, _vp]),
     'csd_reverse_diffusion_step': (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i64, _vp]),
     'csd_row_norms': (_i, [_vp, _vp, _i, _i64, _vp]),
     'csd_affine_noise_step': (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _i64, _vp]),

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(float* __restrict_
                                                               const float* __restrict__ net,
                                                               int64_t net_stride, const float* __restrict__ z,
                                                               const double* __restrict__ partial, int nchunk,
-                                                              float std, float snr, int B, int64_t per,
+                                                              float std, float snr, float alpha, int B, int64_t per,
                                                               size_t total) {
   __shared__ float s_step;
   if (threadIdx.x < 64) {
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(float* __restrict_
     if (threadIdx.x == 0) {
       const float gbar = (float)(g / B), nbar = (float)(n / B);
       const float r = snr * nbar / gbar;
-      s_step = r * r * 2.f;          // (snr*nbar/gbar)**2 * 2 * alpha, alpha = 1
+      s_step = r * r * 2.f * alpha;  // (snr*nbar/gbar)**2 * 2 * alpha; alpha = 1 for the VE SDEs, sde.alphas[timestep] for VP / subVP
     }
   }
   __syncthreads();
@@ -131,10 +131,10 @@ __global__ __launch_bounds__(256) void langevin_update_global_kernel(float* __re
                                                                      const float* __restrict__ net, int64_t net_stride,
                                                                      const float* __restrict__ z,
                                                                      const float* __restrict__ sums, int Bg, float std,
-                                                                     float snr, int64_t per, size_t total) {
+                                                                     float snr, float alpha, int64_t per, size_t total) {
   const float gbar = sums[0] / (float)Bg, nbar = sums[1] / (float)Bg;
   const float r = snr * nbar / gbar;
-  const float step = r * r * 2.f;
+  const float step = r * r * 2.f * alpha;
   const float nz = sqrtf(step * 2.f);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t b = i / (size_t)per;
@@ -255,11 +255,11 @@ int sumsq_rows_launch(const float* net, int64_t net_stride, const float* z, doub
 }
 
 int langevin_update_launch(float* x, float* x_mean, const float* net, int64_t net_stride, const float* z,
-                           const double* partial, int nchunk, float std, float snr, int B, int64_t per,
+                           const double* partial, int nchunk, float std, float snr, float alpha, int B, int64_t per,
                            hipStream_t s) {
   const size_t total = (size_t)B * per;
   hipLaunchKernelGGL(langevin_update_kernel, dim3(ew_grid(total)), dim3(256), 0, s, x, x_mean, net, net_stride, z,
-                     partial, nchunk, std, snr, B, per, total);
+                     partial, nchunk, std, snr, alpha, B, per, total);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
@@ -271,10 +271,11 @@ int norm_sums_launch(const double* partial, int nchunk, float std, int B, float*
 }
 
 int langevin_update_global_launch(float* x, float* x_mean, const float* net, int64_t net_stride, const float* z,
-                                  const float* sums, int Bg, float std, float snr, int B, int64_t per, hipStream_t s) {
+                                  const float* sums, int Bg, float std, float snr, float alpha, int B, int64_t per,
+                                  hipStream_t s) {
   const size_t total = (size_t)B * per;
   hipLaunchKernelGGL(langevin_update_global_kernel, dim3(ew_grid(total)), dim3(256), 0, s, x, x_mean, net, net_stride, z,
-                     sums, Bg, std, snr, per, total);
+                     sums, Bg, std, snr, alpha, per, total);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
@@ -361,13 +362,13 @@ using namespace csd;
 
 extern "C" size_t csd_update_scratch_bytes(int B) { return (size_t)B * 64 * 2 * sizeof(double); }
 
-extern "C" int csd_langevin_step(float* x, float* x_mean, const float* net, const float* z, float std, float snr,
+extern "C" int csd_langevin_step(float* x, float* x_mean, const float* net, const float* z, float std, float snr, float alpha,
                                  int B, int64_t per_sample, void* scratch, void* stream) {
-  CSD_REQUIRE(B > 0 && per_sample > 0 && scratch, "langevin_step: bad arguments");
+  CSD_REQUIRE(B > 0 && per_sample > 0 && scratch && alpha > 0.f, "langevin_step: bad arguments");
   const int nchunk = sumsq_nchunk(per_sample);
   int rc = sumsq_rows_launch(net, per_sample, z, (double*)scratch, B, per_sample, nchunk, (hipStream_t)stream);
   if (rc) return rc;
-  return langevin_update_launch(x, x_mean, net, per_sample, z, (const double*)scratch, nchunk, std, snr, B, per_sample,
+  return langevin_update_launch(x, x_mean, net, per_sample, z, (const double*)scratch, nchunk, std, snr, alpha, B, per_sample,
                                 (hipStream_t)stream);
 }
 

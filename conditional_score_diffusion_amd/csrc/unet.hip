@@ -1923,10 +1923,11 @@ static int pc_phase(const PCCtx& c, int i, int phase, int part, float* sums_out,
       const float* co = (phase == 0 ? p->corr_coef : p->pred_coef) + (size_t)i * 3;
       rc = affine_net_update_launch(c.x, c.x_mean, c.net_out, c.net_stride, zp, p->std_x[i], co[0], co[1], co[2], c.B, c.per, c.s);
     } else if (phase == 0) {
+      const float alpha = p->corr_alpha ? p->corr_alpha[i] : 1.0f;      // sde.alphas[timestep] (VP / subVP); 1 for the VE SDEs
       rc = sums_in ? langevin_update_global_launch(c.x, c.x_mean, c.net_out, c.net_stride, zp, sums_in, Bg, p->std_x[i], p->snr,
-                                                   c.B, c.per, c.s)
+                                                   alpha, c.B, c.per, c.s)
                    : langevin_update_launch(c.x, c.x_mean, c.net_out, c.net_stride, zp, c.partial, c.nchunk, p->std_x[i],
-                                            p->snr, c.B, c.per, c.s);
+                                            p->snr, alpha, c.B, c.per, c.s);
     } else {
       rc = reverse_diffusion_update_launch(c.x, c.x_mean, c.net_out, c.net_stride, zp, p->std_x[i], p->G[i], c.B, c.per, c.s);
     }

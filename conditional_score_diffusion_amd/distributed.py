@@ -18,12 +18,17 @@ import torch
 import torch.distributed as dist
 
 
+def shard_size(n_total, world):
+    """Rows of a full shard: ceil(n_total / world).  The last shards may be shorter (or empty) when the batch does not divide."""
+    return -(-int(n_total) // int(world))
+
+
 def shard_bounds(n_total, rank, world):
-    """Contiguous equal shards; n_total must divide evenly (all_gather needs equal shapes)."""
-    if n_total % world != 0:
-        raise ValueError('global batch %d is not divisible by world size %d' % (n_total, world))
-    per = n_total // world
-    return rank * per, (rank + 1) * per
+    """Contiguous shards of ``shard_size`` rows; a global batch that does not divide evenly (configs[3]: 50 images over 8 GPUs ->
+    7,7,7,7,7,7,7,1) leaves the last shard(s) ragged or empty.  ``sample_sharded`` pads those to the common size for the gather."""
+    per = shard_size(n_total, world)
+    lo = min(rank * per, n_total)
+    return lo, min(lo + per, n_total)
 
 
 def rank_seed(seed, rank):
@@ -31,34 +36,57 @@ def rank_seed(seed, rank):
     return (int(seed) * 1000003 + 7919 * int(rank)) & 0x7FFFFFFFFFFFFFFF
 
 
-def sample_sharded(sampler, model, y_global=None, n_total=None, seed=None, group=None, global_norm=False, **sampler_kw):
+def sample_sharded(sampler, model, y_global=None, n_total=None, seed=None, group=None, global_norm=False, pad_shape=None,
+                   **sampler_kw):
     """Run ``sampler`` on this rank's shard and all-gather the samples.
 
     sampler : ``fn(model, y_shard, seed=..., **kw) -> (x, info)`` for conditional sampling (as returned
               by ``get_conditional_sampling_fn``) or ``fn(model, seed=..., **kw)`` when ``y_global`` is None
               (unconditional; the sampler's ``shape`` must already be the per-rank shape).
+    pad_shape : (C, H, W) of a sample - only needed when a rank can end up with an EMPTY shard (fewer images than ranks).
     Returns (samples of the GLOBAL batch on every rank, info of the local shard).
     """
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    grouped = dist.is_initialized()       # a process group exists: EVERY collective of the path runs through it, also at world size 1
+    world = dist.get_world_size(group) if grouped else 1
+    rank = dist.get_rank(group) if grouped else 0
     if seed is None:        # a fresh base key per call from torch's generator (rank_seed keeps the ranks' streams distinct)
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
-    if global_norm and world > 1:
-        n_global = y_global.shape[0] if y_global is not None else n_total
+    n_global = y_global.shape[0] if y_global is not None else n_total
+    if global_norm and grouped:
         if not n_global:
             raise ValueError('global-norm mode needs the global batch size (y_global or n_total)')
+        lo_last, hi_last = shard_bounds(n_global, world - 1, world)
+        if hi_last <= lo_last:
+            raise ValueError('global-norm mode: %d images leave a rank of %d without work (it would miss the per-step all-reduce)'
+                             % (n_global, world))
         sampler_kw['global_norm'] = (lambda sums: dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group), int(n_global))
     if y_global is not None:
-        lo, hi = shard_bounds(y_global.shape[0], rank, world)
-        x_local, info = sampler(model, y_global[lo:hi].contiguous(), seed=rank_seed(seed, rank), **sampler_kw)
+        lo, hi = shard_bounds(n_global, rank, world)
+        if hi > lo:
+            x_local, info = sampler(model, y_global[lo:hi].contiguous(), seed=rank_seed(seed, rank), **sampler_kw)
+        else:               # an empty ragged shard: nothing to sample, an all-zero block for the gather
+            x_local, info = None, {}
     else:
+        lo, hi = 0, None
         x_local, info = sampler(model, seed=rank_seed(seed, rank), **sampler_kw)
-    if world == 1:
+    if not grouped:
         return x_local, info
+    if y_global is not None:
+        per = shard_size(n_global, world)
+        if x_local is None or x_local.shape[0] < per:           # pad the ragged shard to the common gather size
+            shape_tail = tuple(x_local.shape[1:]) if x_local is not None else tuple(pad_shape or ())
+            if x_local is None and not shape_tail:
+                raise ValueError('an empty shard needs pad_shape=(C, H, W) to take part in the gather')
+            pad = torch.zeros((per,) + shape_tail, dtype=torch.float32, device=y_global.device)
+            if x_local is not None:
+                pad[:x_local.shape[0]] = x_local
+            x_local = pad
     x_local = x_local.contiguous()
     out = torch.empty((world * x_local.shape[0],) + tuple(x_local.shape[1:]), dtype=x_local.dtype,
                       device=x_local.device)
     dist.all_gather_into_tensor(out, x_local, group=group)      # the single collective of the path
+    if y_global is not None and out.shape[0] != n_global:       # drop the padding rows of the ragged tail
+        out = out[:n_global]
     return out, info
 
 
@@ -82,7 +110,8 @@ class GradSync:
 
     def __init__(self, flat, group=None, bucket_bytes=32 << 20):
         self.flat, self.group = flat, group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.grouped = dist.is_initialized()      # with a process group the reduction runs through it, also at world size 1
+        self.world = dist.get_world_size(group) if self.grouped else 1
         per = max(1, bucket_bytes // 4)
         self.buckets = []           # (lo, hi, [param indices])
         lo, idxs = 0, []
@@ -99,11 +128,15 @@ class GradSync:
         self._pending = [len(b[2]) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._handles = []
-        if self.world > 1:
+        if self.grouped:
             for i, p in enumerate(flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
 
-    def scale_loss(self, loss):
+    def scale_loss(self, loss, local_n=None, global_n=None):
+        """The summed gradients must be the GLOBAL-batch mean: equal shards -> loss / world; ragged shards (a global batch that does
+        not divide, ``shard_bounds``) -> the rank's mean weighted by its share ``local_n / global_n`` of the images."""
+        if local_n is not None and global_n:
+            return loss * (float(local_n) / float(global_n))
         return loss if self.world == 1 else loss / self.world
 
     def _make_hook(self, i):
@@ -121,7 +154,7 @@ class GradSync:
 
     def finish(self):
         """Call after ``backward``: every bucket reduced, the flat gradient holds the global mean."""
-        if self.world > 1:
+        if self.grouped:
             for b in range(len(self.buckets)):
                 if not self._launched[b]:
                     self._launch(b)

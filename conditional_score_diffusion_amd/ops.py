@@ -244,13 +244,14 @@ def scale_rows(x, scale, divide=False):
     return out
 
 
-def langevin_step(x, net, z, std, snr):
-    """In-place Langevin corrector update (sampling/correctors.py:88-108); returns (x, x_mean)."""
+def langevin_step(x, net, z, std, snr, alpha=1.0):
+    """In-place Langevin corrector update (sampling/correctors.py:51-78,88-108); ``alpha`` = sde.alphas[timestep] for the VP / subVP
+    SDEs, 1 for the VE SDEs; returns (x, x_mean)."""
     x, net, z = _c(x, 'x'), _c(net, 'net'), _c(z, 'z')
     B = x.shape[0]
     x_mean = torch.empty_like(x)
     sc = _scratch(lib().csd_update_scratch_bytes(B), x.device)
-    check(lib().csd_langevin_step(ptr(x), ptr(x_mean), ptr(net), ptr(z), float(std), float(snr), B,
+    check(lib().csd_langevin_step(ptr(x), ptr(x_mean), ptr(net), ptr(z), float(std), float(snr), float(alpha), B,
                                   x.numel() // B, ptr(sc), current_stream(x.device)), 'langevin_step')
     return x, x_mean
 

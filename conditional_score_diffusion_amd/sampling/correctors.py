@@ -42,17 +42,24 @@ class Corrector(abc.ABC):
         """-> (x, x_mean)"""
 
 
-def _langevin(sde, score_of, x, snr, n_steps):
-    """n_steps Langevin updates with the batch-mean step size (sampling/correctors.py:100-106)."""
+def _alpha(sde, t):
+    """sampling/correctors.py:63-67,94-98: alphas[timestep] for the VP / subVP SDEs, 1 for the VE SDEs.  One host scalar per call:
+    the samplers pass the same time for every sample of the batch (sampling/conditional.py:206, unconditional.py:211)."""
     if isinstance(sde, (sde_lib.VPSDE, sde_lib.cVPSDE, sde_lib.subVPSDE)):
-        raise NotImplementedError('the HIP Langevin step covers the VE SDEs (alpha = 1); got %s'
-                                  % sde.__class__.__name__)
+        timestep = (t[:1].detach().float().cpu() * (sde.N - 1) / sde.T).long()
+        return float(sde.alphas[timestep])
+    return 1.0
+
+
+def _langevin(sde, score_of, x, snr, n_steps, t):
+    """n_steps Langevin updates with the batch-mean step size (sampling/correctors.py:69-76,100-106)."""
+    alpha = _alpha(sde, t)
     x = x.clone()
     x_mean = x
     for _ in range(n_steps):
         grad = score_of(x)
         noise = torch.randn_like(x)
-        x, x_mean = ops.langevin_step(x, grad, noise, 1.0, snr)
+        x, x_mean = ops.langevin_step(x, grad, noise, 1.0, snr, alpha)
     return x, x_mean
 
 
@@ -64,7 +71,7 @@ class LangevinCorrector(Corrector):
             raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
 
     def update_fn(self, x, t):
-        return _langevin(self.sde, lambda v: self.score_fn(v, t), x, self.snr, self.n_steps)
+        return _langevin(self.sde, lambda v: self.score_fn(v, t), x, self.snr, self.n_steps, t)
 
 
 @register_corrector(name='conditional_langevin')
@@ -75,7 +82,7 @@ class conditionalLangevinCorrector(Corrector):
             raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
 
     def update_fn(self, x, y, t):
-        return _langevin(self.sde, lambda v: self.score_fn(v, y, t), x, self.snr, self.n_steps)
+        return _langevin(self.sde, lambda v: self.score_fn(v, y, t), x, self.snr, self.n_steps, t)
 
 
 @register_corrector(name='none')
@@ -96,13 +103,12 @@ class conditionalNoneCorrector(Corrector):
         return x, x
 
 
-def _langevin_global(sde, score_of, x, snr, n_steps, group=None):
+def _langevin_global(sde, score_of, x, snr, n_steps, t=None, group=None):
     """Langevin corrector whose batch-mean norms run over the GLOBAL batch of a sharded run ("global-norm"
     exactness mode): per-sample norms on the device, ONE all-reduce of two fp32 sums per corrector step, then the
     same update as sampling/correctors.py:100-106.  Without an initialised process group it equals ``langevin``."""
     import torch.distributed as dist
-    if isinstance(sde, (sde_lib.VPSDE, sde_lib.cVPSDE, sde_lib.subVPSDE)):
-        raise NotImplementedError('the HIP Langevin step covers the VE SDEs (alpha = 1); got %s' % sde.__class__.__name__)
+    alpha = _alpha(sde, t) if t is not None else 1.0
     x = x.clone()
     x_mean = x
     for _ in range(n_steps):
@@ -110,10 +116,10 @@ def _langevin_global(sde, score_of, x, snr, n_steps, group=None):
         noise = torch.randn_like(x)
         sums = torch.stack([ops.row_norms(grad).sum(), ops.row_norms(noise).sum(),
                             torch.tensor(float(x.shape[0]), device=x.device)])
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized():
             dist.all_reduce(sums, group=group)
         g_sum, n_sum, b_tot = (float(v) for v in sums.tolist())
-        step = (snr * (n_sum / b_tot) / (g_sum / b_tot)) ** 2 * 2
+        step = (snr * (n_sum / b_tot) / (g_sum / b_tot)) ** 2 * 2 * alpha
         x, x_mean = ops.affine_noise_step(x, grad, noise, 1.0, step, (2 * step) ** 0.5)
     return x, x_mean
 
@@ -128,7 +134,7 @@ class LangevinCorrectorGlobal(Corrector):
             raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
 
     def update_fn(self, x, t):
-        return _langevin_global(self.sde, lambda v: self.score_fn(v, t), x, self.snr, self.n_steps)
+        return _langevin_global(self.sde, lambda v: self.score_fn(v, t), x, self.snr, self.n_steps, t)
 
 
 @register_corrector(name='conditional_langevin_global')
@@ -139,7 +145,7 @@ class conditionalLangevinCorrectorGlobal(Corrector):
             raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
 
     def update_fn(self, x, y, t):
-        return _langevin_global(self.sde, lambda v: self.score_fn(v, y, t), x, self.snr, self.n_steps)
+        return _langevin_global(self.sde, lambda v: self.score_fn(v, y, t), x, self.snr, self.n_steps, t)
 
 
 def _ald(sde, score_of, x, t, snr, n_steps):

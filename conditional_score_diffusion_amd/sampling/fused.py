@@ -133,10 +133,14 @@ def path_tables(sy, ts):
 
 
 def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=None, record=False,
-        unconditional_label=None, global_norm=None, predictor=None, corrector=None, probability_flow=False, use_path=False):
+        unconditional_label=None, global_norm=None, predictor=None, corrector=None, probability_flow=False, use_path=False,
+        corr_alpha=None):
     """Run the fused loop; returns (samples, record_or_None, timesteps).  ``seed=None``: a fresh key per call (fresh_seed).
 
     ``predictor`` / ``corrector``: the registered classes (default: the reverse-diffusion / Langevin pair); see ``fusable``.
+
+    ``corr_alpha``: optional [p_steps] fp32 factors of the Langevin step size (csd_pc_params.corr_alpha: alphas[timestep] of the VP
+    SDEs, sampling/correctors.py:63-65,94-96); None = 1 (the VE SDEs - the only ones ``fusable`` admits today).
 
     ``global_norm``: None = the Langevin step size uses the batch means of THIS call's batch (the reference run on this batch;
     one library call enqueues the whole loop).  Otherwise ``(reduce_fn, global_batch)``: the batch is one shard of a larger one
@@ -206,6 +210,11 @@ def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=
     p.corr_coef = _fp(corr_tab) if corr_tab is not None else None
     p.path_coef = _fp(path_tab) if path_tab is not None else None
     p.path_std0 = float(path_std0)
+    if corr_alpha is not None:
+        corr_alpha = torch.as_tensor(corr_alpha, dtype=torch.float32).contiguous()
+        if corr_alpha.numel() != p_steps:
+            raise ValueError('corr_alpha needs one factor per step (%d), got %d' % (p_steps, corr_alpha.numel()))
+    p.corr_alpha = _fp(corr_alpha) if corr_alpha is not None else None
     if global_norm is not None and cid != 0:
         global_norm = None                      # only the Langevin corrector couples the samples of a batch
     yy = y.contiguous() if y is not None else None
@@ -223,5 +232,5 @@ def run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=None, seed=
             reduce_fn(sums)
             check(lib().csd_pc_step_end(*args, i, ptr(sums), int(global_batch), current_stream(dev)), 'pc_step_end')
     # keep the host arrays alive until the enqueue returned (they are read at enqueue time only)
-    del labels, std_x, G, std_y, pred_tab, corr_tab, path_tab
+    del labels, std_x, G, std_y, pred_tab, corr_tab, path_tab, corr_alpha
     return x, rec, ts

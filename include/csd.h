@@ -172,6 +172,8 @@ typedef struct csd_pc_params {
    * y_{T+tau} = y + path_std0 * z.  Draw order: prior | z_y0 | per step: z_y, z_predictor, z_corrector (existing phases only). */
   const float* path_coef;       /* [n_steps][3] = (w0, w1, s), or NULL                                                */
   float path_std0;              /* sigma_y(T + tau)                                                                    */
+  /* Langevin corrector of the VP / subVP SDEs (sampling/correctors.py:63-65,94-96): step size times alphas[timestep_i]     */
+  const float* corr_alpha;      /* [n_steps] or NULL (= 1: the VE SDEs)                                                */
 } csd_pc_params;
 
 /* x: [B, x_channels, S, S] in: prior sample (already scaled by sigma_max); out: result.
@@ -197,13 +199,14 @@ int csd_pc_step_end(csd_unet* net, const void* packed, void* workspace, size_t w
                     const float* norm_sums, int global_batch, void* stream);
 
 /* Stand-alone update kernels (the "noise-add" steps), usable with any score source:
- *   csd_langevin_step: sampling/correctors.py:88-108 (alpha = 1)
+ *   csd_langevin_step: sampling/correctors.py:51-78,88-108: step = (snr * mean||z|| / mean||score||)^2 * 2 * alpha with
+ *                      alpha = sde.alphas[timestep] for the VP / subVP SDEs (:63-65,94-96) and 1 for the VE SDEs
  *   csd_reverse_diffusion_step: sampling/predictors.py:84-89,97-102 with f = 0
  * net: raw network output; score = net / std.  x is updated in place, x_mean written.
  * scratch: >= csd_update_scratch_bytes(B) bytes. */
 size_t csd_update_scratch_bytes(int B);
 int csd_langevin_step(float* x, float* x_mean, const float* net, const float* z, float std,
-                      float snr, int B, int64_t per_sample, void* scratch, void* stream);
+                      float snr, float alpha, int B, int64_t per_sample, void* scratch, void* stream);
 int csd_reverse_diffusion_step(float* x, float* x_mean, const float* net, const float* z, float std,
                                float G, int B, int64_t per_sample, void* stream);
 /* General one-step update  x_mean = p*x + a*score,  x = x_mean + c*z  (n elements, scalars per call): the

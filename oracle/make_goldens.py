@@ -235,6 +235,42 @@ def gen_steps(ref):
     print('steps.npz: %d arrays' % len(out))
 
 
+VP_LANGEVIN_CASES = [       # name, SDE class, kwargs, registry name, conditional
+    ('vp_lang', 'VPSDE', dict(beta_min=0.1, beta_max=20., N=1000), 'langevin', False),
+    ('ve_lang', 'VESDE', dict(sigma_min=0.01, sigma_max=50., N=1000), 'langevin', False),
+    ('cvp_lang', 'cVPSDE', dict(beta_min=0.1, beta_max=20., N=1000), 'conditional_langevin', True),
+    ('cve_lang', 'cVESDE', dict(sigma_min=0.01, sigma_max=50., N=1000), 'conditional_langevin', True),
+]
+
+
+def gen_vp_langevin(ref):
+    """Two Langevin corrector updates (sampling/correctors.py:51-108) of the reference classes on the VP SDEs (subVPSDE has no
+    `alphas`: the reference raises AttributeError there, sde_lib.py:251-287; step size
+    times alphas[timestep], :63-65,94-96) and, for contrast, the VE ones (alpha = 1), with a noise tape and the closed-form score
+    of gen_steps -> tests/golden/vp_langevin.npz."""
+    sl, co = ref['sde_lib'], ref['sampling.correctors']
+    g = torch.Generator().manual_seed(79)
+    B, C, S = 3, 3, 8
+    x0 = torch.randn(B, C, S, S, generator=g) * 2.0
+    y0 = torch.rand(B, C, S, S, generator=g)
+    z0 = torch.randn(2, B, C, S, S, generator=g)
+    out = {'x0': x0.numpy(), 'y0': y0.numpy(), 'z0': z0.numpy(), 'times': np.array(STEP_TIMES, np.float32)}
+    for name, scls, skw, reg, cond in VP_LANGEVIN_CASES:
+        sde = getattr(sl, scls)(**skw)
+        for ti, tv in enumerate(STEP_TIMES):
+            t = torch.full((B,), tv)
+            score_fn = (lambda x, y, t: step_score(x, t, y)) if cond else (lambda x, t: step_score(x, t))
+            with ref_import.TapeRandn([z0[0], z0[1]]):
+                obj = co.get_corrector(reg)(sde, score_fn, 0.16, 2)
+                x, xm = obj.update_fn(x0.clone(), y0, t) if cond else obj.update_fn(x0.clone(), t)
+            out['%s_t%d_x' % (name, ti)] = x.numpy()
+            out['%s_t%d_xmean' % (name, ti)] = xm.numpy()
+            if scls != 'VESDE' and scls != 'cVESDE':
+                out['%s_t%d_alpha' % (name, ti)] = np.float32(sde.alphas[(t[:1] * (sde.N - 1) / sde.T).long()].item())
+    np.savez_compressed(os.path.join(OUT, 'vp_langevin.npz'), **out)
+    print('vp_langevin.npz: %d arrays' % len(out))
+
+
 def gen_use_path(ref):
     """use_path conditional PC sampling (sampling/conditional.py:124-178) of the reference on the CMDE tiny case, 4 steps,
     noise tape -> tests/golden/use_path.npz."""
@@ -591,6 +627,7 @@ def main():
     gen_sde_tables(ref)
     gen_modules(ref)
     gen_steps(ref)
+    gen_vp_langevin(ref)
     gen_ncsnpp(ref)
     gen_use_path(ref)
     gen_losses(ref)

@@ -38,8 +38,12 @@ def _worker(rank, world, port, q):
 def test_shard_bounds_and_seeds():
     from conditional_score_diffusion_amd import distributed as D
     assert [D.shard_bounds(64, r, 8) for r in range(8)] == [(8 * r, 8 * r + 8) for r in range(8)]
-    with pytest.raises(ValueError):
-        D.shard_bounds(10, 0, 4)
+    # a batch that does not divide (BASELINE configs[3]: 50 images over 8 GPUs): full shards first, a ragged / empty tail
+    b = [D.shard_bounds(50, r, 8) for r in range(8)]
+    assert b == [(0, 7), (7, 14), (14, 21), (21, 28), (28, 35), (35, 42), (42, 49), (49, 50)]
+    assert [D.shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert [D.shard_bounds(3, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 3), (3, 3)]      # the last rank is empty
+    assert sum(hi - lo for lo, hi in b) == 50 and D.shard_size(50, 8) == 7
     assert len({D.rank_seed(42, r) for r in range(8)}) == 8
 
 
@@ -61,6 +65,59 @@ def test_two_rank_sharded_sampling_gloo():
     for rank, out, info in res:
         assert torch.equal(out, expect)            # every rank holds the whole batch, shards in rank order
         assert info['n'] == 4 and info['seed'] == D.rank_seed(5, rank)
+
+
+def _ragged_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from conditional_score_diffusion_amd import distributed as D
+    res = {}
+    for n in (5, 1):        # 5 images over 2 ranks -> 3 + 2 (padded gather, sliced back); 1 image -> rank 1 is empty
+        y = torch.arange(n * 3 * 2 * 2, dtype=torch.float32).reshape(n, 3, 2, 2)
+        out, info = D.sample_sharded(_fake_sampler, None, y_global=y, seed=5, pad_shape=(3, 2, 2))
+        res[n] = (out, info)
+    # ragged data-parallel loss weights: the summed gradient is the global-batch mean
+    w = torch.nn.Parameter(torch.zeros(1))
+    from conditional_score_diffusion_amd.distributed import GradSync
+
+    class _Flat:      # the two attributes GradSync reads
+        params, offsets = [w], [0, 1]
+    flat = _Flat()
+    flat.grad = torch.zeros(1)
+    w.grad = flat.grad
+    sync = GradSync(flat)
+    n_local = 3 if rank == 0 else 2
+    x = torch.arange(5.0)[:3] if rank == 0 else torch.arange(5.0)[3:]
+    sync.scale_loss((w * x).mean(), local_n=n_local, global_n=5).backward()
+    sync.finish()
+    res['grad'] = flat.grad.clone()
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ragged_shards_gloo():
+    """a global batch that does not divide by the world size: padded all_gather, sliced result, weighted loss"""
+    from conditional_score_diffusion_amd import distributed as D
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    y5 = torch.arange(5 * 3 * 2 * 2, dtype=torch.float32).reshape(5, 3, 2, 2)
+    expect5 = torch.cat([y5[:3] * 2 + float(D.rank_seed(5, 0) % 97), y5[3:] * 2 + float(D.rank_seed(5, 1) % 97)])
+    y1 = torch.arange(1 * 3 * 2 * 2, dtype=torch.float32).reshape(1, 3, 2, 2)
+    for rank, r in res:
+        assert torch.equal(r[5][0], expect5) and r[5][1].get('n', 0) == (3 if rank == 0 else 2)
+        assert torch.equal(r[1][0], y1 * 2 + float(D.rank_seed(5, 0) % 97))
+        assert torch.allclose(r['grad'], torch.tensor([2.0]))         # mean of 0..4
 
 
 def test_single_process_is_passthrough():

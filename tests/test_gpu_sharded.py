@@ -182,3 +182,26 @@ def test_two_ranks_on_one_gpu(golden_dir, backend):
     # d(sum(W x + b))/dW = sum_b x_b: rank r contributes 2*(r+1) per entry, scaled by 1/world -> (2 + 4)/2 = 3
     w = got[0][1]['grad'][:64 * 64]
     assert np.allclose(w, 3.0) and np.allclose(got[0][1]['grad'], got[1][1]['grad'])
+
+
+def test_rccl_world_one(golden_dir):
+    """RCCL executes this code: a ONE-rank 'nccl' process group on the box's one GPU.  With a process group present the library's
+    N > 1 paths are taken unchanged (distributed.sample_sharded / GradSync do not special-case world size 1 once a group exists):
+    the final all_gather_into_tensor, the per-step 8-byte all-reduce of the global-norm mode (between csd_pc_step_begin and
+    csd_pc_step_end, on the launch stream) and the bucketed gradient all-reduce all run as librccl kernels on device tensors -
+    which proves the device-tensor / stream / device_id plumbing that the two-rank variant cannot (RCCL refuses two ranks on one
+    device).  Both modes must then equal the reference's single-process run of the whole batch."""
+    import torch.multiprocessing as mp
+    g = np.load(os.path.join(golden_dir, 'sharded_modes.npz'))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    pr = ctx.Process(target=_two_rank_worker, args=(0, 1, _free_port(), 'nccl', q))
+    pr.start()
+    rank, res, err = q.get(timeout=600)
+    pr.join(timeout=120)
+    assert err is None, err
+    smax = float(np.sqrt(3 * 20 * 20))
+    assert np.abs(res['shard'] - g['sr3_tiny_global']).max() / smax < 2e-4
+    assert np.abs(res['global'] - g['sr3_tiny_global']).max() / smax < 2e-4
+    # one rank: d(sum(W x + b))/dW = sum_b x_b = 2 * 1, all-reduced over a world of one
+    assert np.allclose(res['grad'][:64 * 64], 2.0)

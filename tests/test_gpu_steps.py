@@ -175,3 +175,75 @@ def test_pc_inpainter_vs_reference(golden_dir):
     x = x.cpu()
     assert float(((x - data) * mask).abs().max()) == 0.0
     assert np.abs(x.numpy() - ref).max() <= 2e-4 * float(cfg.model.sigma_max_x)
+
+
+# ---- Langevin corrector on the VP SDEs: step size times alphas[timestep] (sampling/correctors.py:63-67,94-98) ----
+LANG_GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'vp_langevin.npz')
+LANG_CASES = [      # oracle/make_goldens.py:VP_LANGEVIN_CASES (the reference's subVPSDE has no `alphas`: it raises there)
+    ('vp_lang', 'VPSDE', dict(beta_min=0.1, beta_max=20., N=1000), 'langevin', False),
+    ('ve_lang', 'VESDE', dict(sigma_min=0.01, sigma_max=50., N=1000), 'langevin', False),
+    ('cvp_lang', 'cVPSDE', dict(beta_min=0.1, beta_max=20., N=1000), 'conditional_langevin', True),
+    ('cve_lang', 'cVESDE', dict(sigma_min=0.01, sigma_max=50., N=1000), 'conditional_langevin', True),
+]
+
+
+@pytest.mark.parametrize('name,scls,skw,reg,cond', LANG_CASES)
+def test_langevin_vp_and_ve_vs_reference(name, scls, skw, reg, cond):
+    """two Langevin updates of the reference classes themselves (noise tape, closed-form score) at three times"""
+    from conditional_score_diffusion_amd import sde_lib
+    from conditional_score_diffusion_amd.sampling import correctors
+    g = np.load(LANG_GOLD)
+    dev = torch.device('cuda:0')
+    x0, y0 = torch.from_numpy(g['x0']).to(dev), torch.from_numpy(g['y0']).to(dev)
+    z0 = torch.from_numpy(g['z0'])
+    sde = getattr(sde_lib, scls)(**skw)
+    for ti, tv in enumerate(g['times']):
+        t = torch.full((x0.shape[0],), float(tv), device=dev)
+        score_fn = (lambda x, y, t: step_score(x, t, y)) if cond else (lambda x, t: step_score(x, t))
+        if name + '_t%d_alpha' % ti in g.files:
+            assert abs(correctors._alpha(sde, t) - float(g[name + '_t%d_alpha' % ti])) < 1e-7
+        with _Tape([z0[0], z0[1]]):
+            obj = correctors.get_corrector(reg)(sde, score_fn, 0.16, 2)
+            x, xm = obj.update_fn(x0.clone(), y0, t) if cond else obj.update_fn(x0.clone(), t)
+        for got, key in ((x, 'x'), (xm, 'xmean')):
+            ref = torch.from_numpy(g['%s_t%d_%s' % (name, ti, key)])
+            err = (got.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+            assert err < 5e-6, (name, ti, key, err)
+
+
+def test_langevin_global_vp_equals_langevin():
+    """the global-norm corrector (one process: no other ranks) carries the same alpha"""
+    from conditional_score_diffusion_amd import sde_lib
+    from conditional_score_diffusion_amd.sampling import correctors
+    g = np.load(LANG_GOLD)
+    dev = torch.device('cuda:0')
+    x0 = torch.from_numpy(g['x0']).to(dev)
+    z0 = torch.from_numpy(g['z0'])
+    sde = sde_lib.VPSDE(beta_min=0.1, beta_max=20., N=1000)
+    t = torch.full((x0.shape[0],), 0.31, device=dev)
+    outs = []
+    for reg in ('langevin', 'langevin_global'):
+        with _Tape([z0[0], z0[1]]):
+            outs.append(correctors.get_corrector(reg)(sde, lambda x, t: step_score(x, t), 0.16, 2).update_fn(x0.clone(), t)[0])
+    assert (outs[0] - outs[1]).abs().max().item() < 2e-5 * outs[0].abs().max().item()
+
+
+def test_fused_loop_corrector_alpha():
+    """csd_pc_params.corr_alpha: a constant factor a on the step size equals a run with snr * sqrt(a) (step ~ snr^2 * alpha)"""
+    import cases
+    from test_gpu_network import build, sdes_for
+    from conditional_score_diffusion_amd.sampling import fused
+    case, P = 'sr3_tiny', 4
+    cfg, nc, p, model = build(case)
+    sde = sdes_for(cfg)
+    B = cases.case_config(case)[1]
+    y = cases.case_y(case).to(torch.device('cuda:0'))
+    tape = cases.tape(cases.pc_tape_shapes(case, P), seed=5)
+    shape = (B,) + tuple(cfg.data.shape_x)
+    a = 0.64
+    xa, _, _ = fused.run(model, sde, shape, y, P, 0.16, 1e-5, True, noise_tape=tape, corr_alpha=torch.full((P,), a))
+    xb, _, _ = fused.run(model, sde, shape, y, P, 0.16 * a ** 0.5, 1e-5, True, noise_tape=tape)
+    x1, _, _ = fused.run(model, sde, shape, y, P, 0.16, 1e-5, True, noise_tape=tape)
+    scale = xb.abs().max().item()
+    assert (xa - xb).abs().max().item() < 1e-5 * scale
+    assert (xa - x1).abs().max().item() > 1e-3 * scale          # (the factor does something)
