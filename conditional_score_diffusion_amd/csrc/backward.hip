@@ -632,7 +632,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin
   if (layout & 2) dyh = const_cast<float*>(dy);
   else if ((rc = nchw_to_nhwc_launch(dy, dyh, B, Cout, OH * OW, Cout, Cout, s))) return rc;
   if ((layout & 4) && ksize == 3 && (stride == 2 || up) && Cin % 4 == 0 && Cout % 4 == 0 && !wgrad_wide(Cin) && !getenv("CSD_WGRAD_FP32") &&
-      !getenv("CSD_WGRAD_RESAMPLE_FP32")) {
+      !CSD_TUNE_ENV("CSD_WGRAD_RESAMPLE_FP32")) {
     // resampling convs on the bf16 kernel too (it knows stride 1 only): rebuild ONE operand on the fine grid.
     //   Upsample (nearest x2, then 3x3): x' = nearest_up2(x), the plain stride-1 gradient of (x', dy).
     //   Downsample (pad (0,1,0,1), stride 2): y[p] = sum_k W[k] x[2p + k]  ->  dW[k] = sum_q dy'[q] x[q + k - 1] with dy'[2p + 1] = dy[p],

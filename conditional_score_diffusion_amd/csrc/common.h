@@ -7,6 +7,16 @@
 
 #include "../../include/csd.h"
 
+// Tuning switches (kernel selection A/B, occupancy pads, ablations) exist in the TUNING build only (`make tune` ->
+// libcsd_hip_tune.so, selected with CSD_LIB_PATH): in the product library CSD_TUNE_ENV is a null constant, the branches it guards
+// are dead code and nothing in libcsd_hip.so depends on the process environment - except the three weight-gradient A/B switches
+// that tests/test_gpu_training.py::test_weight_gradient_ab_schedules_agree exercises (backward.hip, wgrad_bf16.hip).
+#ifdef CSD_TUNE
+#define CSD_TUNE_ENV(name) getenv(name)
+#else
+#define CSD_TUNE_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 namespace csd {
 
 // thread-local last-error text behind csd_last_error()

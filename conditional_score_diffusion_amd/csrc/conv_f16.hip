@@ -18,7 +18,7 @@ bool conv16_supported(const ConvPlan& p) {
 }
 
 int conv16_kcs(int ns, int cin) {   // sub-chunks per stage for an fp16-source convolution
-  if (const char* f = getenv("CSD_FORCE_KCS")) {   // tuning aid
+  if (const char* f = CSD_TUNE_ENV("CSD_FORCE_KCS")) {   // tuning aid
     const int v = atoi(f);
     if (v == 1 || (cin % (16 * v) == 0 && (v == 2 || (v == 3 && ns == 1)))) return v;
   }
@@ -50,7 +50,7 @@ int conv16_plan_tiles(ConvPlan* p, int ns, int kcs, bool lc) {
   // tile shape: TW divides OW when possible, maximise covered pixels, then minimise the staged patch
   int best_mt = 0, best_tw = 0, best_th = 0;
   int mt_max = 4;     // (MT = 8 is not instantiated) 128-pixel tiles: 4 workgroups (12 waves) per CU overlap each other's prologue/epilogue
-  if (const char* f = getenv("CSD_FORCE_MT")) {   // tuning aid
+  if (const char* f = CSD_TUNE_ENV("CSD_FORCE_MT")) {   // tuning aid
     const int v = atoi(f);
     if (v == 2 || v == 4) mt_max = v;
   }

@@ -14,7 +14,7 @@ static int launch_in16(const Conv16KArgs& k, size_t lds, hipStream_t s) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  static const int lds_pad = getenv("CSD_C16_LDS_PAD") ? atoi(getenv("CSD_C16_LDS_PAD")) : 0;   // tuning aid: lower the occupancy
+  static const int lds_pad = CSD_TUNE_ENV("CSD_C16_LDS_PAD") ? atoi(CSD_TUNE_ENV("CSD_C16_LDS_PAD")) : 0;   // tuning aid: lower the occupancy
   lds += (size_t)lds_pad;
   hipLaunchKernelGGL(kern, dim3(k.nblocks), dim3(k.nw * 64), lds, s, static_cast<const void*>(k.a.src0),
                      static_cast<const void*>(k.a.src1), reinterpret_cast<const char*>(k.a.wpack), k);

@@ -20,13 +20,13 @@ static int launch_lc(const Conv16KArgs& k, const ConvPlan& p, hipStream_t s) {
     attr_set = true;
   }
   size_t lds = conv16_lc_lds_bytes(p, NS, PWC);
-  static const int lds_pad = getenv("CSD_C16_LDS_PAD") ? atoi(getenv("CSD_C16_LDS_PAD")) : 0;   // tuning aid: lower the occupancy
+  static const int lds_pad = CSD_TUNE_ENV("CSD_C16_LDS_PAD") ? atoi(CSD_TUNE_ENV("CSD_C16_LDS_PAD")) : 0;   // tuning aid: lower the occupancy
   lds += (size_t)lds_pad;
   CSD_REQUIRE(lds <= 160 * 1024 && p.PH * p.PW <= C16_LC_MAXPATCH, "conv16 lc: patch %dx%d does not fit", p.PH, p.PW);
   // persistent: two workgroups per CU; a multiple of 8 keeps every item of a workgroup on its XCD's item range
   int grid = k.nblocks;
   if (grid > 512) grid = 512;
-  static const int force_grid = getenv("CSD_C16_LC_GRID") ? atoi(getenv("CSD_C16_LC_GRID")) : 0;   // tuning aid
+  static const int force_grid = CSD_TUNE_ENV("CSD_C16_LC_GRID") ? atoi(CSD_TUNE_ENV("CSD_C16_LC_GRID")) : 0;   // tuning aid
   if (force_grid >= 8 && force_grid % 8 == 0 && force_grid < k.nblocks) grid = force_grid;
   else if (force_grid >= k.nblocks) grid = k.nblocks;
   hipLaunchKernelGGL(kern, dim3(grid), dim3((k.nw + 1) * 64), lds, s, static_cast<const void*>(k.a.src0),

@@ -438,7 +438,7 @@ bool conv16q_supported(const ConvPlan& p, int ns) {
 bool conv16q_up4_supported(const ConvPlan& p, int ns) {
   ConvPlan q = p;
   q.up = 1;
-  return (ns == 1 || ns == 2) && p.stride == 1 && conv16q_supported(q, ns) && !getenv("CSD_NO_UP4");
+  return (ns == 1 || ns == 2) && p.stride == 1 && conv16q_supported(q, ns) && !CSD_TUNE_ENV("CSD_NO_UP4");
 }
 
 size_t conv16q_up4_packed_bytes(const ConvPlan& p, int ns) {
@@ -606,7 +606,7 @@ int conv16q_plan_tiles(ConvPlan* p, int ns) {
     // (the weight fragments come through the CU's texture path once per WAVE: what a layer costs is the weight traffic of its busiest
     // CU.  128-pixel tiles halve that traffic as soon as they still put a workgroup on every CU: measured at the 20^2 level (B = 64:
     // 400 instead of 800 workgroups) -0.6 ms per PC step; at 10^2 (162 workgroups) the 64-pixel tiles stay ahead.)
-    static const long min_wg = getenv("CSD_Q_MINWG") ? atol(getenv("CSD_Q_MINWG")) : 300;
+    static const long min_wg = CSD_TUNE_ENV("CSD_Q_MINWG") ? atol(CSD_TUNE_ENV("CSD_Q_MINWG")) : 300;
     if (nwg >= min_wg || mq == 2) break;
   }
   CSD_REQUIRE(best_tw > 0, "conv16q: no feasible tile for OW=%d", p->OW);

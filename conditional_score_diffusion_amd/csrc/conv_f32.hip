@@ -408,7 +408,7 @@ int conv_plan_tiles(ConvPlan* p) {
       const double t = (double)cdiv(nwg, slots) * nt * (1.0 + 0.05 * (3 - nt));
       if (t < best - 1e-9) { best = t; best_nt = nt; }
     }
-    if (const char* f = getenv("CSD_FORCE_NT")) {   // tuning aid
+    if (const char* f = CSD_TUNE_ENV("CSD_FORCE_NT")) {   // tuning aid
       const int v = atoi(f);
       if (v >= 1 && v <= 3 && ntiles % v == 0) best_nt = v;
     }

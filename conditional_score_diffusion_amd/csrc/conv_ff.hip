@@ -547,10 +547,10 @@ long long* g_ff_dbg = nullptr;      // tuning aid: per-workgroup phase stamps (c
 static inline int ff_nt(int cout) { return cout % 96 == 0 ? 3 : 2; }
 
 bool convff_supported(const ConvPlan& p, int ns) {
-  if (getenv("CSD_NO_FF")) return false;
+  if (CSD_TUNE_ENV("CSD_NO_FF")) return false;
   const int kc = ns == 1 ? 32 : 16;
   return (ns >= 1 && ns <= 3) && p.taps == 9 && p.stride == 1 && p.up == 0 && p.pad == 1 && p.C0 > 0 && p.C0 % kc == 0 &&
-         p.C1 % kc == 0 && (p.Cout % 96 == 0 || (p.Cout % 64 == 0 && !getenv("CSD_FF_NO_NT2"))) && p.OH % FF_TILE == 0 && p.OW % FF_TILE == 0 &&
+         p.C1 % kc == 0 && (p.Cout % 96 == 0 || (p.Cout % 64 == 0 && !CSD_TUNE_ENV("CSD_FF_NO_NT2"))) && p.OH % FF_TILE == 0 && p.OW % FF_TILE == 0 &&
          p.IH == p.OH && p.IW == p.OW;
 }
 
@@ -638,14 +638,14 @@ static int launch_ff(const ConvFFArgs& k, hipStream_t s) {
   if (!attr_set) {
     CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
-    if (getenv("CSD_FF_OCC")) {
+    if (CSD_TUNE_ENV("CSD_FF_OCC")) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), FF_THREADS, FFCfg<NS, NT>::LDS);
       fprintf(stderr, "conv_ff<%d,%d>: %d workgroups per CU (LDS %zu B)\n", NS, NT, nb, (size_t)FFCfg<NS, NT>::LDS);
     }
   }
   size_t lds = FFCfg<NS, NT>::LDS;
-  if (getenv("CSD_FF_LDS_PAD")) lds += (size_t)atoi(getenv("CSD_FF_LDS_PAD"));      // tuning aid: forces one workgroup per CU
+  if (CSD_TUNE_ENV("CSD_FF_LDS_PAD")) lds += (size_t)atoi(CSD_TUNE_ENV("CSD_FF_LDS_PAD"));      // tuning aid: forces one workgroup per CU
   hipLaunchKernelGGL(kern, dim3(k.nblocks), dim3(FF_THREADS), lds, s, reinterpret_cast<const char*>(k.a.wpack), k);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
@@ -665,7 +665,7 @@ int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
   k.n_groups = p.Cout / (32 * ff_nt(p.Cout));
   k.nblocks = p.B * k.tpi * k.n_groups;
   k.nstage = (p.C0 + p.C1) / (ns == 1 ? 32 : 16);
-  k.abl = getenv("CSD_FF_ABL") ? atoi(getenv("CSD_FF_ABL")) : 0;
+  k.abl = CSD_TUNE_ENV("CSD_FF_ABL") ? atoi(CSD_TUNE_ENV("CSD_FF_ABL")) : 0;
   k.a.dbg = (k.abl & 128) ? g_ff_dbg : nullptr;
   const int nt = ff_nt(p.Cout);
   const bool norm = a.nscale != nullptr;

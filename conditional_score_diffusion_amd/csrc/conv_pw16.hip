@@ -395,7 +395,7 @@ bool pw16_taps_supported(int cin, int cout, int ns) {
   ConvPlan p;
   memset(&p, 0, sizeof(p));
   p.taps = 1; p.stride = 1; p.C0 = cin; p.Cout = pw16_taps_cout(cout);
-  return cout >= 1 && cout <= 6 && pw16_supported(p, ns) && !getenv("CSD_NO_TAPSUM");
+  return cout >= 1 && cout <= 6 && pw16_supported(p, ns) && !CSD_TUNE_ENV("CSD_NO_TAPSUM");
 }
 
 template <int NS, int MTP, int OCC>

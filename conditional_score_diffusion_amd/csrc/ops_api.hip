@@ -116,7 +116,7 @@ int csd::conv2d_impl(const float* x, const float* weight, const float* bias, con
   const size_t bias_fl = al64((size_t)p.CoutPad);
   int ns = precision_ns(precision);
   bool pw = false, quad = false;
-  if (ns && in_nhwc && Cin % 32 == 0 && !getenv("CSD_NO_Q")) {
+  if (ns && in_nhwc && Cin % 32 == 0 && !CSD_TUNE_ENV("CSD_NO_Q")) {
     // NHWC source (the training graph): the quad schedule of the sampling path - one split pass writes the fp16 planes into the
     // scratch region an NCHW source would be transposed into, then conv_f16_q_kernel
     ConvPlan q = p;

@@ -30,16 +30,29 @@ struct TrainState {
   void* ws = nullptr;
   size_t fwd_top = 0;
   float p_drop = 0.f;
+  uint64_t call = 0;            // the forward's call_index: csd_unet_backward must name it
   std::vector<TT> t;
   std::vector<TStep> steps;
   float *xin = nullptr, *emb = nullptr, *temb1 = nullptr, *temb2 = nullptr, *temb2_act = nullptr;
 };
 
-static std::map<const Net*, TrainState> g_train;      // one recorded forward per network handle
+// one recorded forward per (network handle, workspace): two forwards of one network may be alive at once (a monitoring forward
+// between a training forward and its backward) as long as each has its own workspace - and a backward names the call_index of the
+// forward it belongs to, so a workspace that was re-used in between is an error, never a silently wrong gradient
+static std::map<std::pair<const Net*, const void*>, TrainState> g_train;
 static std::mutex g_train_mu;                         // (the map only; a handle itself is driven by one thread at a time)
-static TrainState& train_state_of(const Net* n) {
+static TrainState& train_state_of(const Net* n, const void* ws) {
   std::lock_guard<std::mutex> lk(g_train_mu);
-  return g_train[n];
+  return g_train[std::make_pair(n, ws)];
+}
+static TrainState* train_state_find(const Net* n, const void* ws) {
+  std::lock_guard<std::mutex> lk(g_train_mu);
+  auto it = g_train.find(std::make_pair(n, ws));
+  return it == g_train.end() ? nullptr : &it->second;
+}
+static void train_state_erase(const Net* n) {
+  std::lock_guard<std::mutex> lk(g_train_mu);
+  for (auto it = g_train.begin(); it != g_train.end();) it = it->first.first == n ? g_train.erase(it) : std::next(it);
 }
 
 __global__ void concat_c_kernel(const float4* __restrict__ a, int ca4, const float4* __restrict__ b, int cb4,
@@ -680,24 +693,30 @@ extern "C" int csd_unet_train_forward(csd_unet* net, const float* const* params,
   }
   for (size_t i = 0; i < net->net.params.size(); ++i)
     CSD_REQUIRE(params[i], "train_forward: parameter %zu (%s) is null", i, net->net.params[i].name.c_str());
-  TrainState& st = train_state_of(&net->net);
+  TrainState& st = train_state_of(&net->net, workspace);
   st.valid = false;
   TG g(net->net, st, B, (hipStream_t)stream, false, params, nullptr, static_cast<float*>(workspace));
   g.p_drop = dropout_p; g.seed = dropout_seed; g.call = call_index;
   rc = g.forward(x, y, labels, out);
   if (rc) return rc;
-  st.valid = true; st.B = B; st.ws = workspace; st.p_drop = dropout_p;
+  st.valid = true; st.B = B; st.ws = workspace; st.p_drop = dropout_p; st.call = call_index;
   return CSD_OK;
 }
 
 extern "C" int csd_unet_backward(csd_unet* net, const float* const* params, float* const* grads, void* workspace,
-                                 size_t workspace_bytes, const float* d_out, int B, void* stream) {
+                                 size_t workspace_bytes, const float* d_out, int B, uint64_t call_index, void* stream) {
   int rc = train_check(net);
   if (rc) return rc;
   CSD_REQUIRE(params && grads && workspace && d_out, "backward: null argument");
-  TrainState& st = train_state_of(&net->net);
-  if (!st.valid || st.B != B || st.ws != workspace) {
+  TrainState* sp = train_state_find(&net->net, workspace);
+  if (!sp || !sp->valid || sp->B != B || sp->ws != workspace) {
     set_error("backward: no matching csd_unet_train_forward (same handle, workspace and batch) precedes this call");
+    return CSD_ERR_STATE;
+  }
+  TrainState& st = *sp;
+  if (st.call != call_index) {
+    set_error("backward: the workspace holds the activations of csd_unet_train_forward call %llu, not of call %llu (a later forward "
+              "re-used it before this backward ran)", (unsigned long long)st.call, (unsigned long long)call_index);
     return CSD_ERR_STATE;
   }
   const size_t need = csd_unet_train_workspace_bytes(net, B, st.p_drop);

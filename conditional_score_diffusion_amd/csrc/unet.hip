@@ -506,12 +506,12 @@ static int build_packed_layout(Net& n) {
   const int net_ns = precision_ns(n.cfg.precision);
   // the 6 -> nf stem: with the input padded to 16 channels (zeros) it runs on the fp16 matrix cores like every other 3x3 (one K step
   // per tap) instead of the fp32 ones (36 MFMAs of 64 cycles per 32 pixels: 380 us per evaluation at 160^2, B = 64, MFMA-bound)
-  if (n.cfg.arch == 0 && net_ns && !getenv("CSD_STEM_F32")) n.in_cpad = 16;
+  if (n.cfg.arch == 0 && net_ns && !CSD_TUNE_ENV("CSD_STEM_F32")) n.in_cpad = 16;
   // quad schedule: measured faster than the loader/consumer one in the split (3-MFMA) mode only
-  const bool use_q = net_ns == 2 && !getenv("CSD_NO_Q");
+  const bool use_q = net_ns == 2 && !CSD_TUNE_ENV("CSD_NO_Q");
   int cur_res = n.cfg.image_size;    // resolution of the layer being laid out
   // opt-in experiment (measured slower: one loader wave cannot convert a patch as fast as three waves consume it)
-  const bool fused_norm = getenv("CSD_FUSED_NORM") != nullptr;
+  const bool fused_norm = CSD_TUNE_ENV("CSD_FUSED_NORM") != nullptr;
   auto add_conv = [&](const std::string& key, int c0, int c1, int cout, int taps,
                       std::vector<PackedConv::Src> srcs, bool stride1 = true, bool normed = false,
                       bool resample = false, bool upsample = false, bool last = false) -> int {
@@ -534,7 +534,7 @@ static int build_packed_layout(Net& n) {
     rc = proto_conv(&pc.proto, c0, c1, cout, taps);
     if (rc) return rc;
     // the 5 x 5 level on the quad schedule: 32-cout groups (conv_f16_q.hip: q_ntq)
-    static const int nt1_res = getenv("CSD_Q_NT1_RES") ? atoi(getenv("CSD_Q_NT1_RES")) : 5;      // tuning aid (0 disables)
+    static const int nt1_res = CSD_TUNE_ENV("CSD_Q_NT1_RES") ? atoi(CSD_TUNE_ENV("CSD_Q_NT1_RES")) : 5;      // tuning aid (0 disables)
     if (net_ns == 2 && normed && stride1 && !resample && cur_res <= nt1_res) pc.proto.qnt = 1;
     ConvPlan one = pc.proto;       // a GroupNorm-ed conv reads ONE fp16 tensor of c0 + c1 channels
     one.C0 = c0 + c1; one.C1 = 0;
@@ -542,7 +542,7 @@ static int build_packed_layout(Net& n) {
     // (standard fragment layout); the quad schedule serves the lower levels, whose tiles straddle samples
     // (fp16 mode: the loader/consumer schedule wins on the GroupNorm-ed convs, the quad schedule on the resampling ones,
     // which would otherwise convert fp32 -> fp16 inside the old kernel's staging loop)
-    const bool q_here = use_q || (net_ns == 1 && resample && !getenv("CSD_NO_Q"));
+    const bool q_here = use_q || (net_ns == 1 && resample && !CSD_TUNE_ENV("CSD_NO_Q"));
     // fused-prologue schedule: GroupNorm-ed stride-1 convs whose 16 x 16 tiles lie inside one sample (reads the fp32 residual
     // stream itself: the gn_apply16 pass and its fp16 planes disappear)
     ConvPlan ffp = pc.proto;
@@ -919,7 +919,7 @@ struct Builder {
     const int kcs = (pc.ns && !pc.pw && norm) ? conv16_kcs(pc.ns, o.cp.C0 + o.cp.C1) : 1;    // fp16-source convs stage in bursts
     bool fused = false;     // GroupNorm affine + activation applied by the conv's loader wave (no gn_apply16 pass)
     if (pc.ns && !pc.pw && !pc.q && norm && stride == 1 && !up && o.cp.C0 % 32 == 0 && o.cp.C1 % 32 == 0 &&
-        !getenv("CSD_NO_LC") && getenv("CSD_FUSED_NORM")) {
+        !CSD_TUNE_ENV("CSD_NO_LC") && CSD_TUNE_ENV("CSD_FUSED_NORM")) {
       ConvPlan trial = o.cp;
       if (conv16_plan_tiles(&trial, pc.ns, 2, true) == CSD_OK && trial.LC && trial.OH % trial.TH == 0) {
         fused = true;
@@ -940,7 +940,7 @@ struct Builder {
       if (conv16q_plan_tiles(&o.cp, pc.ns)) { rc = CSD_ERR_INVALID; return NONE; }
     } else if (pc.pw) {
       if (act != CSD_ACT_NONE || temb_col != NONE || external_nchw) { set_error("pointwise fp16 layer with act/temb/NCHW"); rc = CSD_ERR_INVALID; return NONE; }
-    } else if (pc.ns ? conv16_plan_tiles(&o.cp, pc.ns, kcs, kcs > 1 && !getenv("CSD_NO_LC")) : conv_plan_tiles(&o.cp)) { rc = CSD_ERR_INVALID; return NONE; }
+    } else if (pc.ns ? conv16_plan_tiles(&o.cp, pc.ns, kcs, kcs > 1 && !CSD_TUNE_ENV("CSD_NO_LC")) : conv_plan_tiles(&o.cp)) { rc = CSD_ERR_INVALID; return NONE; }
     // the packed layout depends on KC only (not on NT / tile shape)
     if (o.cp.KC != pc.proto.KC) { set_error("conv plan/pack mismatch"); rc = CSD_ERR_INVALID; return NONE; }
     o.a = src0; o.b = src1; o.pk0 = pc.w_off; o.pk1 = pc.b_off;
@@ -979,7 +979,7 @@ struct Builder {
     const size_t out_elems = (size_t)B * o.cp.OH * o.cp.OW * o.cp.Cout;
     o.out = external_nchw ? NONE : alloc_(out_elems);
     const int oh_tiled = o.cp.up == 2 ? o.cp.IH : o.cp.OH;         // (the phase form tiles the SOURCE image, four workgroups per tile)
-    if (!pc.pw && !external_nchw && o.cp.taps == 9 && oh_tiled % o.cp.TH == 0 && !getenv("CSD_NO_FUSED_STATS") &&
+    if (!pc.pw && !external_nchw && o.cp.taps == 9 && oh_tiled % o.cp.TH == 0 && !CSD_TUNE_ENV("CSD_NO_FUSED_STATS") &&
         o.cp.up != 2) {     // (phase-decomposed Upsample: its fp64 epilogue statistics cost more than the streaming pass over the output,
                             // and their tile grouping would make a sample's bits depend on the batch size it is run in)
       // every tile lies inside one sample: the epilogue also leaves (sum, sumsq) per (tile, cout) for the next
@@ -1007,7 +1007,7 @@ struct Builder {
     // the shortcut contraction first; with CSD_SIDE_STREAM=1 on the side stream (it only depends on the block's input; Conv_1 joins it).
     // Opt-in: -0.35 ms per PC step in a same-box A/B, but the per-launch durations of the overlapped 3x3 launches (what the bench's
     // roofline object and the rocprofv3 summaries report) then include the time they share the CUs with it
-    static const bool side_on = getenv("CSD_SIDE_STREAM") != nullptr && atoi(getenv("CSD_SIDE_STREAM")) != 0;
+    static const bool side_on = CSD_TUNE_ENV("CSD_SIDE_STREAM") != nullptr && atoi(CSD_TUNE_ENV("CSD_SIDE_STREAM")) != 0;
     size_t shortcut = x0, sc_buf = NONE;
     if (m.cin != m.cout) {
       const size_t op0 = pl.ops.size();
@@ -1541,7 +1541,7 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
       }
       case OP_ATTN:
         // fp16 arithmetic modes: the split-operand kernel on the fp16 matrix cores (fp32-class in the split modes); fp32 mode: the fp32 MFMA one
-        rc = (precision_ns(c.precision) && !getenv("CSD_ATTN_F32"))
+        rc = (precision_ns(c.precision) && !CSD_TUNE_ENV("CSD_ATTN_F32"))
                  ? attention16_launch(W(o.a), 3 * o.i1, W(o.out), B, o.i0, o.i1, precision_ns(c.precision) >= 2 ? 2 : 1, s)
                  : attention_launch(W(o.a), 3 * o.i1, W(o.out), B, o.i0, o.i1, s);
         break;
@@ -1695,8 +1695,7 @@ extern "C" int csd_unet_create(const csd_unet_config* cfg, csd_unet** out) {
 
 extern "C" void csd_unet_destroy(csd_unet* net) {
   if (net) {
-    std::lock_guard<std::mutex> lk(g_train_mu);
-    g_train.erase(&net->net);
+    train_state_erase(&net->net);
   }
   delete net;
 }

@@ -328,7 +328,7 @@ int wgrad_bf16_launch(const float* xh, const float* dyh, float* partial, int B, 
   const int n_ci = cdiv(Cin, 32), n_co = cdiv(Cout, 32);
   const dim3 grid((unsigned)S * n_ci * n_co);
   const bool staged = W > 8 && Cin % 4 == 0 && Cout % 4 == 0 && !getenv("CSD_WGRAD_GATHER");
-  const bool full = staged && Cin % 32 == 0 && Cout % 32 == 0 && !getenv("CSD_WGRAD_MASKED");
+  const bool full = staged && Cin % 32 == 0 && Cout % 32 == 0 && !CSD_TUNE_ENV("CSD_WGRAD_MASKED");
 #define WG_LAUNCH(KS_, ST_, FU_)                                                                                                   \
   hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS_, ST_, FU_>), grid, dim3(256), 0, s, xh, dyh, partial, B, H, W, Cin, H, W, Cout,   \
                      per_split, n_ci, n_co)

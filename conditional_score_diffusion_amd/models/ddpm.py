@@ -54,7 +54,7 @@ class HipUNet(nn.Module):
         if precision is None:
             precision = m.get('csd_precision', None) if hasattr(m, 'get') else getattr(m, 'csd_precision', None)
         if precision is None:
-            precision = os.environ.get('CSD_PRECISION', 'fp16f8')     # the fastest certified mode (1e-5 norm-wise, 4e-5 element-wise)
+            precision = os.environ.get('CSD_PRECISION', 'fp16f8')     # the fastest certified mode (1.3e-5 norm-wise / 4.5e-5 element-wise per evaluation)
         if precision not in _lib.PREC_IDS:
             raise ValueError('unknown csd precision %r (choose from %s)' % (precision, sorted(_lib.PREC_IDS)))
         self.precision = precision
@@ -75,6 +75,7 @@ class HipUNet(nn.Module):
         self.train_layout = os.environ.get('CSD_TRAIN_LAYOUT', 'nhwc')     # 'nhwc' | 'nchw' (see _train_forward)
         self.train_executor = os.environ.get('CSD_TRAIN_EXECUTOR', 'planned')   # 'planned' (csd_unet_backward) | 'operators' (autograd)
         self._train_ws = None
+        self._train_ws_busy = False        # a forward whose backward has not run yet holds the shared training workspace
         self.dropout_seed = int(getattr(config, 'seed', 0) or 0)   # Philox key of the dropout masks
         cfg = _lib.UNetConfig()
         cfg.arch = self.arch
@@ -365,6 +366,13 @@ class HipUNet(nn.Module):
         return G.conv2d(h, m[i + 1].weight, m[i + 1].bias, precision=prec)
 
 
+def _release_shared_ws(model_ref, ws_ptr):
+    """the forward that held the model's shared training workspace is done with it (its backward ran, or its graph was dropped)"""
+    model = model_ref()
+    if model is not None and model._train_ws is not None and model._train_ws.data_ptr() == ws_ptr:
+        model._train_ws_busy = False
+
+
 class _PlannedNet(torch.autograd.Function):
     """The whole training-mode network as one autograd node over csd_unet_train_forward / csd_unet_backward."""
 
@@ -374,13 +382,21 @@ class _PlannedNet(torch.autograd.Function):
         for name, p in zip(model._param_names, params):
             if p.dtype != torch.float32 or not p.is_contiguous() or p.device != x.device:
                 raise RuntimeError('parameter %s must be contiguous float32 on %s' % (name, x.device))
-        ws = model._train_workspace(B)
+        # the shared training workspace belongs to ONE live forward; a second one (e.g. a monitoring forward between a training
+        # forward and its backward) gets a workspace of its own, released with its autograd context
+        shared = not model._train_ws_busy
+        ws = model._train_workspace(B) if shared else torch.empty(
+            lib().csd_unet_train_workspace_bytes(model._h, B, model._dropout), dtype=torch.uint8, device=x.device)
         table = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
         out = torch.empty(B, model.out_channels, model.image_size, model.image_size, dtype=torch.float32, device=x.device)
         check(lib().csd_unet_train_forward(model._h, table, ptr(ws), ws.numel(), ptr(x), ptr(y) if y is not None else None,
                                            ptr(labels), ptr(out), B, model._dropout, model.dropout_seed, model._train_calls,
                                            current_stream(x.device)), 'unet_train_forward')
-        ctx.model, ctx.table, ctx.ws, ctx.B = model, table, ws, B
+        ctx.model, ctx.table, ctx.ws, ctx.B, ctx.call = model, table, ws, B, model._train_calls
+        if shared:
+            model._train_ws_busy = True
+            import weakref
+            weakref.finalize(ctx, _release_shared_ws, weakref.ref(model), ws.data_ptr())
         ctx.shapes = [(p.shape, p.numel()) for p in params]
         ctx.sink = [p.grad for p in params] if getattr(model, 'grad_sink', False) else None
         return out
@@ -399,8 +415,9 @@ class _PlannedNet(torch.autograd.Function):
             flat = torch.empty(offs[-1], dtype=torch.float32, device=dout.device)
             grads = [flat[o:o + n].view(shape) for o, (shape, n) in zip(offs, ctx.shapes)]
         gtable = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
-        check(lib().csd_unet_backward(model._h, ctx.table, gtable, ptr(ctx.ws), ctx.ws.numel(), ptr(dout), B,
+        check(lib().csd_unet_backward(model._h, ctx.table, gtable, ptr(ctx.ws), ctx.ws.numel(), ptr(dout), B, ctx.call,
                                       current_stream(dout.device)), 'unet_backward')
+        _release_shared_ws(lambda: model, ctx.ws.data_ptr())
         if direct:
             return (None, None, None, None) + (None,) * len(grads)
         return (None, None, None, None) + tuple(grads)

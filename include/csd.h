@@ -45,7 +45,8 @@ enum {
   CSD_PREC_F16 = 2,          /* fp16 operands, fp32 accumulate                                      */
   CSD_PREC_F16F8 = 3         /* split operands; hi*hi on the fp16 MFMA, the two correction products K-concatenated on the fp8 MFMA
                                 (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3 operands, block scale 2^-11) in the fused-prologue block
-                                convolution; every other layer as CSD_PREC_F16X3.  Network error ~2e-5 (fp16x3: 1e-6, fp16: 5e-4) */
+                                convolution; every other layer as CSD_PREC_F16X3.  Measured network error, full-size SR3-160 against the
+                                reference: 1.3e-5 norm-wise / 4.5e-5 element-wise per evaluation (fp16x3: 1.9e-6 / 5.8e-6; fp16: 9e-4 / 3.9e-3) */
 };
 
 const char* csd_version(void);
@@ -337,12 +338,13 @@ int csd_ema_update(float* ema, const float* param, int64_t n, float decay, void*
  * ---------------------------------------------------------------------------------------- */
 /* The ResnetBlock convolution with its prologue fused (csrc/conv_ff.hip; reference models/layers.py:632-675: Conv(act(GroupNorm(x)))
  * [+ Dense(temb)] [+ x]): 3x3, stride 1, pad 1 on NHWC fp32 tensors.  x0 [B,H,W,C0] (+ x1 [B,H,W,C1] or NULL: virtual concat),
- * H % 16 == 0, W % 16 == 0, C0 / C1 multiples of 32, Cout a multiple of 96; weight OIHW [Cout, C0+C1, 3, 3]; nscale / nshift
+ * H % 16 == 0, W % 16 == 0, C0 / C1 multiples of 32, Cout a multiple of 96 (three 32-cout tiles per workgroup: the nf = 96 nets) or of
+ * 64 (two: the nf = 128 nets); weight OIHW [Cout, C0+C1, 3, 3]; nscale / nshift
  * [B, C0+C1] = the GroupNorm's per-(sample, channel) rstd*gamma and beta - mean*rstd*gamma, applied as SiLU(x*scale + shift)
  * while the operand is staged (both NULL: the convolution reads x as it is); temb [B, temb_stride] or NULL (column c of sample b
  * is added to cout c), res [B,H,W,Cout] or NULL (added), out_scale multiplies the result.  stats (or NULL):
- * [B*(H/16)*(W/16)][Cout][2] doubles = per-tile (sum, sum of squares) of the written tensor.  precision: CSD_PREC_F16X3 or
- * CSD_PREC_F16.  scratch holds the packed weight: csd_conv3x3_block_scratch_bytes(C0 + C1, Cout). */
+ * [B*(H/16)*(W/16)][Cout][2] doubles = per-tile (sum, sum of squares) of the written tensor.  precision: CSD_PREC_F16X3, CSD_PREC_F16F8 (the
+ * split operands with the two correction products on the fp8 matrix cores; 1.3e-5 / 4.5e-5 network error, see csd_precision) or CSD_PREC_F16.  scratch holds the packed weight: csd_conv3x3_block_scratch_bytes(C0 + C1, Cout). */
 size_t csd_conv3x3_block_scratch_bytes(int Cin, int Cout);
 int csd_conv3x3_block(const float* x0, const float* x1, const float* weight, const float* bias, const float* nscale,
                       const float* nshift, const float* temb, int temb_stride, const float* res, float out_scale, float* y,
@@ -389,7 +391,9 @@ int csd_attention_backward_nhwc(const float* qkv, const float* dout, float* dqkv
  *     (call_index << 16) + running dropout index), models/layers.py:647,662); every tensor a gradient needs stays in `workspace`.
  *   csd_unet_backward: given d loss / d out ([B, out_channels, S, S]), writes d loss / d parameter i to grads[i] (overwrite).
  * params[i] / grads[i]: device pointers of parameter i in csd_unet_param_info order and layout (fp32, 16-byte aligned).
- * One backward per forward, same handle / workspace / B; the workspace must not be touched in between.
+ * One backward per forward, same handle / workspace / B / call_index; the workspace must not be touched in between: a second
+ * forward into the same workspace before the backward makes that backward fail with CSD_ERR_STATE (it names the first forward's
+ * call_index) - two forwards of one network may be alive at once when each has its own workspace.
  * csd_unet_train_workspace_bytes depends on B and on whether dropout_p > 0. arch 0 only (NCSN++ trains per operator).
  * ---------------------------------------------------------------------------------------- */
 size_t csd_unet_train_workspace_bytes(csd_unet* net, int B, float dropout_p);
@@ -397,7 +401,7 @@ int csd_unet_train_forward(csd_unet* net, const float* const* params, void* work
                            const float* y, const float* labels, float* out, int B, float dropout_p, uint64_t dropout_seed,
                            uint64_t call_index, void* stream);
 int csd_unet_backward(csd_unet* net, const float* const* params, float* const* grads, void* workspace, size_t workspace_bytes,
-                      const float* d_out, int B, void* stream);
+                      const float* d_out, int B, uint64_t call_index, void* stream);
 
 #ifdef __cplusplus
 }

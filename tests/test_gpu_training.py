@@ -241,15 +241,56 @@ def test_planned_graph_call_sequence_errors():
     gtable = (ctypes.c_void_p * len(ps))(*[q.data_ptr() for q in gs])
     ws = model._train_workspace(B)
     dout = torch.zeros(B, model.out_channels, model.image_size, model.image_size, device=dev())
-    assert lib().csd_unet_backward(model._h, table, gtable, ptr(ws), ws.numel(), ptr(dout), B, None) == -3     # CSD_ERR_STATE
+    assert lib().csd_unet_backward(model._h, table, gtable, ptr(ws), ws.numel(), ptr(dout), B, 1, None) == -3     # CSD_ERR_STATE
     assert b'csd_unet_train_forward' in lib().csd_last_error()
     xs = x.to(dev()); ys = y.to(dev()); lab = torch.full((B,), 3., device=dev()); out = torch.empty_like(dout)
     assert lib().csd_unet_train_forward(model._h, table, ptr(ws), 1024, ptr(xs), ptr(ys), ptr(lab), ptr(out), B, 0.0, 0, 1, None) == -5
     assert lib().csd_unet_train_forward(model._h, table, ptr(ws), ws.numel(), ptr(xs), ptr(ys), ptr(lab), ptr(out), B, 0.0, 0, 1, None) == 0
-    assert lib().csd_unet_backward(model._h, table, gtable, ptr(ws), ws.numel(), ptr(dout), B + 1, None) == -3
-    assert lib().csd_unet_backward(model._h, table, gtable, ptr(ws), ws.numel(), ptr(dout), B, None) == 0
-    assert lib().csd_unet_backward(model._h, table, gtable, ptr(ws), ws.numel(), ptr(dout), B, None) == -3        # consumed
+    assert lib().csd_unet_backward(model._h, table, gtable, ptr(ws), ws.numel(), ptr(dout), B + 1, 1, None) == -3
+    assert lib().csd_unet_backward(model._h, table, gtable, ptr(ws), ws.numel(), ptr(dout), B, 1, None) == 0
+    assert lib().csd_unet_backward(model._h, table, gtable, ptr(ws), ws.numel(), ptr(dout), B, 1, None) == -3        # consumed
+    # a second forward into the SAME workspace before the first one's backward: that backward names call 2, the workspace holds call 3
+    assert lib().csd_unet_train_forward(model._h, table, ptr(ws), ws.numel(), ptr(xs), ptr(ys), ptr(lab), ptr(out), B, 0.0, 0, 2, None) == 0
+    assert lib().csd_unet_train_forward(model._h, table, ptr(ws), ws.numel(), ptr(xs), ptr(ys), ptr(lab), ptr(out), B, 0.0, 0, 3, None) == 0
+    assert lib().csd_unet_backward(model._h, table, gtable, ptr(ws), ws.numel(), ptr(dout), B, 2, None) == -3
+    assert b're-used' in lib().csd_last_error()
+    assert lib().csd_unet_backward(model._h, table, gtable, ptr(ws), ws.numel(), ptr(dout), B, 3, None) == 0
     torch.cuda.synchronize()
+
+
+def test_two_live_forwards_of_one_model_keep_their_own_activations():
+    """a monitoring forward (train mode, grad enabled) between a training forward and its backward must not disturb the first
+    forward's saved activations: the second live forward gets its own workspace, both backwards give the gradients of their own
+    inputs (one workspace per model used to be overwritten silently)"""
+    cfg, B, x, y, u, tape = cases.grad_case('sr3_tiny')
+    cfg, nc, p, model = build(cfg)
+    model.train()
+    model._dropout = 0.0
+    assert model.train_executor == 'planned'
+    xs, ys = x.to(dev()), y.to(dev())
+    lab = torch.full((B,), 3., device=dev())
+
+    def grads_of(xin, other=None):
+        for q in model.parameters():
+            q.grad = None
+        out = model({'x': xin, 'y': ys}, lab)
+        if other is not None:
+            out2 = model({'x': other, 'y': ys}, lab)          # alive at the same time as `out`
+        out.square().sum().backward()
+        g = torch.cat([q.grad.reshape(-1) for q in model.parameters()]).clone()
+        if other is not None:
+            for q in model.parameters():
+                q.grad = None
+            out2.square().sum().backward()
+            return g, torch.cat([q.grad.reshape(-1) for q in model.parameters()]).clone()
+        return g
+
+    x2 = xs * 0.5 + 0.1
+    ref1, ref2 = grads_of(xs), grads_of(x2)
+    g1, g2 = grads_of(xs, other=x2)
+    assert torch.equal(g1, ref1) and torch.equal(g2, ref2)
+    assert not model._train_ws_busy
+    assert torch.equal(grads_of(xs), ref1)                   # the shared workspace is free again
 
 
 def test_training_fp16x3_grads_close_to_fp32():
