@@ -134,10 +134,22 @@ def configure_sde(config, buffers=None):
     m, name = config.model, config.training.sde.lower()
     if config.data.get('use_data_mean', False):
         raise NotImplementedError('data.use_data_mean: the data-mean prior needs the dataset statistics file')
-    conditional = 'conditioning_approach' in config.training or m.name.lower().endswith(('paired', 'sr3'))
+    # which Lightning module built the checkpoint decides (lightning_modules/utils.py:23-27 create_lightning_module dispatches on
+    # config.training.lightning_module: 'base' | 'conditional' | 'conditional_decreasing_variance'); configs without that key fall
+    # back to the markers of a conditional model
+    lm = str(config.training.get('lightning_module', '') or '').lower()
+    if lm in ('base', 'conditional', 'conditional_decreasing_variance'):
+        conditional = lm != 'base'
+    else:
+        conditional = 'conditioning_approach' in config.training or m.name.lower().endswith(('paired', 'sr3'))
     if name == 'vpsde':
-        cls = sde_lib.cVPSDE if conditional else sde_lib.VPSDE
-        return cls(beta_min=m.beta_min, beta_max=m.beta_max, N=m.num_scales), 1e-3
+        # ConditionalSdeGenerativeModel.configure_sde (:18-21): cVPSDE, CDE ('sr3') only; the decreasing-variance module (:144-146)
+        # and the base module build a plain VPSDE
+        if lm == 'conditional' or (not lm and conditional):
+            if config.training.get('conditioning_approach', 'sr3') != 'sr3':
+                raise NotImplementedError('We support only CDE with VP sde currently.')
+            return sde_lib.cVPSDE(beta_min=m.beta_min, beta_max=m.beta_max, N=m.num_scales), 1e-3
+        return sde_lib.VPSDE(beta_min=m.beta_min, beta_max=m.beta_max, N=m.num_scales), 1e-3
     if name == 'subvpsde':
         return sde_lib.subVPSDE(beta_min=m.beta_min, beta_max=m.beta_max, N=m.num_scales), 1e-3
     if name != 'vesde':

@@ -16,10 +16,22 @@ from . import _lib
 from ._lib import check, current_stream, lib, ptr
 
 
+# Parameter -> the live FlatParams that holds its storage.  Kept OUTSIDE the Parameter (keyed by id, validated by identity): an
+# attribute on the Parameter would be serialised by Parameter.__reduce_ex__ and a weakref there breaks torch.save(model),
+# copy.deepcopy(optimizer) and module pickling for multiprocessing spawn.
+_OWNERS = {}
+
+
 def _owner(p):
-    """the live FlatParams that holds this Parameter's storage (kept as a weak reference on the Parameter), or None"""
-    r = getattr(p, '_csd_flat', None)
-    return r() if r is not None else None
+    """the live FlatParams that holds this Parameter's storage, or None"""
+    ent = _OWNERS.get(id(p))
+    if ent is None:
+        return None
+    pref, fref = ent
+    if pref() is not p or fref() is None:          # (the id was recycled, or the flat buffer is gone)
+        _OWNERS.pop(id(p), None)
+        return None
+    return fref()
 
 
 class FlatParams:
@@ -63,7 +75,7 @@ class FlatParams:
             self.data[o:o + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.data[o:o + p.numel()].view_as(p)
             p.grad = self.grad[o:o + p.numel()].view_as(p)      # autograd accumulates in place into the flat buffer
-            p._csd_flat = weakref.ref(self)
+            _OWNERS[id(p)] = (weakref.ref(p), weakref.ref(self))
         _lib.WEIGHT_EPOCH[0] += 1
 
     def zero_grad(self):

@@ -121,9 +121,11 @@ def get_pc_conditional_sampler(sde, shape, predictor, corrector, snr, p_steps, c
             return out, {}
 
     if use_path:
-        def pc_path_sampler(model, y, show_evolution=False, noise_tape=None, seed=None):
+        def pc_path_sampler(model, y, show_evolution=False, noise_tape=None, seed=None, global_norm=None):
             """the bridge sampler on the fused device loop (csd_pc_params.path_coef) when the pair is fusable and no y_t evolution is
             asked for; else step by step (path_sampler above)"""
+            if global_norm is not None:
+                raise NotImplementedError('use_path is not provided in the global-norm sharded mode (sample_sharded(global_norm=True))')
             if not show_evolution and fused.fusable(model, sde, predictor, corrector, c_steps, probability_flow, continuous, use_path=True):
                 x, _, _ = fused.run(model, sde, shape, y, p_steps, snr, eps, denoise, noise_tape=noise_tape, seed=seed,
                                     predictor=predictor, corrector=corrector, probability_flow=probability_flow, use_path=True)
@@ -143,6 +145,11 @@ def get_pc_conditional_sampler(sde, shape, predictor, corrector, snr, p_steps, c
             return x, {}
         if noise_tape is not None:
             raise NotImplementedError('noise_tape is only available on the fused path')
+        if global_norm is not None:
+            # the step-by-step fallback (c_steps != 1, a VP SDE, a model that is not a HipUNet) computes per-shard norms: refusing is
+            # better than silently not delivering "identical to one process"; use the 'conditional_langevin_global' corrector there
+            raise NotImplementedError('global-norm sharded sampling runs on the fused device loop only; this (model, sde, predictor, '
+                                      'corrector, c_steps) combination falls back to the step-by-step loop')
         with torch.no_grad():
             x = c_sde.prior_sampling(shape).to(model.device)
             evolution = {'x': [], 'y': []}

@@ -166,6 +166,9 @@ def get_pc_sampler(sde, shape, predictor, corrector, snr, p_steps, c_steps, prob
             return x, info
         if noise_tape is not None:
             raise NotImplementedError('noise_tape is only available on the fused path')
+        if global_norm is not None:       # (the step-by-step fallback would use per-shard norms: refuse instead; 'langevin_global' exists)
+            raise NotImplementedError('global-norm sharded sampling runs on the fused device loop only; this (model, sde, predictor, '
+                                      'corrector, c_steps) combination falls back to the step-by-step loop')
         with torch.no_grad():
             x = sde.prior_sampling(shape).to(model.device).type(torch.float32)
             timesteps = torch.linspace(sde.T, eps, p_steps, device=model.device)

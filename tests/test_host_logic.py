@@ -185,6 +185,37 @@ def test_flat_params_are_shared_not_reflattened():
     with pytest.raises(RuntimeError):
         optim.FlatParams(net.parameters())                      # explicit re-flattening
     assert issubclass(optim.FusedAdam, torch.optim.Optimizer)   # LambdaLR (configure_optimizers) accepts it
+    # flattened modules stay picklable / deep-copyable (the owner map lives outside the Parameter: ADVICE r2)
+    import copy
+    import pickle
+    clone = pickle.loads(pickle.dumps(net))
+    assert torch.equal(clone[0].weight, net[0].weight)
+    copy.deepcopy(net)
+
+
+def test_configure_sde_dispatches_on_the_lightning_module():
+    """checkpoint.configure_sde follows create_lightning_module (lightning_modules/utils.py:23-27): 'conditional' + VP -> cVPSDE,
+    'conditional_decreasing_variance' + VP -> plain VPSDE (ConditionalSdeGenerativeModel.py:18-21,144-146), 'base' -> VPSDE"""
+    from conditional_score_diffusion_amd import checkpoint, sde_lib
+    from conditional_score_diffusion_amd.config_dict import ConfigDict
+
+    def cfg(lm, approach='sr3', name='ddpm_paired_SR3'):
+        c = ConfigDict()
+        c.training = ConfigDict(); c.model = ConfigDict(); c.data = ConfigDict()
+        c.training.sde = 'vpsde'
+        if lm is not None:
+            c.training.lightning_module = lm
+        if approach is not None:
+            c.training.conditioning_approach = approach
+        c.model.name, c.model.beta_min, c.model.beta_max, c.model.num_scales = name, 0.1, 20., 1000
+        c.data.use_data_mean = False
+        return c
+    assert type(checkpoint.configure_sde(cfg('conditional'))[0]) is sde_lib.cVPSDE
+    assert type(checkpoint.configure_sde(cfg('conditional_decreasing_variance'))[0]) is sde_lib.VPSDE
+    assert type(checkpoint.configure_sde(cfg('base', approach=None, name='ddpm'))[0]) is sde_lib.VPSDE
+    assert type(checkpoint.configure_sde(cfg(None))[0]) is sde_lib.cVPSDE             # no key: the name heuristics
+    with pytest.raises(NotImplementedError):
+        checkpoint.configure_sde(cfg('conditional', approach='ours_NDV'))
 
 
 def test_product_code_never_imports_the_oracle():
