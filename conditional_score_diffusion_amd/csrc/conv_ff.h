@@ -67,4 +67,7 @@ struct FFCfg {
   static constexpr size_t LDS = 2 * (size_t)FF_PATCH_BYTES + (size_t)R * GB + 2 * FF_NPATCH * sizeof(int);
 };
 
+// conv_fx.hip: the fp16f8 form with one workgroup per CU (whole-stage weight buffers, one barrier per stage)
+int convfx_launch(const ConvFFArgs& k, int nt, hipStream_t s);
+
 }  // namespace csd

@@ -668,6 +668,8 @@ int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
   k.abl = CSD_TUNE_ENV("CSD_FF_ABL") ? atoi(CSD_TUNE_ENV("CSD_FF_ABL")) : 0;
   k.a.dbg = (k.abl & 128) ? g_ff_dbg : nullptr;
   const int nt = ff_nt(p.Cout);
+  static const bool use_fx = getenv("CSD_FX") != nullptr;       // (development switch of round 3: A/B against the two-workgroup form)
+  if (ns == 3 && use_fx) return convfx_launch(k, nt, s);
   const bool norm = a.nscale != nullptr;
 #define FF_DISPATCH(NT_)                                                                                            \
   if (ns == 1) return norm ? launch_ff<1, NT_, false, true>(k, s) : launch_ff<1, NT_, false, false>(k, s);       \

@@ -64,13 +64,19 @@ class Trainer:
         self.sde['y'] = sde_lib.VESDE(sigma_min=self.sigma_min_y, sigma_max=self.sigma_max_y, N=self.config.model.num_scales)
         self._build_loss_fns()
 
-    def train_step(self, batch):
-        """-> detached loss of this rank's shard.  ``batch`` is the loss_fn's: ``x`` or ``(y, x)``."""
+    def train_step(self, batch, global_n=None):
+        """-> detached loss of this rank's shard.  ``batch`` is the loss_fn's: ``x`` or ``(y, x)``.  ``global_n``: images of the GLOBAL
+        batch when the shards are ragged (a global batch that does not divide by the world size, distributed.shard_bounds): the
+        rank's mean loss is then weighted by its share of the images instead of 1 / world."""
         if self._vs is not None:
             self.reconfigure_conditioning_sde()
         self.optimizer.zero_grad()
         loss = self.loss_fn(self.model, batch)
-        self.sync.scale_loss(loss).backward()
+        if global_n:
+            first = batch[0] if isinstance(batch, (tuple, list)) else batch
+            self.sync.scale_loss(loss, local_n=first.shape[0], global_n=global_n).backward()
+        else:
+            self.sync.scale_loss(loss).backward()
         self.sync.finish()
         # Lightning's gradient_clip_val (run_lib.py:58-59): 0 disables; losses.optimization_manager: negative disables
         clip = float(self.config.optim.grad_clip)

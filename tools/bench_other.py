@@ -88,10 +88,33 @@ def ncsnpp(name='ncsnpp_paired', B=8, reps=3):
                       'params': sum(v.numel() for v in model.state_dict().values())}))
 
 
+def ncsnpp256(B=8, reps=3):
+    """BASELINE configs[4]: NCSN++ 256 x 256 (nf = 128, ch_mult (1,1,2,2,2,2,2), attention at 16, Fourier embedding, pyramids), forward only,
+    at the per-GPU batch of an 8-GPU sampling run"""
+    c = ncsnpp_config('ncsnpp')
+    S = 256
+    c.data = ConfigDict(image_size=S, effective_image_size=S, centered=False, num_channels=3)
+    c.model.nf, c.model.ch_mult, c.model.attn_resolutions, c.model.embedding_type = 128, (1, 1, 2, 2, 2, 2, 2), (16,), 'fourier'
+    c.model.num_scales, c.model.sigma_max = 2000, 348.
+    model = build(c)
+    x = torch.randn(B, 3, S, S, device=dev)
+    lab = torch.full((B,), float(np.log(3.7)), device=dev)
+    with torch.no_grad():
+        model(x, lab)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps):
+            model(x, lab)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+    print(json.dumps({'workload': 'BASELINE configs[4]: NCSN++ 256x256 nf=128, forward only', 'precision': prec, 'batch': B,
+                      'ms_per_forward': dt * 1e3, 'images_per_sec_per_nfe': B / dt,
+                      'params': sum(v.numel() for v in model.state_dict().values())}))
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 2 and sys.argv[2] == 'bench':      # the two side figures of bench.py's line (B = 64, planned executors only)
+    if len(sys.argv) > 2 and sys.argv[2] == 'bench':      # the side figures of bench.py's line (planned executors only)
         cmde128()
         ncsnpp('ncsnpp_paired', 64)
+        ncsnpp256(8)
     else:
         cmde128()
         ncsnpp('ncsnpp_paired', 8)

@@ -53,8 +53,10 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+    grouped = 'RANK' in os.environ and 'MASTER_PORT' in os.environ      # launched by torch.distributed.run: RCCL also at world size 1
+    if grouped:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     cfg = make_config(a.precision)
     torch.manual_seed(0)
     model = mutils.create_model(cfg).to(dev)
@@ -62,34 +64,39 @@ def main():
     sde = {'x': sde_lib.cVESDE(m.sigma_min_x, m.sigma_max_x, m.num_scales),
            'y': sde_lib.VESDE(m.sigma_min_y, m.sigma_max_y, m.num_scales)}
     tr = train.Trainer(cfg, model, sde)
-    B = a.batch // world
+    from conditional_score_diffusion_amd.distributed import shard_bounds
+    lo, hi = shard_bounds(a.batch, rank, world)       # the config's global batch of 50 over 8 GPUs: 7,7,7,7,7,7,7,1 (ragged)
+    B = hi - lo
+    if B == 0:
+        sys.exit('rank %d has no images (global batch %d over %d ranks)' % (rank, a.batch, world))
+    global_n = a.batch if a.batch % world else None
     g = torch.Generator().manual_seed(1 + rank)
     batch = (torch.rand(B, 3, 64, 64, generator=g).to(dev), torch.rand(B, 3, 64, 64, generator=g).to(dev))
 
     def sync():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        loss = tr.train_step(batch)
+        loss = tr.train_step(batch, global_n=global_n)
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        loss = tr.train_step(batch)
+        loss = tr.train_step(batch, global_n=global_n)
     sync()
     dt = torch.tensor([time.perf_counter() - t0], device=dev)
-    if world > 1:
+    if grouped:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt)
     if rank == 0:
         sps = a.steps / dt
         print(json.dumps({'metric': 'training steps/sec, VS-CMDE edges2shoes 64x64 (ddpm_paired nf=128), fwd+bwd+all-reduce+Adam/EMA',
-                          'value': sps, 'unit': 'steps/sec', 'images_per_sec': sps * B * world, 'n_gpus': world,
-                          'global_batch': B * world, 'ms_per_step': 1e3 * dt / a.steps, 'steps': a.steps, 'warmup': a.warmup,
+                          'value': sps, 'unit': 'steps/sec', 'images_per_sec': sps * a.batch, 'n_gpus': world,
+                          'global_batch': a.batch, 'rank0_batch': B, 'ms_per_step': 1e3 * dt / a.steps, 'steps': a.steps, 'warmup': a.warmup,
                           'precision': a.precision, 'params': tr.flat.numel, 'loss': float(loss),
-                          'achieved_TFLOPs_3x_fwd': 3 * FWD_GFLOP_PER_IMAGE * 1e-3 * sps * B * world, 'data': 'synthetic'}))
-    if world > 1:
+                          'achieved_TFLOPs_3x_fwd': 3 * FWD_GFLOP_PER_IMAGE * 1e-3 * sps * a.batch, 'data': 'synthetic'}))
+    if grouped:
         dist.destroy_process_group()
 
 
