@@ -668,8 +668,12 @@ int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
   k.abl = CSD_TUNE_ENV("CSD_FF_ABL") ? atoi(CSD_TUNE_ENV("CSD_FF_ABL")) : 0;
   k.a.dbg = (k.abl & 128) ? g_ff_dbg : nullptr;
   const int nt = ff_nt(p.Cout);
-  static const bool use_fx = getenv("CSD_FX") != nullptr;       // (development switch of round 3: A/B against the two-workgroup form)
-  if (ns == 3 && use_fx) return convfx_launch(k, nt, s);
+#ifdef CSD_TUNE
+  // round-3 development kernel (conv_fx.hip: one persistent 8-wave workgroup per CU, matrix waves + producer waves; at parity with this
+  // kernel, profiles/NOTEBOOK.md) - tuning build only, A/B with CSD_FX=1.  It carries one residual chunk in each of its first 2 nt stages.
+  static const bool use_fx = CSD_TUNE_ENV("CSD_FX") != nullptr;
+  if (ns == 3 && use_fx && k.nstage >= 2 * nt) return convfx_launch(k, nt, s);
+#endif
   const bool norm = a.nscale != nullptr;
 #define FF_DISPATCH(NT_)                                                                                            \
   if (ns == 1) return norm ? launch_ff<1, NT_, false, true>(k, s) : launch_ff<1, NT_, false, false>(k, s);       \
