@@ -150,6 +150,10 @@ int pw16_pack_weight_taps(const ConvPlan& p, int ns, const float* w, int cout, v
 int tapsum_launch(const float* part, const float* bias, const float* res, float* out, int B, int H, int W, int cout, int nchw,
                   float out_scale, hipStream_t s);
 // y16 = fp16 split of act(x*scale + shift): hi plane (and lo plane when ns == 2), NHWC halves [B*HW][C0+C1]
+// statistics + finalize + apply + split of a small map in one launch (norm.hip); gn_fused16_groups() == 0: use the three-launch form
+int gn_fused16_groups(int HW, int C0, int C1, int G);
+int gn_fused16_launch(const float* src0, const float* src1, int C0, int C1, const float* gamma, const float* beta, float eps,
+                      void* hi, void* lo, int B, int HW, int G, int act, hipStream_t s, int f8);
 int gn_apply16_launch(const float* src0, const float* src1, int C0, int C1, const float* nscale, const float* nshift,
                       void* hi, void* lo, int B, int HW, int act, hipStream_t s, int f8 = 0);
 static inline int precision_ns(int precision) {   // CSD_PREC_* -> number of fp16 planes (0: fp32 kernel)

@@ -262,6 +262,133 @@ __global__ __launch_bounds__(GA_THREADS) void gn_apply16_kernel(
   }
 }
 
+// GroupNorm statistics + affine + activation + fp16 split in ONE launch, for maps small enough that a workgroup keeps its share of a
+// sample in registers (the 10^2 / 5^2 levels and the narrower 20^2 tensors of SR3-160: three dependent launches of 5-10 us each -
+// gn_stats, gn_finalize, gn_apply16 - were pure latency there; reference models/layers.py:638,646,659,667 h = act(GroupNorm(h))).
+// One workgroup = (sample, GB consecutive groups = cb channels, cb % 8 == 0): thread (row, unit) owns the 8 channels of unit `unit` at
+// pixels row, row + rows, ...: ONE sweep over HBM/L2, per-channel (sum, sum of squares) in fp64, rows folded in a fixed order through
+// LDS, then mean / rstd per group, scale / shift per channel, and the arithmetic of gn_apply16_kernel on the registers.  Deterministic
+// and per-sample: a sample's bits do not depend on the batch it runs in.
+#define GNFU_THREADS 256
+#define GNFU_MAXS 6                                  // pixel sweeps a thread holds (48 floats)
+__global__ __launch_bounds__(GNFU_THREADS) void gn_fused16_kernel(
+    const float* __restrict__ src0, const float* __restrict__ src1, int C0, int C1, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, half8_t* __restrict__ hi, half8_t* __restrict__ lo, int HW, int G, int GB, int act,
+    int f8) {
+  __shared__ double sred[2][GNFU_THREADS * 8];
+  __shared__ double chs[2][GNFU_THREADS];
+  __shared__ float ssc[GNFU_THREADS], ssh[GNFU_THREADS];
+  const int C = C0 + C1, cpg = C / G, cb = cpg * GB, U = cb >> 3, rows = GNFU_THREADS / U;
+  const int t = threadIdx.x, pr = t / U, u = t - pr * U;
+  const int b = blockIdx.y, cbase = blockIdx.x * cb;
+  const int c = cbase + u * 8;                       // first of this thread's 8 channels
+  const bool active = pr < rows;
+  const float* src;
+  int Cs;
+  if (c < C0) { src = src0 + (size_t)b * HW * C0 + c; Cs = C0; }
+  else { src = src1 + (size_t)b * HW * C1 + (c - C0); Cs = C1; }
+  float v[GNFU_MAXS][8];
+  double s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0; q[j] = 0; }
+#pragma unroll
+  for (int k = 0; k < GNFU_MAXS; ++k) {
+    const int p = pr + k * rows;
+    if (active && p < HW) {
+      const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)p * Cs);
+      const float4 a1 = *reinterpret_cast<const float4*>(src + (size_t)p * Cs + 4);
+      v[k][0] = a0.x; v[k][1] = a0.y; v[k][2] = a0.z; v[k][3] = a0.w; v[k][4] = a1.x; v[k][5] = a1.y; v[k][6] = a1.z; v[k][7] = a1.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[j] += v[k][j]; q[j] += (double)v[k][j] * v[k][j]; }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sred[0][pr * cb + u * 8 + j] = s[j]; sred[1][pr * cb + u * 8 + j] = q[j]; }
+  }
+  __syncthreads();
+  if (t < cb) {                                      // rows folded per channel, in row order
+    double a = 0, bq = 0;
+    for (int r = 0; r < rows; ++r) { a += sred[0][r * cb + t]; bq += sred[1][r * cb + t]; }
+    chs[0][t] = a;
+    chs[1][t] = bq;
+  }
+  __syncthreads();
+  if (t < cb) {
+    const int g0 = (t / cpg) * cpg;
+    double gs = 0, gq = 0;
+    for (int j = 0; j < cpg; ++j) { gs += chs[0][g0 + j]; gq += chs[1][g0 + j]; }
+    const double n = (double)HW * cpg;
+    const double mean = gs / n;
+    double var = gq / n - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = rstd * gamma[cbase + t];
+    ssc[t] = sc;
+    ssh[t] = beta[cbase + t] - (float)mean * sc;
+  }
+  __syncthreads();
+  if (!active) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = ssc[u * 8 + j]; sh[j] = ssh[u * 8 + j]; }
+  const int C8 = C >> 3;
+  half8_t* hdst = hi + ((size_t)b * HW * C + c) / 8;
+  half8_t* ldst = lo ? lo + ((size_t)b * HW * C + c) / 8 : nullptr;
+#pragma unroll
+  for (int k = 0; k < GNFU_MAXS; ++k) {
+    const int p = pr + k * rows;
+    if (p < HW) {
+      half8_t h, l;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {                  // (the arithmetic of gn_apply16_kernel, to the letter)
+        float tv = v[k][j] * sc[j] + sh[j];
+        switch (act) {
+          case CSD_ACT_SWISH: tv = tv * __frcp_rn(1.0f + __expf(-tv)); break;
+          case CSD_ACT_RELU: tv = tv > 0.f ? tv : 0.f; break;
+          case CSD_ACT_LRELU: tv = tv > 0.f ? tv : 0.2f * tv; break;
+          case CSD_ACT_ELU: tv = tv > 0.f ? tv : expm1f(tv); break;
+          default: break;
+        }
+        h[j] = (_Float16)tv;
+        l[j] = (_Float16)(tv - (float)h[j]);
+        if (f8) {
+          const float hf = fminf(fmaxf((float)h[j], -448.f), 448.f), lf = fminf(fmaxf((tv - (float)h[j]) * 2048.f, -448.f), 448.f);
+          const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(lf, hf, 0, false);
+          l[j] = __builtin_bit_cast(_Float16, (unsigned short)(pk & 0xffff));
+        }
+      }
+      hdst[(size_t)p * C8] = h;
+      if (ldst) ldst[(size_t)p * C8] = l;
+    }
+  }
+}
+
+// groups per workgroup for the fused kernel (0: the tensor does not fit the one-sweep form)
+int gn_fused16_groups(int HW, int C0, int C1, int G) {
+  const int C = C0 + C1;
+  if (G <= 0 || C % G || C0 % 8 || C1 % 8) return 0;
+  const int cpg = C / G;
+  for (int GB = 1; GB <= G; GB *= 2) {
+    const int cb = cpg * GB;
+    if (G % GB || cb % 8) continue;
+    if (cb > GNFU_THREADS) return 0;
+    const int rows = GNFU_THREADS / (cb / 8);
+    return (HW + rows - 1) / rows <= GNFU_MAXS ? GB : 0;
+  }
+  return 0;
+}
+
+int gn_fused16_launch(const float* src0, const float* src1, int C0, int C1, const float* gamma, const float* beta, float eps,
+                      void* hi, void* lo, int B, int HW, int G, int act, hipStream_t s, int f8) {
+  const int GB = gn_fused16_groups(HW, C0, C1, G);
+  CSD_REQUIRE(GB > 0, "gn_fused16: %d pixels x %d+%d channels in %d groups does not fit the one-sweep form", HW, C0, C1, G);
+  hipLaunchKernelGGL(gn_fused16_kernel, dim3(G / GB, B), dim3(GNFU_THREADS), 0, s, src0, src1, C0, C1, gamma, beta, eps,
+                     static_cast<half8_t*>(hi), static_cast<half8_t*>(lo), HW, G, GB, act, f8);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
 int gn_apply16_launch(const float* src0, const float* src1, int C0, int C1, const float* nscale, const float* nshift,
                       void* hi, void* lo, int B, int HW, int act, hipStream_t s, int f8) {
   const int C = C0 + C1;

@@ -105,7 +105,7 @@ struct Net;
 // ---------------------------------------------------------------------------------------------
 // execution plan for one batch size
 // ---------------------------------------------------------------------------------------------
-enum OpKind { OP_ASSEMBLE, OP_TEMB, OP_FOURIER, OP_FIR, OP_GN_APPLY32, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_GN_FINAL_TILES, OP_GN_APPLY16, OP_CONV, OP_ATTN, OP_AVGPOOL,
+enum OpKind { OP_ASSEMBLE, OP_TEMB, OP_FOURIER, OP_FIR, OP_GN_APPLY32, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_GN_FINAL_TILES, OP_GN_APPLY16, OP_GN_FUSED16, OP_CONV, OP_ATTN, OP_AVGPOOL,
               OP_UPNEAR, OP_TO_NCHW, OP_TAPSUM };
 
 static const size_t NONE = (size_t)-1;
@@ -959,6 +959,19 @@ struct Builder {
       hi16 = alloc_(nh);
       if (pc.ns >= 2) lo16 = alloc_(nh);
       ap.out = hi16; ap.c = lo16;
+      // small maps: the GroupNorm's statistics + finalize launches (the two ops gn() has just pushed) and this pass become ONE launch
+      const size_t nops = pl.ops.size();
+      if (norm && nops >= 2 && pl.ops[nops - 2].kind == OP_GN_STATS && pl.ops[nops - 1].kind == OP_GN_FINAL &&
+          pl.ops[nops - 2].a == src0 && pl.ops[nops - 2].b == src1 && !CSD_TUNE_ENV("CSD_NO_GN_FUSED") &&
+          gn_fused16_groups(ih * iw, pc.proto.C0, pc.proto.C1, pl.ops[nops - 2].gp.G) > 0) {
+        ap.kind = OP_GN_FUSED16;
+        ap.gp = pl.ops[nops - 2].gp;
+        ap.pk0 = pl.ops[nops - 1].pk0; ap.pk1 = pl.ops[nops - 1].pk1;      // gamma, beta
+        ap.d = NONE; ap.e = NONE;
+        pl.ops.pop_back();
+        pl.ops.pop_back();
+        pl.launches -= 2;
+      }
       ap.cls = CSD_PROF_GN_APPLY;
       ap.bytes = (double)B * ih * iw * (o.cp.C0 + o.cp.C1) * (4 + 2 * (pc.ns >= 2 ? 2 : 1));
       ap.i3 = pc.ns == 3;                       // second plane = e4m3 byte pairs
@@ -1510,6 +1523,9 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         rc = gn_finalize_tiles_launch(reinterpret_cast<const double*>(W(o.a)), o.i0, o.i1,
                                       reinterpret_cast<const double*>(W(o.b)), o.i2, o.i3, B, o.i4, o.gp.G, pk + o.pk0,
                                       pk + o.pk1, 1e-6f, W(o.out), W(o.c), s);
+        break;
+      case OP_GN_FUSED16:
+        rc = gn_fused16_launch(W(o.a), W(o.b), o.i0, o.i1, pk + o.pk0, pk + o.pk1, 1e-6f, W(o.out), W(o.c), B, o.i2, o.gp.G, o.act, s, o.i3);
         break;
       case OP_GN_APPLY16:
         rc = gn_apply16_launch(W(o.a), W(o.b), o.i0, o.i1, W(o.d), W(o.e), W(o.out), W(o.c), B, o.i2, o.act, s, o.i3);
