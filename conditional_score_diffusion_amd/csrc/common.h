@@ -153,7 +153,8 @@ int tapsum_launch(const float* part, const float* bias, const float* res, float*
 // statistics + finalize + apply + split of a small map in one launch (norm.hip); gn_fused16_groups() == 0: use the three-launch form
 int gn_fused16_groups(int HW, int C0, int C1, int G);
 int gn_fused16_launch(const float* src0, const float* src1, int C0, int C1, const float* gamma, const float* beta, float eps,
-                      void* hi, void* lo, int B, int HW, int G, int act, hipStream_t s, int f8);
+                      void* hi, void* lo, int B, int HW, int G, int act, hipStream_t s, int f8, float* nscale = nullptr,
+                      float* nshift = nullptr);      // hi == nullptr: statistics only (scale / shift out)
 int gn_apply16_launch(const float* src0, const float* src1, int C0, int C1, const float* nscale, const float* nshift,
                       void* hi, void* lo, int B, int HW, int act, hipStream_t s, int f8 = 0);
 static inline int precision_ns(int precision) {   // CSD_PREC_* -> number of fp16 planes (0: fp32 kernel)

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(GA_THREADS) void gn_apply16_kernel(
 __global__ __launch_bounds__(GNFU_THREADS) void gn_fused16_kernel(
     const float* __restrict__ src0, const float* __restrict__ src1, int C0, int C1, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, half8_t* __restrict__ hi, half8_t* __restrict__ lo, int HW, int G, int GB, int act,
-    int f8) {
+    int f8, float* __restrict__ nscale, float* __restrict__ nshift) {
   __shared__ double sred[2][GNFU_THREADS * 8];
   __shared__ double chs[2][GNFU_THREADS];
   __shared__ float ssc[GNFU_THREADS], ssh[GNFU_THREADS];
@@ -326,7 +326,12 @@ __global__ __launch_bounds__(GNFU_THREADS) void gn_fused16_kernel(
     const float sc = rstd * gamma[cbase + t];
     ssc[t] = sc;
     ssh[t] = beta[cbase + t] - (float)mean * sc;
+    if (nscale) {                                    // statistics-only form: the per-(sample, channel) scale / shift for a consumer that applies them itself
+      nscale[(size_t)b * C + cbase + t] = ssc[t];
+      nshift[(size_t)b * C + cbase + t] = ssh[t];
+    }
   }
+  if (hi == nullptr) return;
   __syncthreads();
   if (!active) return;
   float sc[8], sh[8];
@@ -380,11 +385,11 @@ int gn_fused16_groups(int HW, int C0, int C1, int G) {
 }
 
 int gn_fused16_launch(const float* src0, const float* src1, int C0, int C1, const float* gamma, const float* beta, float eps,
-                      void* hi, void* lo, int B, int HW, int G, int act, hipStream_t s, int f8) {
+                      void* hi, void* lo, int B, int HW, int G, int act, hipStream_t s, int f8, float* nscale, float* nshift) {
   const int GB = gn_fused16_groups(HW, C0, C1, G);
   CSD_REQUIRE(GB > 0, "gn_fused16: %d pixels x %d+%d channels in %d groups does not fit the one-sweep form", HW, C0, C1, G);
   hipLaunchKernelGGL(gn_fused16_kernel, dim3(G / GB, B), dim3(GNFU_THREADS), 0, s, src0, src1, C0, C1, gamma, beta, eps,
-                     static_cast<half8_t*>(hi), static_cast<half8_t*>(lo), HW, G, GB, act, f8);
+                     static_cast<half8_t*>(hi), static_cast<half8_t*>(lo), HW, G, GB, act, f8, nscale, nshift);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }

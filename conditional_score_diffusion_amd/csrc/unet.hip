@@ -105,7 +105,7 @@ struct Net;
 // ---------------------------------------------------------------------------------------------
 // execution plan for one batch size
 // ---------------------------------------------------------------------------------------------
-enum OpKind { OP_ASSEMBLE, OP_TEMB, OP_FOURIER, OP_FIR, OP_GN_APPLY32, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_GN_FINAL_TILES, OP_GN_APPLY16, OP_GN_FUSED16, OP_CONV, OP_ATTN, OP_AVGPOOL,
+enum OpKind { OP_ASSEMBLE, OP_TEMB, OP_FOURIER, OP_FIR, OP_GN_APPLY32, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_GN_FINAL_TILES, OP_GN_APPLY16, OP_GN_FUSED16, OP_GN_STATFIN, OP_CONV, OP_ATTN, OP_AVGPOOL,
               OP_UPNEAR, OP_TO_NCHW, OP_TAPSUM };
 
 static const size_t NONE = (size_t)-1;
@@ -1116,6 +1116,33 @@ struct Builder {
   }
 };
 
+// after the walk: a GroupNorm whose statistics + finalize pair survived (its consumer applies scale / shift itself: the attention
+// blocks' q/k/v contraction, the last layer) becomes ONE launch when the map is small enough for the one-sweep kernel
+static void fold_small_gn_pairs(Plan& pl) {
+  if (CSD_TUNE_ENV("CSD_NO_GN_FUSED")) return;
+  std::vector<Op> out;
+  out.reserve(pl.ops.size());
+  for (size_t i = 0; i < pl.ops.size(); ++i) {
+    const Op& a = pl.ops[i];
+    if (a.kind == OP_GN_STATS && i + 1 < pl.ops.size() && pl.ops[i + 1].kind == OP_GN_FINAL &&
+        gn_fused16_groups(a.gp.HW, a.gp.C0, a.gp.C1, a.gp.G) > 0) {
+      const Op& f = pl.ops[i + 1];
+      Op o;
+      o.kind = OP_GN_STATFIN;
+      o.a = a.a; o.b = a.b; o.gp = a.gp;
+      o.pk0 = f.pk0; o.pk1 = f.pk1;
+      o.out = f.out; o.c = f.b;                       // nscale, nshift
+      o.cls = CSD_PROF_GN_STATS; o.bytes = a.bytes;
+      out.push_back(o);
+      pl.launches -= 1;
+      ++i;
+    } else {
+      out.push_back(a);
+    }
+  }
+  pl.ops.swap(out);
+}
+
 static int build_plan(Net& n, int B, Plan** out) {
   auto it = n.plans.find(B);
   if (it != n.plans.end()) { *out = it->second.get(); return CSD_OK; }
@@ -1313,6 +1340,7 @@ static int build_plan(Net& n, int B, Plan** out) {
     double pbytes1 = 0;
     for (auto& p : n.params) pbytes1 += 4.0 * p.numel;
     pl.bytes += pbytes1;
+    fold_small_gn_pairs(pl);
     pl.ws_floats = bd.ar.peak();
     *out = plp.get();
     n.plans[B] = std::move(plp);
@@ -1466,6 +1494,7 @@ static int build_plan(Net& n, int B, Plan** out) {
   double pbytes = 0;
   for (auto& p : n.params) pbytes += 4.0 * p.numel;
   pl.bytes += pbytes;
+  fold_small_gn_pairs(pl);
   pl.ws_floats = bd.ar.peak();
   *out = plp.get();
   n.plans[B] = std::move(plp);
@@ -1523,6 +1552,10 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         rc = gn_finalize_tiles_launch(reinterpret_cast<const double*>(W(o.a)), o.i0, o.i1,
                                       reinterpret_cast<const double*>(W(o.b)), o.i2, o.i3, B, o.i4, o.gp.G, pk + o.pk0,
                                       pk + o.pk1, 1e-6f, W(o.out), W(o.c), s);
+        break;
+      case OP_GN_STATFIN:
+        rc = gn_fused16_launch(W(o.a), W(o.b), o.gp.C0, o.gp.C1, pk + o.pk0, pk + o.pk1, 1e-6f, nullptr, nullptr, B, o.gp.HW, o.gp.G,
+                               CSD_ACT_NONE, s, 0, W(o.out), W(o.c));
         break;
       case OP_GN_FUSED16:
         rc = gn_fused16_launch(W(o.a), W(o.b), o.i0, o.i1, pk + o.pk0, pk + o.pk1, 1e-6f, W(o.out), W(o.c), B, o.i2, o.gp.G, o.act, s, o.i3);
