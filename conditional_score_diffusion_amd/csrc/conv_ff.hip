@@ -668,12 +668,15 @@ int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
   k.abl = CSD_TUNE_ENV("CSD_FF_ABL") ? atoi(CSD_TUNE_ENV("CSD_FF_ABL")) : 0;
   k.a.dbg = (k.abl & 128) ? g_ff_dbg : nullptr;
   const int nt = ff_nt(p.Cout);
-#ifdef CSD_TUNE
-  // round-3 development kernel (conv_fx.hip: one persistent 8-wave workgroup per CU, matrix waves + producer waves; at parity with this
-  // kernel, profiles/NOTEBOOK.md) - tuning build only, A/B with CSD_FX=1.  It carries one residual chunk in each of its first 2 nt stages.
-  static const bool use_fx = CSD_TUNE_ENV("CSD_FX") != nullptr;
-  if (ns == 3 && use_fx && k.nstage >= 2 * nt) return convfx_launch(k, nt, s);
-#endif
+  // conv_fx.hip (one persistent 8-wave workgroup per CU: four matrix waves + four producer waves, whole-stage weight buffers): 4-5 %
+  // faster than this kernel on the layers with a long K loop (>= 192 input channels: the up path's Conv_0 on the virtual concat), at
+  // parity or slower on the 96-channel ones (profiles/NOTEBOOK.md).  It carries one residual chunk in each of its first 2 nt stages.
+  // Tuning build: CSD_FX=1 forces it for every fp16f8 layer, CSD_FX=0 disables it.
+  {
+    const char* fx = CSD_TUNE_ENV("CSD_FX");
+    const bool use_fx = fx ? atoi(fx) != 0 : k.nstage >= 12;
+    if (ns == 3 && use_fx && k.nstage >= 2 * nt) return convfx_launch(k, nt, s);
+  }
   const bool norm = a.nscale != nullptr;
 #define FF_DISPATCH(NT_)                                                                                            \
   if (ns == 1) return norm ? launch_ff<1, NT_, false, true>(k, s) : launch_ff<1, NT_, false, false>(k, s);       \
