@@ -464,20 +464,11 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
   FF_TS();
   // ---- GroupNorm partials of the written tile: (sum, sum of squares) per cout over its 256 pixels ----
   if (a_stats) {
-    constexpr int NV = NT * 16;
-    float vs[NV], vq[NV];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float a0 = acc[0][nt][r], a1 = acc[1][nt][r];
-        vs[nt * 16 + r] = a0 + a1;
-        vq[nt * 16 + r] = a0 * a0 + a1 * a1;
-      }
-    // halving butterfly over the 32 pixel lanes of a K half: after the step of a lane bit a lane keeps the lower (bit clear)
-    // or upper (bit set) half of the values, summed with its partner's copy of that half
-    // lane bits 0 and 1 first (the two big steps: 24 + 12 values) - their partners sit in the same quad, so the exchange is a
-    // DPP quad_perm move at VALU rate; bits 2 and 3 (6 + 3 values) and the plain exchange over bit 4 go through ds_bpermute
+    // halving butterfly over the 32 pixel lanes of a K half, one cout tile (16 values per lane) at a time: after the step of a lane bit a
+    // lane keeps the lower (bit clear) or upper (bit set) half of the values, summed with its partner's copy of that half.  Lane bits 0
+    // and 1 first - their partners sit in the same quad, so the exchange is a DPP quad_perm move at VALU rate; bits 2, 3 and the plain
+    // exchange over bit 4 go through ds_bpermute.  (Per value the same additions in the same order as one 48-value butterfly - same
+    // bits - with a third of the live registers.)
 #define FF_HALVE(XCHG, BIT, H)                                                                   \
     {                                                                                            \
       const bool up = (lane >> BIT) & 1;                                                         \
@@ -490,33 +481,33 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
     }
 #define FF_X_DPP(v, BIT) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), (BIT) == 0 ? 0xB1 : 0x4E, 0xF, 0xF, true))
 #define FF_X_SHFL(v, BIT) __shfl_xor(v, 1 << (BIT))
-    FF_HALVE(FF_X_DPP, 0, NV / 2)
-    FF_HALVE(FF_X_DPP, 1, NV / 4)
-    FF_HALVE(FF_X_SHFL, 2, NV / 8)
-    FF_HALVE(FF_X_SHFL, 3, NV / 16)
+    float* const red = reinterpret_cast<float*>(smem);       // [4 waves][NT*32 couts][2] (the patch buffers are dead)
+    __syncthreads();                                   // everyone is done with the patch / ring
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float vs[16], vq[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float a0 = acc[0][nt][r], a1 = acc[1][nt][r];
+        vs[r] = a0 + a1;
+        vq[r] = a0 * a0 + a1 * a1;
+      }
+      FF_HALVE(FF_X_DPP, 0, 8)
+      FF_HALVE(FF_X_DPP, 1, 4)
+      FF_HALVE(FF_X_SHFL, 2, 2)
+      FF_HALVE(FF_X_SHFL, 3, 1)
+      vs[0] += __shfl_xor(vs[0], 16);
+      vq[0] += __shfl_xor(vq[0], 16);
+      if ((lane & 16) == 0) {
+        const int r = (lane & 1) * 8 + ((lane >> 1) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1);
+        const int cl = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        red[(wave * NT * 32 + cl) * 2 + 0] = vs[0];
+        red[(wave * NT * 32 + cl) * 2 + 1] = vq[0];
+      }
+    }
 #undef FF_HALVE
 #undef FF_X_DPP
 #undef FF_X_SHFL
-    constexpr int NF = NV / 16;                        // values left per lane (3 or 4); bit 0: plain exchange
-    float* const red = reinterpret_cast<float*>(smem);       // [4 waves][NT*32 couts][2] (the patch buffers are dead)
-#pragma unroll
-    for (int i = 0; i < NF; ++i) {
-      vs[i] += __shfl_xor(vs[i], 16);
-      vq[i] += __shfl_xor(vq[i], 16);
-    }
-    __syncthreads();                                   // everyone is done with the patch / ring
-    if ((lane & 16) == 0) {
-      const int sel = (lane & 1) * (NV / 2) + ((lane >> 1) & 1) * (NV / 4) + ((lane >> 2) & 1) * (NV / 8) +
-                      ((lane >> 3) & 1) * (NV / 16);
-#pragma unroll
-      for (int i = 0; i < NF; ++i) {
-        const int idx = sel + i;                       // = nt*16 + r
-        const int nt = idx >> 4, r = idx & 15;
-        const int cl = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        red[(wave * NT * 32 + cl) * 2 + 0] = vs[i];
-        red[(wave * NT * 32 + cl) * 2 + 1] = vq[i];
-      }
-    }
     __syncthreads();
     if (tid < NT * 32) {
       double s = 0.0, q = 0.0;
