@@ -263,7 +263,8 @@ def main():
         elif args.precision == 'fp16f8':
             dom_kernel, dom_peak = ('3x3 stride-1 convolution class: conv_ff_kernel<NS=2,F8> (fused GroupNorm+SiLU+split prologue, LDS-DMA weight '
                                     'ring; hi*hi on v_mfma_f32_32x32x16_f16, the two correction products K-concatenated on '
-                                    'v_mfma_scale_f32_32x32x64_f8f6f4; the 160^2 / 80^2 levels) + conv_f16_q_kernel<NS=2> (40^2 and below, '
+                                    'v_mfma_scale_f32_32x32x64_f8f6f4; the 160^2 / 80^2 levels; its persistent matrix-wave / producer-wave form conv_fx_kernel on '
+                                    'the >= 192-channel layers) + conv_f16_q_kernel<NS=2> (40^2 and below, '
                                     '3 fp16 MFMAs per product)'), F16_MFMA_PEAK_TF / 2
             dom_note = ('fp16 MFMA dense peak (2500 TF) / 2: one fp16 MFMA per product + two correction products at the fp8 rate '
                         '(half an fp16 MFMA each); achieved counts algorithmic flops')
@@ -282,7 +283,7 @@ def main():
         # HBM traffic of the same kernel class from PMC counters (a separate rocprofv3 pass cannot run inside this
         # process): the committed summary of tools/pmc_hbm.sh for this mode, bytes per launch like `achieved`
         traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_hbm_traffic_%s.json' % args.precision)
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_hbm_traffic_%s.json' % args.precision)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic = tj['conv3x3_class']['hbm_bytes_per_launch']

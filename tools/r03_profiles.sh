@@ -11,7 +11,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python $R/be
 f=$(find $O/trace -name '*kernel_stats.csv' | head -1); cp $f $O/kernel_stats.csv
 t=$(find $O/trace -name '*kernel_trace.csv' | head -1)
 python $R/tools/prof_summary.py trace $t csd:: > $O/kernel_trace_summary.txt
-python $R/tools/trace_list.py $t > $O/timeline_sampling_fp16f8.txt 2>/dev/null
 rm -rf $O/trace
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/sq -- python $R/bench.py --steps 1 --warmup 0 --no-alt --no-cpu-baseline > /dev/null 2>&1
 f=$(find $O/sq -name '*counter_collection.csv' | head -1)
@@ -20,3 +19,5 @@ rm -rf $O/sq
 cd $R
 bash tools/pmc_hbm.sh fp16f8 r03_fp16f8
 python tools/hbm_traffic.py r03_fp16f8 $O/hbm_traffic_fp16f8.json > $O/hbm_traffic_fp16f8.txt
+bash tools/timeline_run.sh fp16f8 r03_sampling_fp16f8
+cp gpurun_out/timeline_r03_sampling_fp16f8.txt $O/ 2>/dev/null
