@@ -149,6 +149,13 @@ int pw16_taps_cout(int cout);
 int pw16_pack_weight_taps(const ConvPlan& p, int ns, const float* w, int cout, void* wpack, hipStream_t s);
 int tapsum_launch(const float* part, const float* bias, const float* res, float* out, int B, int H, int W, int cout, int nchw,
                   float out_scale, hipStream_t s);
+// stem.hip: cat(x, y [+ sigma z]) + 2v - 1 + NCHW -> NHWC + the first 3 x 3 conv (<= 8 -> Cout channels) + GroupNorm tile partials, one launch
+bool stem_supported(int Cx, int Cy, int Cout, int S, int ns);
+size_t stem_packed_bytes(int Cout, int ns);
+int stem_pack_weight(const float* w, int Cin, int Cout, int ns, void* wpack, hipStream_t s);
+int stem_tiles_per_image(int S);
+int stem_launch(const float* x, const float* y, const float* y_noise, float y_sigma, const void* wpack, const float* bias, float* out,
+                double* stats, int B, int Cx, int Cy, int Cout, int S, int centered, int ns, hipStream_t s);
 // y16 = fp16 split of act(x*scale + shift): hi plane (and lo plane when ns == 2), NHWC halves [B*HW][C0+C1]
 // statistics + finalize + apply + split of a small map in one launch (norm.hip); gn_fused16_groups() == 0: use the three-launch form
 int gn_fused16_groups(int HW, int C0, int C1, int G);

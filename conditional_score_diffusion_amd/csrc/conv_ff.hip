@@ -244,61 +244,50 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
 
 
   // ---- accumulators start at (bias + temb) * 2^8 ----
-  // lane = pixel p32 of each M tile; its 16 results of cout tile nt are couts nt*32 + 8q + 4kh + i (q = r >> 2, i = r & 3)
-  const int c_lane = ng * NT * 32 + kh * 4;
+  // The PIXELS are the MFMA's M operand, the couts its N operand: a lane holds ONE cout (nt*32 + p32) of 16 pixels of each M tile -
+  // register r = pixel 8 (r / 4) + 4 kh + r % 4 of the tile's 32 (4 rows x 8 columns) - so every residual load and output store of a
+  // wave covers whole 128-byte lines (tools/store_probe.hip: 5.4 TB/s against 3.3 TB/s for the weights-as-M layout, whose lanes own
+  // 16-byte pieces that four different instructions assemble into a line), and the GroupNorm partials are in-lane sums.
+  const int c_lane = ng * NT * 32 + p32;
   floatx16 acc[2][NT];
   {
-    float4 bv[NT * 4];                               // (all loads of a kind in one straight-line burst)
+    float bv[NT];
 #pragma unroll
-    for (int i = 0; i < NT * 4; ++i) bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a_bias) {
-#pragma unroll
-      for (int i = 0; i < NT * 4; ++i) bv[i] = gload4f(a_bias + c_lane + (i >> 2) * 32 + (i & 3) * 8);
-    }
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = a_bias ? a_bias[c_lane + nt * 32] : 0.f;
     if (a_temb) {
-      float4 tv[NT * 4];
 #pragma unroll
-      for (int i = 0; i < NT * 4; ++i) tv[i] = gload4f(a_temb + (size_t)b * a_temb_stride + c_lane + (i >> 2) * 32 + (i & 3) * 8);
-#pragma unroll
-      for (int i = 0; i < NT * 4; ++i) bv[i] = make_float4(bv[i].x + tv[i].x, bv[i].y + tv[i].y, bv[i].z + tv[i].z, bv[i].w + tv[i].w);
+      for (int nt = 0; nt < NT; ++nt) bv[nt] += a_temb[(size_t)b * a_temb_stride + c_lane + nt * 32];
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          acc[mt][nt][q * 4 + 0] = bv[nt * 4 + q].x * acc_in; acc[mt][nt][q * 4 + 1] = bv[nt * 4 + q].y * acc_in;
-          acc[mt][nt][q * 4 + 2] = bv[nt * 4 + q].z * acc_in; acc[mt][nt][q * 4 + 3] = bv[nt * 4 + q].w * acc_in;
-        }
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bv[nt] * acc_in;
   }
   // the residual (the block's shortcut) joins the accumulators HERE, not in the epilogue: its loads travel under the first
   // stage's patch round trip, the epilogue is scale + store only (it used to spend ~10 k cycles per tile on issue -> wait -> add)
   constexpr unsigned OOB = 0x80000000u;
   constexpr int RSRC_FLAGS = 0x00020000;
   const size_t tile_pix = img0 + (size_t)ty0 * kW + tx0;
-  int opix[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) opix[mt] = (4 * wave + (p32 >> 3)) * kW + 8 * mt + (p32 & 7);
+  // output / residual element of register r of M tile mt: pixel row 4 wave + r / 4, column 8 mt + 4 kh + r % 4, cout c_lane + 32 nt
+  // (buffer addressing: the lane part - K half and cout - is ONE voffset register per tensor, the register's pixel a scalar soffset)
+  auto upix = [&](int mt, int r) __attribute__((always_inline)) { return (4 * wave + (r >> 2)) * kW + 8 * mt + (r & 3); };      // uniform
   if (a_res != nullptr && !FF_ABL(8)) {
     const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_res + tile_pix * kCout), 0, OOB, RSRC_FLAGS);
+    const unsigned res_voff = (unsigned)(4 * kh * kCout + c_lane) * 4u;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {                 // (one M tile at a time: 48 registers of loads in flight, not 96)
-      uint4f rv[NT][4];
+      float rv[NT][16];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          rv[nt][q] = __builtin_amdgcn_raw_buffer_load_b128(res_r, (unsigned)(opix[mt] * kCout + c_lane + nt * 32 + q * 8) * 4u, 0, 0);
+        for (int r = 0; r < 16; ++r)
+          rv[nt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(res_r, res_voff, (unsigned)(upix(mt, r) * kCout + nt * 32) * 4u, 0));
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[mt][nt][q * 4 + 0] += __uint_as_float(rv[nt][q].x) * acc_in;
-          acc[mt][nt][q * 4 + 1] += __uint_as_float(rv[nt][q].y) * acc_in;
-          acc[mt][nt][q * 4 + 2] += __uint_as_float(rv[nt][q].z) * acc_in;
-          acc[mt][nt][q * 4 + 3] += __uint_as_float(rv[nt][q].w) * acc_in;
-        }
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] += rv[nt][r] * acc_in;
     }
   }
 
@@ -385,10 +374,10 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
       // MFMAs on ONE accumulator stay back to back (tools/mfma_chain.hip: 2465 TF/s against 2218 round-robin).
       auto mma = [&](int mt, int nt) __attribute__((always_inline)) {
         if constexpr (NS == 2 && !F8) {              // small terms first: lo*hi, hi*lo, then hi*hi
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][nt][1], xb[cur][mt][0], acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][nt][0], xb[cur][mt][1], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xb[cur][mt][0], wa[cur][nt][1], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xb[cur][mt][1], wa[cur][nt][0], acc[mt][nt], 0, 0, 0);
         }
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][nt][0], xb[cur][mt][0], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xb[cur][mt][0], wa[cur][nt][0], acc[mt][nt], 0, 0, 0);
       };
       __builtin_amdgcn_sched_barrier(0);
       FF_FS(step * 5 + 0);
@@ -414,8 +403,8 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
       if constexpr (F8) {
 #pragma unroll
         for (int i = 0; i < (corr ? 2 * NT : 0); ++i) {
-          acc[i / NT][i % NT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa8[i % NT], xb8[i / NT], acc[i / NT][i % NT], 0, 0, 0,
-                                                                                  116, 0, 127);      // block scale 2^-11 on A
+          acc[i / NT][i % NT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xb8[i / NT], wa8[i % NT], acc[i / NT][i % NT], 0, 0, 0,
+                                                                                  127, 0, 116);      // block scale 2^-11 on B (the weights)
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -442,6 +431,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
   const __amdgpu_buffer_rsrc_t out_r =
       __builtin_amdgcn_make_buffer_rsrc(a_out + tile_pix * a_out_stride + a_out_coff, 0, OOB, RSRC_FLAGS);
   if (FF_ABL(16)) return;
+  const unsigned out_voff = (unsigned)(4 * kh * a_out_stride + c_lane) * 4u;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -453,61 +443,31 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        uint4f ov;
-        ov.x = __float_as_uint(acc[mt][nt][q * 4 + 0]); ov.y = __float_as_uint(acc[mt][nt][q * 4 + 1]);
-        ov.z = __float_as_uint(acc[mt][nt][q * 4 + 2]); ov.w = __float_as_uint(acc[mt][nt][q * 4 + 3]);
-        const unsigned off = (unsigned)(opix[mt] * a_out_stride + c_lane + nt * 32 + q * 8) * 4u;
-        __builtin_amdgcn_raw_buffer_store_b128(ov, out_r, off, 0, 0);
-      }
+      for (int r = 0; r < 16; ++r)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][r]), out_r, out_voff, (unsigned)(upix(mt, r) * a_out_stride + nt * 32) * 4u, 0);
 
   FF_TS();
   // ---- GroupNorm partials of the written tile: (sum, sum of squares) per cout over its 256 pixels ----
   if (a_stats) {
-    // halving butterfly over the 32 pixel lanes of a K half, one cout tile (16 values per lane) at a time: after the step of a lane bit a
-    // lane keeps the lower (bit clear) or upper (bit set) half of the values, summed with its partner's copy of that half.  Lane bits 0
-    // and 1 first - their partners sit in the same quad, so the exchange is a DPP quad_perm move at VALU rate; bits 2, 3 and the plain
-    // exchange over bit 4 go through ds_bpermute.  (Per value the same additions in the same order as one 48-value butterfly - same
-    // bits - with a third of the live registers.)
-#define FF_HALVE(XCHG, BIT, H)                                                                   \
-    {                                                                                            \
-      const bool up = (lane >> BIT) & 1;                                                         \
-      _Pragma("unroll") for (int i = 0; i < H; ++i) {                                            \
-        const float ss = up ? vs[i] : vs[i + H], ks = up ? vs[i + H] : vs[i];                    \
-        const float sq = up ? vq[i] : vq[i + H], kq = up ? vq[i + H] : vq[i];                    \
-        vs[i] = ks + XCHG(ss, BIT);                                                              \
-        vq[i] = kq + XCHG(sq, BIT);                                                              \
-      }                                                                                          \
-    }
-#define FF_X_DPP(v, BIT) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), (BIT) == 0 ? 0xB1 : 0x4E, 0xF, 0xF, true))
-#define FF_X_SHFL(v, BIT) __shfl_xor(v, 1 << (BIT))
+    // in-lane over a lane's 32 pixels (16 registers x 2 M tiles), one exchange between the K halves, the four waves through LDS
     float* const red = reinterpret_cast<float*>(smem);       // [4 waves][NT*32 couts][2] (the patch buffers are dead)
     __syncthreads();                                   // everyone is done with the patch / ring
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      float vs[16], vq[16];
+      float vs = 0.f, vq = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float a0 = acc[0][nt][r], a1 = acc[1][nt][r];
-        vs[r] = a0 + a1;
-        vq[r] = a0 * a0 + a1 * a1;
+        vs += a0 + a1;
+        vq += a0 * a0 + a1 * a1;
       }
-      FF_HALVE(FF_X_DPP, 0, 8)
-      FF_HALVE(FF_X_DPP, 1, 4)
-      FF_HALVE(FF_X_SHFL, 2, 2)
-      FF_HALVE(FF_X_SHFL, 3, 1)
-      vs[0] += __shfl_xor(vs[0], 16);
-      vq[0] += __shfl_xor(vq[0], 16);
-      if ((lane & 16) == 0) {
-        const int r = (lane & 1) * 8 + ((lane >> 1) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1);
-        const int cl = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        red[(wave * NT * 32 + cl) * 2 + 0] = vs[0];
-        red[(wave * NT * 32 + cl) * 2 + 1] = vq[0];
+      vs += __shfl_xor(vs, 32);
+      vq += __shfl_xor(vq, 32);
+      if (kh == 0) {
+        red[(wave * NT * 32 + nt * 32 + p32) * 2 + 0] = vs;
+        red[(wave * NT * 32 + nt * 32 + p32) * 2 + 1] = vq;
       }
     }
-#undef FF_HALVE
-#undef FF_X_DPP
-#undef FF_X_SHFL
     __syncthreads();
     if (tid < NT * 32) {
       double s = 0.0, q = 0.0;

@@ -279,10 +279,9 @@ __global__ __launch_bounds__(FX_THREADS, 1) void conv_fx_kernel(const char* __re
   // =======================================================================================================================
   constexpr unsigned OOB = 0x80000000u;
   constexpr int RSRC_FLAGS = 0x00020000;
-  int opix[2], base[2], base8[2];
+  int base[2], base8[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
-    opix[mt] = (4 * wave + (p32 >> 3)) * kW + 8 * mt + (p32 & 7);
     base[mt] = (4 * wave + (p32 >> 3)) * FF_RS + (8 * mt + (p32 & 7)) * FF_PSB + kh * 16;
     base8[mt] = (4 * wave + (p32 >> 3)) * FF_RS + (8 * mt + (p32 & 7)) * FF_PSB + 32;
   }
@@ -297,31 +296,33 @@ __global__ __launch_bounds__(FX_THREADS, 1) void conv_fx_kernel(const char* __re
     FX_TS();
     const Tile nxt = tile_at(it + 1);
     const bool has_next = nxt.w >= 0;
-    const int c_lane = cur.ng * NT * 32 + kh * 4;
-    // ---- accumulators start at (bias + temb) * acc_in; the residual joins them during the last stage ----
+    // the PIXELS are the MFMA's M operand (conv_ff.hip): a lane holds ONE cout (nt*32 + p32) of 16 pixels of each M tile - register r =
+    // pixel row 4 wave + r / 4, column 8 mt + 4 kh + r % 4 - so residual loads and output stores cover whole 128-byte lines and the
+    // GroupNorm partials are in-lane sums
+    const int c_lane = cur.ng * NT * 32 + p32;
+    // ---- accumulators start at (bias + temb) * acc_in; the residual joins them during the first stages ----
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt) {
+      const float bq = btl[nt * 32 + p32];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 bq = *reinterpret_cast<const float4*>(btl + nt * 32 + q * 8 + kh * 4);
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          acc[mt][nt][q * 4 + 0] = bq.x * acc_in; acc[mt][nt][q * 4 + 1] = bq.y * acc_in;
-          acc[mt][nt][q * 4 + 2] = bq.z * acc_in; acc[mt][nt][q * 4 + 3] = bq.w * acc_in;
-        }
-      }
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bq * acc_in;
+    }
     const __amdgpu_buffer_rsrc_t res_r =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_res ? a_res + cur.pix * kCout : a_out), 0, OOB, RSRC_FLAGS);
 
-    uint4f rr[2][4];                                 // residual chunks in flight (even / odd chunk index)
+    float rr[2][16];                                 // residual chunks in flight (even / odd chunk index)
+    const unsigned res_voff = (unsigned)(4 * kh * kCout + c_lane) * 4u;
+    auto upix = [&](int mt, int r) __attribute__((always_inline)) { return (4 * wave + (r >> 2)) * kW + 8 * mt + (r & 3); };      // uniform
     auto res_load = [&](auto c_tag) __attribute__((always_inline)) {
       constexpr int CI = decltype(c_tag)::value, mt = CI / NT, nt = CI % NT;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        rr[CI & 1][q] = __builtin_amdgcn_raw_buffer_load_b128(res_r, (unsigned)(opix[mt] * kCout + c_lane + nt * 32 + q * 8) * 4u, 0, 0);
+      for (int r = 0; r < 16; ++r)
+        rr[CI & 1][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(res_r, res_voff, (unsigned)(upix(mt, r) * kCout + nt * 32) * 4u, 0));
     };
     if (a_res != nullptr) res_load(std::integral_constant<int, 0>{});
-    // One stage (9 taps x 16 channels).  RC >= 0: the residual's (M tile, cout tile) chunk RC (4 x 16 bytes per lane) is requested at the
+    // One stage (9 taps x 16 channels).  RC >= 0: the residual's (M tile, cout tile) chunk RC (16 dwords per lane) is requested at the
     // top of the stage and added after its last tap - an HBM round trip under a whole stage of matrix work.  RC is a compile-time
     // constant (the first 2 NT stages of a tile are unrolled): a run-time accumulator selection would put branches into the K loop.
     auto stage = [&](auto rc_tag) __attribute__((always_inline)) {
@@ -371,12 +372,12 @@ __global__ __launch_bounds__(FX_THREADS, 1) void conv_fx_kernel(const char* __re
         const bool corr = (tap & 1) == 0;            // taps 0, 2, 4, 6 bring their right neighbour, tap 8 goes alone
 #pragma unroll
         for (int i = 0; i < 2 * NT; ++i)
-          acc[i / NT][i % NT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cb3][i % NT], xb[cb3][i / NT], acc[i / NT][i % NT], 0, 0, 0);
+          acc[i / NT][i % NT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xb[cb3][i / NT], wa[cb3][i % NT], acc[i / NT][i % NT], 0, 0, 0);
         if (corr) {
 #pragma unroll
           for (int i = 0; i < 2 * NT; ++i)
-            acc[i / NT][i % NT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa8[i % NT], xb8[i / NT], acc[i / NT][i % NT], 0, 0, 0,
-                                                                                    116, 0, 127);      // block scale 2^-11 on A
+            acc[i / NT][i % NT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xb8[i / NT], wa8[i % NT], acc[i / NT][i % NT], 0, 0, 0,
+                                                                                    127, 0, 116);      // block scale 2^-11 on B (the weights)
         } else if (tap + 1 < 9) {
           ld8(tap + 1);                              // the next pair's fp8 fragments, one tap ahead (single register set)
         }
@@ -385,12 +386,7 @@ __global__ __launch_bounds__(FX_THREADS, 1) void conv_fx_kernel(const char* __re
         if (do_res) {
           constexpr int mt = RC / NT, nt = RC % NT;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            acc[mt][nt][q * 4 + 0] += __uint_as_float(rr[RC & 1][q].x) * acc_in;
-            acc[mt][nt][q * 4 + 1] += __uint_as_float(rr[RC & 1][q].y) * acc_in;
-            acc[mt][nt][q * 4 + 2] += __uint_as_float(rr[RC & 1][q].z) * acc_in;
-            acc[mt][nt][q * 4 + 3] += __uint_as_float(rr[RC & 1][q].w) * acc_in;
-          }
+          for (int r = 0; r < 16; ++r) acc[mt][nt][r] += rr[RC & 1][r] * acc_in;
         }
       }
       FX_TS();
@@ -417,62 +413,35 @@ __global__ __launch_bounds__(FX_THREADS, 1) void conv_fx_kernel(const char* __re
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = acc[mt][nt][r] * acc_out * a_out_scale;
+    const unsigned out_voff = (unsigned)(4 * kh * a_out_stride + c_lane) * 4u;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          uint4f ov;
-          ov.x = __float_as_uint(acc[mt][nt][q * 4 + 0]); ov.y = __float_as_uint(acc[mt][nt][q * 4 + 1]);
-          ov.z = __float_as_uint(acc[mt][nt][q * 4 + 2]); ov.w = __float_as_uint(acc[mt][nt][q * 4 + 3]);
-          const unsigned off = (unsigned)(opix[mt] * a_out_stride + c_lane + nt * 32 + q * 8) * 4u;
-          __builtin_amdgcn_raw_buffer_store_b128(ov, out_r, off, 0, 0);
-        }
+        for (int r = 0; r < 16; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][r]), out_r, out_voff, (unsigned)(upix(mt, r) * a_out_stride + nt * 32) * 4u, 0);
     FX_TS();
 
-    // ---- GroupNorm partials of the written tile: (sum, sum of squares) per cout over its 256 pixels (the reduction tree of conv_ff:
-    // same order, same bits) ----
+    // ---- GroupNorm partials of the written tile: (sum, sum of squares) per cout over its 256 pixels (conv_ff's order: in-lane over the
+    // lane's 32 pixels, one exchange between the K halves, the four matrix waves through LDS) ----
     if (a_stats) {
-      // one cout tile at a time (16 values per lane): the same exchange order per value as conv_ff's 48-value butterfly - same bits -
-      // with a third of the live registers
-#define FX_X_DPP(v, BIT) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), (BIT) == 0 ? 0xB1 : 0x4E, 0xF, 0xF, true))
-#define FX_X_SHFL(v, BIT) __shfl_xor(v, 1 << (BIT))
-#define FX_HALVE(XCHG, BIT, H)                                                                   \
-      {                                                                                          \
-        const bool up = (lane >> BIT) & 1;                                                       \
-        _Pragma("unroll") for (int i = 0; i < H; ++i) {                                          \
-          const float ss = up ? vs[i] : vs[i + H], ks = up ? vs[i + H] : vs[i];                  \
-          const float sq = up ? vq[i] : vq[i + H], kq = up ? vq[i + H] : vq[i];                  \
-          vs[i] = ks + XCHG(ss, BIT);                                                            \
-          vq[i] = kq + XCHG(sq, BIT);                                                            \
-        }                                                                                        \
-      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        float vs[16], vq[16];
+        float vs = 0.f, vq = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float a0 = acc[0][nt][r], a1 = acc[1][nt][r];
-          vs[r] = a0 + a1;
-          vq[r] = a0 * a0 + a1 * a1;
+          vs += a0 + a1;
+          vq += a0 * a0 + a1 * a1;
         }
-        FX_HALVE(FX_X_DPP, 0, 8)
-        FX_HALVE(FX_X_DPP, 1, 4)
-        FX_HALVE(FX_X_SHFL, 2, 2)
-        FX_HALVE(FX_X_SHFL, 3, 1)
-        vs[0] += __shfl_xor(vs[0], 16);
-        vq[0] += __shfl_xor(vq[0], 16);
-        if ((lane & 16) == 0) {
-          const int r = (lane & 1) * 8 + ((lane >> 1) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1);
-          const int cl = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          red[(wave * NT * 32 + cl) * 2 + 0] = vs[0];
-          red[(wave * NT * 32 + cl) * 2 + 1] = vq[0];
+        vs += __shfl_xor(vs, 32);
+        vq += __shfl_xor(vq, 32);
+        if (kh == 0) {
+          red[(wave * NT * 32 + nt * 32 + p32) * 2 + 0] = vs;
+          red[(wave * NT * 32 + nt * 32 + p32) * 2 + 1] = vq;
         }
       }
-#undef FX_HALVE
-#undef FX_X_DPP
-#undef FX_X_SHFL
       ff_barrier();
       if (tid < NT * 32) {
         double sm = 0.0, sq = 0.0;

@@ -95,6 +95,7 @@ struct PackedConv {
   bool ff = false;               // ns != 0 and the layer runs on the fused-prologue kernel (conv_ff.hip): fp32 sources, no gn_apply16
   int tap_cout = 0;              // pw and the layer is a 3x3 convolution with tap_cout (<= 6) output channels in its tap-partial form (conv_pw16.hip):
                                  // proto is the POINTWISE contraction to 9 * tap_cout partial channels, a 9-tap gather finishes it
+  bool stem = false;             // the DDPM-family first layer fused with the input assembly (stem.hip): x, y (NCHW) -> nf channels NHWC
   bool up4 = false;              // q and the layer is the nearest-x2 Upsample conv in its phase-decomposed form (4 x 2x2 taps; conv_f16_q.hip UP4)
   struct Src { int param_w, param_b, layout, cout_src, cout_off, cin_src; };
   std::vector<Src> srcs;
@@ -105,7 +106,7 @@ struct Net;
 // ---------------------------------------------------------------------------------------------
 // execution plan for one batch size
 // ---------------------------------------------------------------------------------------------
-enum OpKind { OP_ASSEMBLE, OP_TEMB, OP_FOURIER, OP_FIR, OP_GN_APPLY32, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_GN_FINAL_TILES, OP_GN_APPLY16, OP_GN_FUSED16, OP_GN_STATFIN, OP_CONV, OP_ATTN, OP_AVGPOOL,
+enum OpKind { OP_ASSEMBLE, OP_STEM, OP_TEMB, OP_FOURIER, OP_FIR, OP_GN_APPLY32, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_GN_FINAL_TILES, OP_GN_APPLY16, OP_GN_FUSED16, OP_GN_STATFIN, OP_CONV, OP_ATTN, OP_AVGPOOL,
               OP_UPNEAR, OP_TO_NCHW, OP_TAPSUM };
 
 static const size_t NONE = (size_t)-1;
@@ -600,9 +601,22 @@ static int build_packed_layout(Net& n) {
   int rc;
   if (c.arch == 0) {
     Module& m = next_mod();   // stem: Cin padded to 8 (zero weights for the padding channels)
-    rc = add_conv(std::to_string(m.idx), n.in_cpad, 0, m.cout, 9,
-                  {{n.P(mname(m.idx, "weight")), n.P(mname(m.idx, "bias")), 0, m.cout, 0, m.cin}});
-    if (rc) return rc;
+    if (net_ns && m.cin == c.x_channels + c.y_channels && stem_supported(c.x_channels, c.y_channels, m.cout, c.image_size, net_ns)) {
+      // fp16 modes: input assembly + first conv + the next GroupNorm's partials as one launch (stem.hip)
+      PackedConv pc;
+      if ((rc = proto_conv(&pc.proto, n.in_cpad, 0, m.cout, 9))) return rc;
+      pc.ns = net_ns;
+      pc.stem = true;
+      pc.w_off = take(stem_packed_bytes(m.cout, net_ns) / sizeof(float) + 1);
+      pc.b_off = take((size_t)pc.proto.CoutPad + 96);
+      pc.srcs = {{n.P(mname(m.idx, "weight")), n.P(mname(m.idx, "bias")), 0, m.cout, 0, m.cin}};
+      n.pconv_by_name[std::to_string(m.idx)] = (int)n.pconvs.size();
+      n.pconvs.push_back(pc);
+    } else {
+      rc = add_conv(std::to_string(m.idx), n.in_cpad, 0, m.cout, 9,
+                    {{n.P(mname(m.idx, "weight")), n.P(mname(m.idx, "bias")), 0, m.cout, 0, m.cin}});
+      if (rc) return rc;
+    }
   }
   auto res_layout = [&](Module& m, int c0, int c1) -> int {
     const std::string k = std::to_string(m.idx);
@@ -1348,11 +1362,15 @@ static int build_plan(Net& n, int B, Plan** out) {
   }
 
   // ---- input + time embedding ----
+  const PackedConv& stem_pc = n.pconvs[n.pconv_by_name.at(std::to_string(n.mods[c.conditional ? 2 : 0].idx))];
   Op as;
   as.kind = OP_ASSEMBLE;
-  as.out = bd.alloc_((size_t)B * S * S * n.in_cpad);
-  pl.ops.push_back(as);
-  pl.launches += 1;
+  as.out = NONE;
+  if (!stem_pc.stem) {
+    as.out = bd.alloc_((size_t)B * S * S * n.in_cpad);
+    pl.ops.push_back(as);
+    pl.launches += 1;
+  }
   if (c.conditional) {
     const Module& l0 = next_mod();
     const Module& l1 = next_mod();
@@ -1394,9 +1412,27 @@ static int build_plan(Net& n, int B, Plan** out) {
   std::vector<Skip> hs;
   {
     const Module& m = next_mod();
-    const size_t h0 = bd.conv(std::to_string(m.idx), as.out, NONE, S, S, 1, 1, 0, false, 0, NONE, NONE, false,
-                              c.x_channels + c.y_channels);
-    bd.ar.release(as.out);
+    size_t h0;
+    if (stem_pc.stem) {
+      Op o;
+      o.kind = OP_STEM;
+      o.pk0 = stem_pc.w_off; o.pk1 = stem_pc.b_off;
+      o.i0 = m.cout; o.i4 = stem_pc.ns;
+      const size_t out_elems = (size_t)B * S * S * m.cout;
+      o.out = bd.alloc_(out_elems);
+      const int tpi = stem_tiles_per_image(S);
+      o.stats = bd.alloc_((size_t)B * tpi * m.cout * 2 * 2);      // doubles; never released (small)
+      bd.tile_stats[o.out] = Builder::TileStats{o.stats, tpi};
+      o.cls = CSD_PROF_CONV3X3;
+      pl.ops.push_back(o);
+      const int cin = c.x_channels + c.y_channels;
+      bd.count(2.0 * out_elems * cin * 9, ((double)B * S * S * cin + (double)out_elems) * 4);
+      h0 = o.out;
+    } else {
+      h0 = bd.conv(std::to_string(m.idx), as.out, NONE, S, S, 1, 1, 0, false, 0, NONE, NONE, false,
+                   c.x_channels + c.y_channels);
+      bd.ar.release(as.out);
+    }
     hs.push_back({h0, m.cout});
   }
   int in_ch = nf;
@@ -1526,6 +1562,10 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         rc = assemble_input_launch(x, y, y_noise, y_sigma, W(o.out), B, c.x_channels, c.y_channels, S * S,
                                    n.in_cpad, c.centered, s);
         break;
+      case OP_STEM:
+        rc = stem_launch(x, y, y_noise, y_sigma, pk + o.pk0, pk + o.pk1, W(o.out), reinterpret_cast<double*>(W(o.stats)), B,
+                         c.x_channels, c.y_channels, o.i0, S, c.centered, o.i4, s);
+        break;
       case OP_TEMB:
         rc = timestep_embedding_launch(labels, W(o.out), B, o.i0, s);
         break;
@@ -1650,7 +1690,8 @@ static int pack_all(Net& n, float* pk, hipStream_t s) {
       const int cin_src = src.cin_src > 0 ? src.cin_src : pc.proto.C0 + pc.proto.C1;
       ConvPlan one = pc.proto;
       one.C0 = pc.proto.C0 + pc.proto.C1; one.C1 = 0;
-      rc = pc.ff ? convff_pack_weight(pc.proto, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
+      rc = pc.stem ? stem_pack_weight(n.params[src.param_w].ptr, cin_src, pc.proto.Cout, pc.ns, pk + pc.w_off, s)
+         : pc.ff ? convff_pack_weight(pc.proto, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
                                       src.cout_off, pk + pc.w_off, s)
          : pc.up4 ? conv16q_pack_weight_up4(one, pc.ns, n.params[src.param_w].ptr, pk + pc.w_off, s)
          : pc.q ? conv16q_pack_weight(one, pc.ns, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,

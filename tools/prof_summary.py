@@ -56,6 +56,8 @@ def timeline(path, marker='assemble_input_kernel'):
     """the launches of the LAST complete network evaluation in start order: index, kernel, workgroups, us, gap to the previous end"""
     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r['Start_Timestamp']))
     starts = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
+    if len(starts) < 2:         # (the DDPM-family fp16 modes start an evaluation with the fused stem launch)
+        starts = [i for i, r in enumerate(rows) if 'stem_kernel' in r['Kernel_Name']]
     lo, hi = starts[-2], starts[-1]
     prev = None
     tot = 0
