@@ -176,8 +176,9 @@ struct GNPlan {
 };
 size_t gn_partial_bytes(const GNPlan& p);
 int gn_plan(GNPlan* p, int B, int HW, int C0, int C1, int G);
+// per_channel: partial = [B * nchunk][C][2] (sum, sum of squares) per channel - the layout of the conv epilogues' tile partials
 int gn_stats_launch(const GNPlan& p, const float* src0, const float* src1, double* partial,
-                    hipStream_t s);
+                    hipStream_t s, int per_channel = 0);
 int gn_finalize_launch(const GNPlan& p, const double* partial, const float* gamma, const float* beta,
                        float eps, float* nscale, float* nshift, hipStream_t s);
 // finalize from the per-tile partials the conv epilogues wrote (ConvArgs::stats): source s has Cs channels and

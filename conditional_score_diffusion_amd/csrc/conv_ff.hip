@@ -451,7 +451,8 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
   if (a_stats) {
     // in-lane over a lane's 32 pixels (16 registers x 2 M tiles), one exchange between the K halves, the four waves through LDS
     float* const red = reinterpret_cast<float*>(smem);       // [4 waves][NT*32 couts][2] (the patch buffers are dead)
-    __syncthreads();                                   // everyone is done with the patch / ring
+    ff_barrier();                                      // everyone is done with the patch / ring (no fence: __syncthreads() would wait for the
+                                                       // output stores above to be acknowledged - vmcnt(0) - before the statistics start)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float vs = 0.f, vq = 0.f;
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
         red[(wave * NT * 32 + nt * 32 + p32) * 2 + 1] = vq;
       }
     }
-    __syncthreads();
+    ff_barrier();
     if (tid < NT * 32) {
       double s = 0.0, q = 0.0;
 #pragma unroll

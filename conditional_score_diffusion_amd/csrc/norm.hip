@@ -23,7 +23,7 @@ namespace csd {
 
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
     const float* __restrict__ src0, const float* __restrict__ src1, double* __restrict__ partial,
-    int HW, int C0, int C1, int G, int nchunk) {
+    int HW, int C0, int C1, int G, int nchunk, int per_channel) {
   extern __shared__ __attribute__((aligned(16))) double sred[];   // [2][C]
   const int C = C0 + C1;
   const int C4 = C >> 2;
@@ -45,7 +45,22 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
     if (c < C0) { src = src0; Cs = C0; coff = c; }
     else { src = src1; Cs = C1; coff = c - C0; }
     const float* base = src + (size_t)b * HW * Cs + coff;
-    for (int p = p0 + row; p < p1; p += rows) {
+    // eight rows in flight per thread (one load per dependent fp64 chain left the kernel latency-bound: 2.6 TB/s on the 160^2 x 96
+    // Upsample output); the additions keep their order - same bits
+    int p = p0 + row;
+    for (; p + 7 * rows < p1; p += 8 * rows) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(base + (size_t)(p + u * rows) * Cs);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s[0] += v[u].x; q[0] += (double)v[u].x * v[u].x;
+        s[1] += v[u].y; q[1] += (double)v[u].y * v[u].y;
+        s[2] += v[u].z; q[2] += (double)v[u].z * v[u].z;
+        s[3] += v[u].w; q[3] += (double)v[u].w * v[u].w;
+      }
+    }
+    for (; p < p1; p += rows) {
       const float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * Cs);
       s[0] += v.x; q[0] += (double)v.x * v.x;
       s[1] += v.y; q[1] += (double)v.y * v.y;
@@ -66,6 +81,14 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
       }
     }
     __syncthreads();
+  }
+  if (per_channel) {      // the layout of the conv epilogues' tile partials ([B * nchunk][C][2]): gn_finalize_tiles folds them with another source's
+    for (int c = tid; c < C; c += GN_THREADS) {
+      double* dst = partial + (((size_t)b * nchunk + chunk) * C + c) * 2;
+      dst[0] = ssum[c];
+      dst[1] = ssq[c];
+    }
+    return;
   }
   const int cpg = C / G;
   for (int g = tid; g < G; g += GN_THREADS) {
@@ -426,11 +449,11 @@ size_t gn_partial_bytes(const GNPlan& p) {
   return (size_t)p.B * p.nchunk * p.G * 2 * sizeof(double);
 }
 
-int gn_stats_launch(const GNPlan& p, const float* src0, const float* src1, double* partial, hipStream_t s) {
+int gn_stats_launch(const GNPlan& p, const float* src0, const float* src1, double* partial, hipStream_t s, int per_channel) {
   const int C = p.C0 + p.C1;
   const size_t lds = (size_t)2 * C * sizeof(double);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(p.nchunk, p.B), dim3(GN_THREADS), lds, s, src0, src1, partial,
-                     p.HW, p.C0, p.C1, p.G, p.nchunk);
+                     p.HW, p.C0, p.C1, p.G, p.nchunk, per_channel);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }

@@ -846,6 +846,22 @@ struct Builder {
   // GroupNorm statistics of (src0|src1) -> nscale/nshift
   void gn(size_t src0, size_t src1, int c0, int c1, int hw, const std::string& gname, const std::string& bname) {
     const int G = n.cfg.arch == 1 ? ncsnpp_groups(c0 + c1) : 32;
+    if (src1 != NONE && (tile_stats.count(src0) != 0) != (tile_stats.count(src1) != 0)) {
+      // a concatenated input of which ONE half carries epilogue partials (the skip tensor next to an Upsample output): the streaming pass
+      // reads only the other half and leaves per-channel partials in the same layout (it used to re-read both: 1.26 GB at 160^2 x 192)
+      const bool first = tile_stats.count(src0) == 0;
+      const size_t src = first ? src0 : src1;
+      const int cs = first ? c0 : c1;
+      Op s;
+      s.kind = OP_GN_STATS;
+      if (gn_plan(&s.gp, B, hw, cs, 0, 1)) { rc = CSD_ERR_INVALID; return; }
+      s.a = src; s.b = NONE; s.i0 = 1;      // per-channel partials
+      s.out = alloc_((size_t)B * s.gp.nchunk * cs * 2 * 2);      // doubles; never released (small)
+      s.cls = CSD_PROF_GN_STATS; s.bytes = (double)B * hw * cs * 4;
+      pl.ops.push_back(s);
+      pl.launches += 1;
+      tile_stats[src] = TileStats{s.out, s.gp.nchunk};
+    }
     const auto t0 = tile_stats.find(src0);
     const auto t1 = src1 == NONE ? tile_stats.end() : tile_stats.find(src1);
     if (t0 != tile_stats.end() && (src1 == NONE || t1 != tile_stats.end())) {
@@ -1582,7 +1598,7 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         rc = linear_launch(W(o.a), pk + o.pk0, pk + o.pk1, W(o.out), B, o.i0, o.i1, o.act, s, o.i2);
         break;
       case OP_GN_STATS:
-        rc = gn_stats_launch(o.gp, W(o.a), W(o.b), reinterpret_cast<double*>(W(o.out)), s);
+        rc = gn_stats_launch(o.gp, W(o.a), W(o.b), reinterpret_cast<double*>(W(o.out)), s, o.i0);
         break;
       case OP_GN_FINAL:
         rc = gn_finalize_launch(o.gp, reinterpret_cast<const double*>(W(o.a)), pk + o.pk0, pk + o.pk1, 1e-6f,
