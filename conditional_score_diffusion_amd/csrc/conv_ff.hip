@@ -9,10 +9,12 @@
 // kernel's input: every element is converted ONCE per workgroup while it is staged, by three of the four waves.
 //
 // Schedule (one workgroup = 4 waves = 256 output pixels (16 x 16) x NT*32 couts, 2 workgroups per CU):
-//   * MFMA: v_mfma_f32_32x32x16_f16, operands swapped (A = weights, B = pixels) so a lane's 16 results are 4 x 4
-//     consecutive couts of ONE pixel: the epilogue moves 16 bytes per lane.  Wave w owns pixel rows 4w..4w+3 as two
-//     4 x 8 M tiles (that lane->pixel map + a 1168-byte LDS row pitch makes every ds_read_b128 of a tap conflict-free)
-//     and ALL NT cout tiles: 2*NT accumulators, 2 + NT fragment reads per K step.
+//   * MFMA: v_mfma_f32_32x32x16_f16 with A = pixels, B = weights: a lane's 16 results are ONE cout of 16 pixels, so a residual load /
+//     output store of a wave is two whole 128-byte lines per instruction and the GroupNorm partials are in-lane sums (the
+//     weights-as-M order gave each lane 4 x 4 consecutive couts of one pixel - 16-byte stores whose 32-byte pieces reach L2 as four
+//     partial-line writes: 3.3 TB/s against 5.4 TB/s in tools/store_probe.hip, and -6..8 % on the 160^2 layers).  Wave w owns pixel
+//     rows 4w..4w+3 as two 4 x 8 M tiles (that lane->pixel map + a 1168-byte LDS row pitch makes every ds_read_b128 of a tap
+//     conflict-free) and ALL NT cout tiles: 2*NT accumulators, 2 + NT fragment reads per K step.
 //   * weights: through LDS, shared by the four waves (each wave pulling its own fragments from L2 saturates the
 //     64 B/clk L1 path - the binding resource of the quad / loader-consumer schedules).  Wave 0 streams them with
 //     global_load_lds_dwordx4 (no registers, fragment order = linear) into a ring of R groups, a few hundred cycles
@@ -23,8 +25,8 @@
 //   * one LDS-only barrier per ring group (18 MFMAs per wave between barriers in both arithmetic modes).
 //   NS = 1 (fp16): KC = 32 channels per stage (2 K steps per tap), ring group = 3 steps.
 //   NS = 2 (fp16x3: hi|lo operands, 3 MFMAs per product): KC = 16, ring group = 1 step.
-// Epilogue: acc starts at (bias + temb) * 2^8, residual added, out_scale, 16-byte stores, and the GroupNorm partials
-// (sum, sum of squares per (tile, cout)) of the written tensor for the NEXT GroupNorm - fp32 tree over the tile's 256
+// Epilogue: acc starts at (bias + temb) * 2^8, residual added, out_scale, full-line dword stores, and the GroupNorm partials
+// (sum, sum of squares per (tile, cout)) of the written tensor for the NEXT GroupNorm - fp32 sums over the tile's 256
 // pixels in a fixed order, folded in fp64 by gn_finalize_tiles_kernel.
 #include "conv_ff.h"
 
