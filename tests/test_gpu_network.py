@@ -152,6 +152,45 @@ def test_nf96_batch_unmasked_tiles(precision, tol):
     assert rel(out.cpu().numpy(), ref.numpy()) < tol
 
 
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-6), ('fp16', 1e-3), ('fp16x3', 2e-6), ('fp16f8', 5e-5)])
+@pytest.mark.parametrize('nf,S,centered', [(96, 32, False), (128, 48, True)])
+def test_fused_y_perturbation_equals_perturbing_y(precision, tol, nf, S, centered):
+    """csd_unet_forward's y_noise / y_sigma (y_t = y + sigma z assembled inside the first layer: stem.hip in the fp16 modes,
+    assemble_input in fp32) against the same network on a y perturbed beforehand - the first layer with and without its
+    noise source, 96 and 128 output channels, both data centerings"""
+    cfg = cases.make_config(name='ddpm_paired_SR3', nf=nf, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(), image_size=S)
+    cfg.data.centered = centered
+    cfg, nc, p, model = build(cfg, precision)
+    rs = np.random.RandomState(3)
+    B = 3
+    x = torch.from_numpy(rs.standard_normal((B, 3, S, S)).astype(np.float32) * 4).to(dev())
+    y = torch.from_numpy(rs.uniform(0, 1, (B, 3, S, S)).astype(np.float32)).to(dev())
+    z = torch.from_numpy(rs.standard_normal((B, 3, S, S)).astype(np.float32)).to(dev())
+    lab = torch.tensor([700., 30., 999.], device=dev())
+    sig = 0.37
+    with torch.no_grad():
+        fused = model._run(x, y, lab, y_noise=z, y_sigma=sig)
+        plain = model._run(x, (y + sig * z).contiguous(), lab)
+        clean = model._run(x, y, lab)
+    # (a fused multiply-add against torch's mul + add: one fp32 ulp of y, which the rounding of the fp16 / e4m3 operands can amplify)
+    assert rel(fused.cpu().numpy(), plain.cpu().numpy()) < tol
+    assert rel(clean.cpu().numpy(), plain.cpu().numpy()) > 1e-3        # the perturbation is really there
+
+
+@pytest.mark.parametrize('precision,tol', [('fp16x3', 2e-5), ('fp16f8', 2e-4), ('fp16', 5e-3)])
+def test_unconditional_nf96_first_layer_without_a_condition(precision, tol):
+    """the unconditional family (3 input channels, y absent) through the fused first layer (stem.hip: Cy = 0), odd tile counts (48 = 3 x 16)"""
+    cfg = cases.make_config(name='ddpm', nf=96, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(), image_size=48)
+    cfg, nc, p, model = build(cfg, precision)
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.standard_normal((5, 3, 48, 48)).astype(np.float32) * 7)
+    lab = torch.tensor([999., 500., 20., 3., 250.])
+    with torch.no_grad():
+        ref = so.ddpm_forward(p, nc, x, lab)
+        out = model(x.to(dev()), lab.to(dev()))
+    assert rel(out.cpu().numpy(), ref.numpy()) < tol
+
+
 @pytest.mark.parametrize('S,B,ch_mult,attn', [(40, 3, (1, 2, 2), (20, 10)), (32, 5, (1, 1, 2, 2, 3, 3), (4, 2, 1)), (64, 2, (1, 2, 2, 3), (8,)),
                                             (80, 2, (1, 2, 3), (20,))])
 def test_fp16f8_networks_vs_oracle(S, B, ch_mult, attn):
