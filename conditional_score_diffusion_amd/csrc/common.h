@@ -179,16 +179,22 @@ int gn_plan(GNPlan* p, int B, int HW, int C0, int C1, int G);
 // per_channel: partial = [B * nchunk][C][2] (sum, sum of squares) per channel - the layout of the conv epilogues' tile partials
 int gn_stats_launch(const GNPlan& p, const float* src0, const float* src1, double* partial,
                     hipStream_t s, int per_channel = 0);
+// rs / ms (optional): the plain statistics (rstd, -mean * rstd) per (sample, channel) as well
 int gn_finalize_launch(const GNPlan& p, const double* partial, const float* gamma, const float* beta,
-                       float eps, float* nscale, float* nshift, hipStream_t s);
+                       float eps, float* nscale, float* nshift, hipStream_t s, float* rs = nullptr, float* ms = nullptr);
 // finalize from the per-tile partials the conv epilogues wrote (ConvArgs::stats): source s has Cs channels and
 // tpi_s tiles per sample, laid out [B*tpi_s][Cs][2]; p1 may be null (single source)
 int gn_finalize_tiles_launch(const double* p0, int tpi0, int C0, const double* p1, int tpi1, int C1, int B, int HW, int G,
                              const float* gamma, const float* beta, float eps, float* nscale, float* nshift,
                              hipStream_t s);
 // stand-alone apply: y = act(x*scale + shift), NHWC
+// mask != null: y = dropout(act(x*scale + shift)) with the mask csd_dropout would draw for (seed, stream_id), written to mask
 int gn_apply_launch(const float* x, const float* nscale, const float* nshift, float* y, int B, int HW,
-                    int C, int act, hipStream_t s);
+                    int C, int act, hipStream_t s, float* mask = nullptr, float p_drop = 0.f, uint64_t seed = 0, uint64_t stream_id = 0);
+// csd_groupnorm_act_nhwc with the training forward's dropout fused into the apply pass (train_nhwc.hip)
+int groupnorm_act_dropout_nhwc(const float* x, const float* gamma, const float* beta, float* y, float* rs, float* ms, float* mask,
+                               float p_drop, uint64_t seed, uint64_t stream_id, int B, int C, int HW, int groups, float eps, int act,
+                               void* scratch, void* stream);
 
 // ---------------------------------------------------------------------------------------
 // attention core on NHWC qkv (attention.hip): qkv [B, L, ld] with q at +0, k at +C, v at +2C

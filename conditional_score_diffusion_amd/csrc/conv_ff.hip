@@ -227,6 +227,43 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
     for (int i = 0; i < GLW; ++i) issue_w1(G, slot, i);
   };
 
+  // ---- accumulators: (bias + temb + residual) * 2^8 ----
+  // The PIXELS are the MFMA's M operand, the couts its N operand: a lane holds ONE cout (nt*32 + p32) of 16 pixels of each M tile -
+  // register r = pixel 8 (r / 4) + 4 kh + r % 4 of the tile's 32 (4 rows x 8 columns) - so every residual load and output store of a
+  // wave covers whole 128-byte lines (tools/store_probe.hip: 5.4 TB/s against 3.3 TB/s for the weights-as-M layout, whose lanes own
+  // 16-byte pieces that four different instructions assemble into a line), and the GroupNorm partials are in-lane sums.
+  // The residual (the block's shortcut) is requested FIRST, straight into the accumulator registers, before the weight DMAs and the
+  // first patch: ONE HBM round trip for all three (it used to be loaded one M tile at a time behind the patch: two more round trips,
+  // +50-70 us per launch at 160^2).  Being the oldest entries of the in-order vmcnt queue, the residual has landed wherever the
+  // patch / the first weight groups have; the scaling to the accumulator domain follows the first patch conversion.
+  const int c_lane = ng * NT * 32 + p32;
+  floatx16 acc[2][NT];
+  float bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bv[nt] = a_bias ? a_bias[c_lane + nt * 32] : 0.f;
+  if (a_temb) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] += a_temb[(size_t)b * a_temb_stride + c_lane + nt * 32];
+  }
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int RSRC_FLAGS = 0x00020000;
+  const size_t tile_pix = img0 + (size_t)ty0 * kW + tx0;
+  // output / residual element of register r of M tile mt: pixel row 4 wave + r / 4, column 8 mt + 4 kh + r % 4, cout c_lane + 32 nt
+  // (buffer addressing: the lane part - K half and cout - is ONE voffset register per tensor, the register's pixel a scalar soffset)
+  auto upix = [&](int mt, int r) __attribute__((always_inline)) { return (4 * wave + (r >> 2)) * kW + 8 * mt + (r & 3); };      // uniform
+  const bool has_res = a_res != nullptr && !FF_ABL(8);
+  if (has_res) {
+    const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_res + tile_pix * kCout), 0, OOB, RSRC_FLAGS);
+    const unsigned res_voff = (unsigned)(4 * kh * kCout + c_lane) * 4u;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          acc[mt][nt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(res_r, res_voff, (unsigned)(upix(mt, r) * kCout + nt * 32) * 4u, 0));
+  }
+
   // ---- prologue: the first stage's patch (waves 1-3) and the first R-1 weight groups (wave 0) are requested before anything
   // else, the tables / bias / time-embedding work runs under their latency ----
   if (wave < NDMA) {
@@ -245,54 +282,6 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
   }
 
 
-  // ---- accumulators start at (bias + temb) * 2^8 ----
-  // The PIXELS are the MFMA's M operand, the couts its N operand: a lane holds ONE cout (nt*32 + p32) of 16 pixels of each M tile -
-  // register r = pixel 8 (r / 4) + 4 kh + r % 4 of the tile's 32 (4 rows x 8 columns) - so every residual load and output store of a
-  // wave covers whole 128-byte lines (tools/store_probe.hip: 5.4 TB/s against 3.3 TB/s for the weights-as-M layout, whose lanes own
-  // 16-byte pieces that four different instructions assemble into a line), and the GroupNorm partials are in-lane sums.
-  const int c_lane = ng * NT * 32 + p32;
-  floatx16 acc[2][NT];
-  {
-    float bv[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bv[nt] = a_bias ? a_bias[c_lane + nt * 32] : 0.f;
-    if (a_temb) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bv[nt] += a_temb[(size_t)b * a_temb_stride + c_lane + nt * 32];
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bv[nt] * acc_in;
-  }
-  // the residual (the block's shortcut) joins the accumulators HERE, not in the epilogue: its loads travel under the first
-  // stage's patch round trip, the epilogue is scale + store only (it used to spend ~10 k cycles per tile on issue -> wait -> add)
-  constexpr unsigned OOB = 0x80000000u;
-  constexpr int RSRC_FLAGS = 0x00020000;
-  const size_t tile_pix = img0 + (size_t)ty0 * kW + tx0;
-  // output / residual element of register r of M tile mt: pixel row 4 wave + r / 4, column 8 mt + 4 kh + r % 4, cout c_lane + 32 nt
-  // (buffer addressing: the lane part - K half and cout - is ONE voffset register per tensor, the register's pixel a scalar soffset)
-  auto upix = [&](int mt, int r) __attribute__((always_inline)) { return (4 * wave + (r >> 2)) * kW + 8 * mt + (r & 3); };      // uniform
-  if (a_res != nullptr && !FF_ABL(8)) {
-    const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_res + tile_pix * kCout), 0, OOB, RSRC_FLAGS);
-    const unsigned res_voff = (unsigned)(4 * kh * kCout + c_lane) * 4u;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {                 // (one M tile at a time: 48 registers of loads in flight, not 96)
-      float rv[NT][16];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          rv[nt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(res_r, res_voff, (unsigned)(upix(mt, r) * kCout + nt * 32) * 4u, 0));
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nt][r] += rv[nt][r] * acc_in;
-    }
-  }
-
   // per-lane LDS offset of tap (0,0) of its pixel in M tile mt (rows 4*wave + (p32 >> 3), cols 8*mt + (p32 & 7)) + K half
   int base[2];
 #pragma unroll
@@ -304,8 +293,16 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
 
   ff_barrier();                                      // tables visible
   FF_TS();
-  if (wave < NDMA) ff_wait_vm<(R - 3) * GLW>();      // groups 0 and 1 have landed
+  if (wave < NDMA) ff_wait_vm<(R - 3) * GLW>();      // groups 0 and 1 have landed (and the older residual loads)
   else store_patch(patch);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const float b_in = bv[nt] * acc_in;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = has_res ? fmaf(acc[mt][nt][r], acc_in, b_in) : b_in;
+  }
   ff_barrier();
   FF_TS();
 

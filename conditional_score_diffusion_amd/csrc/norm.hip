@@ -102,7 +102,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
 
 __global__ void gn_finalize_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float* __restrict__ nscale,
-                                   float* __restrict__ nshift, int HW, int C, int G, int nchunk) {
+                                   float* __restrict__ nshift, int HW, int C, int G, int nchunk, float* __restrict__ rs,
+                                   float* __restrict__ ms) {
   const int b = blockIdx.x;
   const int cpg = C / G;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -121,6 +122,10 @@ __global__ void gn_finalize_kernel(const double* __restrict__ partial, const flo
     const float sc = rstd * (gamma ? gamma[c] : 1.f);          // gamma == null: the plain statistics (rstd, -mean*rstd)
     nscale[(size_t)b * C + c] = sc;
     nshift[(size_t)b * C + c] = (beta ? beta[c] : 0.f) - (float)mean * sc;
+    if (rs) {                                                  // the plain statistics next to the affine ones (training forward: one launch, not two)
+      rs[(size_t)b * C + c] = rstd;
+      ms[(size_t)b * C + c] = 0.f - (float)mean * rstd;
+    }
   }
 }
 
@@ -216,6 +221,44 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
     o.z = gn_act(v.z * sc.z + sh.z, act);
     o.w = gn_act(v.w * sc.w + sh.w, act);
     reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
+
+// the training forward's dropout(act(GroupNorm(x))) in one pass: the mask (0 or 1 / (1 - p), nn.Dropout) of float4 i is Philox4x32-10 counter
+// i of (seed, stream) - element for element what csd_dropout (backward.hip) draws, so the fused and the two-launch form agree bitwise
+__global__ void gn_apply_dropout_kernel(const float* __restrict__ x, const float* __restrict__ nscale, const float* __restrict__ nshift,
+                                        float* __restrict__ y, float* __restrict__ mask, int HW, int C, int act, size_t total4, float p,
+                                        uint64_t seed, uint64_t stream_id) {
+  const int C4 = C >> 2;
+  const float keep = 1.0f / (1.0f - p);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i / C4;
+    const int c4 = (int)(i - pix * C4);
+    const int b = (int)(pix / HW);
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 sc = *reinterpret_cast<const float4*>(nscale + (size_t)b * C + c4 * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(nshift + (size_t)b * C + c4 * 4);
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+      const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+      c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+      k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    float4 m;
+    m.x = (float)(c[0] >> 8) * (1.0f / 16777216.0f) >= p ? keep : 0.f;
+    m.y = (float)(c[1] >> 8) * (1.0f / 16777216.0f) >= p ? keep : 0.f;
+    m.z = (float)(c[2] >> 8) * (1.0f / 16777216.0f) >= p ? keep : 0.f;
+    m.w = (float)(c[3] >> 8) * (1.0f / 16777216.0f) >= p ? keep : 0.f;
+    float4 o;
+    o.x = gn_act(v.x * sc.x + sh.x, act) * m.x;
+    o.y = gn_act(v.y * sc.y + sh.y, act) * m.y;
+    o.z = gn_act(v.z * sc.z + sh.z, act) * m.z;
+    o.w = gn_act(v.w * sc.w + sh.w, act) * m.w;
+    reinterpret_cast<float4*>(y)[i] = o;
+    reinterpret_cast<float4*>(mask)[i] = m;
   }
 }
 
@@ -459,9 +502,9 @@ int gn_stats_launch(const GNPlan& p, const float* src0, const float* src1, doubl
 }
 
 int gn_finalize_launch(const GNPlan& p, const double* partial, const float* gamma, const float* beta,
-                       float eps, float* nscale, float* nshift, hipStream_t s) {
+                       float eps, float* nscale, float* nshift, hipStream_t s, float* rs, float* ms) {
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B), dim3(256), 0, s, partial, gamma, beta, eps, nscale,
-                     nshift, p.HW, p.C0 + p.C1, p.G, p.nchunk);
+                     nshift, p.HW, p.C0 + p.C1, p.G, p.nchunk, rs, ms);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
@@ -481,10 +524,14 @@ int gn_finalize_tiles_launch(const double* p0, int tpi0, int C0, const double* p
 }
 
 int gn_apply_launch(const float* x, const float* nscale, const float* nshift, float* y, int B, int HW, int C,
-                    int act, hipStream_t s) {
+                    int act, hipStream_t s, float* mask, float p_drop, uint64_t seed, uint64_t stream_id) {
   const size_t total4 = (size_t)B * HW * C / 4;
   const int grid = (int)std::min<size_t>(cdiv64(total4, 256), 2048 * 4);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, s, x, nscale, nshift, y, HW, C, act, total4);
+  if (mask)
+    hipLaunchKernelGGL(gn_apply_dropout_kernel, dim3(grid), dim3(256), 0, s, x, nscale, nshift, y, mask, HW, C, act, total4, p_drop, seed,
+                       stream_id);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, s, x, nscale, nshift, y, HW, C, act, total4);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }

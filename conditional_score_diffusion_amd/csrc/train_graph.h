@@ -142,10 +142,12 @@ struct TG {
     top = m;
     return CSD_OK;
   }
-  int gn(const float* x, const float* gamma, const float* beta, float* y, float* rs, float* ms, int C, int H, int a) {
+  // (mask != null: nn.Dropout of the activated tensor in the same pass; the mask csd_dropout would draw for (seed, drop_id))
+  int gn(const float* x, const float* gamma, const float* beta, float* y, float* rs, float* ms, int C, int H, int a, float* mask = nullptr,
+         uint64_t drop_id = 0) {
     const size_t m = top;
     float* sc = alloc_bytes(csd_groupnorm_nhwc_scratch_bytes(B, C, H * H));
-    TG_RUN(csd_groupnorm_act_nhwc(x, gamma, beta, y, rs, ms, B, C, H * H, 32, 1e-6f, a, sc, s));
+    TG_RUN(groupnorm_act_dropout_nhwc(x, gamma, beta, y, rs, ms, mask, p_drop, seed, drop_id, B, C, H * H, 32, 1e-6f, a, sc, s));
     top = m;
     return CSD_OK;
   }
@@ -228,15 +230,12 @@ struct TG {
     }
     float* a1 = alloc(act_n(H, cout));               // dropout(act(GroupNorm_1(.))): Conv_1's operand
     float* rs1 = alloc((size_t)B * cout); float* ms1 = alloc((size_t)B * cout);
-    rc = gn(c0, W(m.idx, "GroupNorm_1.weight"), W(m.idx, "GroupNorm_1.bias"), a1, rs1, ms1, cout, H, act);
-    if (rc) return rc;
     float* mask = nullptr;
     ++drop_count;
     sp.drop_id = (call << 16) + (uint64_t)drop_count;
-    if (p_drop > 0.f) {
-      mask = alloc(act_n(H, cout));
-      TG_RUN(csd_dropout(a1, a1, mask, p_drop, seed, sp.drop_id, (int64_t)act_n(H, cout), s));
-    }
+    if (p_drop > 0.f) mask = alloc(act_n(H, cout));
+    rc = gn(c0, W(m.idx, "GroupNorm_1.weight"), W(m.idx, "GroupNorm_1.bias"), a1, rs1, ms1, cout, H, act, mask, sp.drop_id);   // (dropout in the apply pass)
+    if (rc) return rc;
     const int out = new_tensor(H, cout);
     float* o = st.t[out].p;
     if (cin != cout) {                               // NIN shortcut: h . W + b through the transposed-weight flag (no W^T copy)

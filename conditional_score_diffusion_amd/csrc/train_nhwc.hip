@@ -264,7 +264,14 @@ extern "C" size_t csd_groupnorm_nhwc_scratch_bytes(int B, int C, int HW) {
 // y = act(GroupNorm(x)); rs / ms [B, C] receive the statistics (rstd, -mean*rstd per channel) the backward needs
 extern "C" int csd_groupnorm_act_nhwc(const float* x, const float* gamma, const float* beta, float* y, float* rs, float* ms,
                                       int B, int C, int HW, int groups, float eps, int act, void* scratch, void* stream) {
+  return csd::groupnorm_act_dropout_nhwc(x, gamma, beta, y, rs, ms, nullptr, 0.f, 0, 0, B, C, HW, groups, eps, act, scratch, stream);
+}
+
+int csd::groupnorm_act_dropout_nhwc(const float* x, const float* gamma, const float* beta, float* y, float* rs, float* ms, float* mask,
+                                    float p_drop, uint64_t seed, uint64_t stream_id, int B, int C, int HW, int groups, float eps,
+                                    int act, void* scratch, void* stream) {
   CSD_REQUIRE(x && gamma && beta && y && rs && ms && scratch, "groupnorm_act_nhwc: null argument");
+  CSD_REQUIRE(mask == nullptr || (p_drop > 0.f && p_drop < 1.f && ((size_t)B * HW * C) % 4 == 0), "groupnorm_act_nhwc: dropout p = %f", (double)p_drop);
   hipStream_t s = (hipStream_t)stream;
   GNPlan g;
   int rc = gn_plan(&g, B, HW, C, 0, groups);
@@ -274,9 +281,8 @@ extern "C" int csd_groupnorm_act_nhwc(const float* x, const float* gamma, const 
   float* sh = f; f += al64((size_t)B * C);
   double* partial = reinterpret_cast<double*>(f);
   if ((rc = gn_stats_launch(g, x, nullptr, partial, s))) return rc;
-  if ((rc = gn_finalize_launch(g, partial, gamma, beta, eps, sc, sh, s))) return rc;
-  if ((rc = gn_finalize_launch(g, partial, nullptr, nullptr, eps, rs, ms, s))) return rc;
-  return gn_apply_launch(x, sc, sh, y, B, HW, C, act, s);
+  if ((rc = gn_finalize_launch(g, partial, gamma, beta, eps, sc, sh, s, rs, ms))) return rc;
+  return gn_apply_launch(x, sc, sh, y, B, HW, C, act, s, mask, p_drop, seed, stream_id);
 }
 
 // dx = GroupNorm(+act) backward of dy (+ add, when given: the gradient arriving over the residual shortcut)
