@@ -215,6 +215,9 @@ int assemble_input_launch(const float* x, const float* y, const float* y_noise, 
                           float* out, int B, int Cx, int Cy, int HW, int Cpad, int centered,
                           hipStream_t s);
 int fir_resample_nhwc_launch(const float* in, float* out, int B, int H, int W, int C, const float* taps4, int up, hipStream_t s);
+// out_x = FIR(in), out_h = FIR(act(in * nscale + nshift)) in one pass (the up / down BigGAN block's two resampled tensors)
+int fir_resample2_nhwc_launch(const float* in, const float* nscale, const float* nshift, float* out_x, float* out_h, int B, int H, int W,
+                              int C, const float* taps4, int up, int act, hipStream_t s);
 int fourier_embedding_launch(const float* t, const float* W, float* out, int B, int E, hipStream_t s);
 // per-operator convolution of the C ABI (ops_api.hip) with an optional NHWC residual added in the epilogue; GroupNorm backward with
 // an optional addend (train_nhwc.hip): the fused forms the planned training graph (train_graph.h) uses

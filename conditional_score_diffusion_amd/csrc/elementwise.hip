@@ -446,6 +446,69 @@ __global__ void fir_resample_nhwc4_kernel(const float4* __restrict__ in, float4*
     out[i] = acc;
   }
 }
+// the up / down ResnetBlockBigGANpp's two resampled tensors in ONE pass over x (layerspp.py:242-260): out_x = FIR(x) and
+// out_h = FIR(act(x * scale + shift)) - the GroupNorm'ed, activated tensor is never materialised (it used to be written, read by its FIR pass,
+// and x read a second time by the other: 3 launches, 2.2 x the bytes).  Same taps, same accumulation order as the single-tensor kernel.
+__global__ void fir_resample2_nhwc4_kernel(const float4* __restrict__ in, const float* __restrict__ nscale, const float* __restrict__ nshift,
+                                           float4* __restrict__ out_x, float4* __restrict__ out_h, int H, int W, int C4, int up, int act,
+                                           Fir16 f, size_t total) {
+  const int OH = up ? H * 2 : H / 2, OW = up ? W * 2 : W / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    size_t r = i / C4;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const size_t b = r / OH;
+    const float4* src = in + b * (size_t)H * W * C4 + c;
+    const float4 sc = *reinterpret_cast<const float4*>(nscale + (b * C4 + c) * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(nshift + (b * C4 + c) * 4);
+    float4 ax = make_float4(0.f, 0.f, 0.f, 0.f), ah = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      const int my = up ? oy + ky - 2 : oy * 2 + ky - 1;
+      if (my < 0 || (up && (my & 1))) continue;
+      const int iy = up ? my >> 1 : my;
+      if (iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const int mx = up ? ox + kx - 2 : ox * 2 + kx - 1;
+        if (mx < 0 || (up && (mx & 1))) continue;
+        const int ix = up ? mx >> 1 : mx;
+        if (ix >= W) continue;
+        const float4 v = src[((size_t)iy * W + ix) * C4];
+        const float w = f.k[(3 - ky) * 4 + (3 - kx)];
+        ax.x += v.x * w; ax.y += v.y * w; ax.z += v.z * w; ax.w += v.w * w;
+        // (SiLU in the conv prologues' form - v_exp_f32 + v_rcp_f32, 1 ulp each: with libm's expf and an IEEE division the 16 taps of an
+        // output made the pass vector-bound: 739 us at 160^2 for 190 us of HBM traffic)
+        auto actf = [&](float t) __attribute__((always_inline)) {
+          return act == CSD_ACT_SWISH ? t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)) : ew_act(t, act);
+        };
+        const float hx = actf(v.x * sc.x + sh.x), hy = actf(v.y * sc.y + sh.y);
+        const float hz = actf(v.z * sc.z + sh.z), hw = actf(v.w * sc.w + sh.w);
+        ah.x += hx * w; ah.y += hy * w; ah.z += hz * w; ah.w += hw * w;
+      }
+    }
+    out_x[i] = ax;
+    out_h[i] = ah;
+  }
+}
+int fir_resample2_nhwc_launch(const float* in, const float* nscale, const float* nshift, float* out_x, float* out_h, int B, int H, int W,
+                              int C, const float* taps4, int up, int act, hipStream_t s) {
+  CSD_REQUIRE(C % 4 == 0, "fir_resample2: C = %d is not a multiple of 4", C);
+  Fir16 f;
+  float sum = 0.f;
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b) { f.k[a * 4 + b] = taps4[a] * taps4[b]; sum += f.k[a * 4 + b]; }
+  for (int a = 0; a < 16; ++a) f.k[a] = f.k[a] / sum * (up ? 4.f : 1.f);
+  const size_t total = (size_t)B * (up ? H * 2 : H / 2) * (up ? W * 2 : W / 2) * C;
+  hipLaunchKernelGGL(fir_resample2_nhwc4_kernel, dim3((unsigned)std::min<size_t>(cdiv64(total / 4, 256), 65536)), dim3(256), 0, s,
+                     reinterpret_cast<const float4*>(in), nscale, nshift, reinterpret_cast<float4*>(out_x), reinterpret_cast<float4*>(out_h),
+                     H, W, C / 4, up, act, f, total / 4);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
 int fir_resample_nhwc_launch(const float* in, float* out, int B, int H, int W, int C, const float* taps4, int up, hipStream_t s) {
   // _setup_kernel (up_or_down_sampling.py:181-189): outer product, normalised, times the gain (factor^2 when upsampling)
   Fir16 f;

@@ -106,7 +106,7 @@ struct Net;
 // ---------------------------------------------------------------------------------------------
 // execution plan for one batch size
 // ---------------------------------------------------------------------------------------------
-enum OpKind { OP_ASSEMBLE, OP_STEM, OP_TEMB, OP_FOURIER, OP_FIR, OP_GN_APPLY32, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_GN_FINAL_TILES, OP_GN_APPLY16, OP_GN_FUSED16, OP_GN_STATFIN, OP_CONV, OP_ATTN, OP_AVGPOOL,
+enum OpKind { OP_ASSEMBLE, OP_STEM, OP_TEMB, OP_FOURIER, OP_FIR, OP_FIR2, OP_GN_APPLY32, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_GN_FINAL_TILES, OP_GN_APPLY16, OP_GN_FUSED16, OP_GN_STATFIN, OP_CONV, OP_ATTN, OP_AVGPOOL,
               OP_UPNEAR, OP_TO_NCHW, OP_TAPSUM };
 
 static const size_t NONE = (size_t)-1;
@@ -598,21 +598,25 @@ static int build_packed_layout(Net& n) {
       add_copy(mname(m.idx, "bias"));
     }
   }
+  // the first layer of both families in the fp16 modes: input assembly + 3x3 conv + the next GroupNorm's partials as one launch (stem.hip)
+  auto stem_layout = [&](Module& m) -> bool {
+    if (!(net_ns && m.cin == c.x_channels + c.y_channels && stem_supported(c.x_channels, c.y_channels, m.cout, c.image_size, net_ns)))
+      return false;
+    PackedConv pc;
+    if (proto_conv(&pc.proto, n.in_cpad, 0, m.cout, 9)) return false;
+    pc.ns = net_ns;
+    pc.stem = true;
+    pc.w_off = take(stem_packed_bytes(m.cout, net_ns) / sizeof(float) + 1);
+    pc.b_off = take((size_t)pc.proto.CoutPad + 96);
+    pc.srcs = {{n.P(mname(m.idx, "weight")), n.P(mname(m.idx, "bias")), 0, m.cout, 0, m.cin}};
+    n.pconv_by_name[std::to_string(m.idx)] = (int)n.pconvs.size();
+    n.pconvs.push_back(pc);
+    return true;
+  };
   int rc;
   if (c.arch == 0) {
     Module& m = next_mod();   // stem: Cin padded to 8 (zero weights for the padding channels)
-    if (net_ns && m.cin == c.x_channels + c.y_channels && stem_supported(c.x_channels, c.y_channels, m.cout, c.image_size, net_ns)) {
-      // fp16 modes: input assembly + first conv + the next GroupNorm's partials as one launch (stem.hip)
-      PackedConv pc;
-      if ((rc = proto_conv(&pc.proto, n.in_cpad, 0, m.cout, 9))) return rc;
-      pc.ns = net_ns;
-      pc.stem = true;
-      pc.w_off = take(stem_packed_bytes(m.cout, net_ns) / sizeof(float) + 1);
-      pc.b_off = take((size_t)pc.proto.CoutPad + 96);
-      pc.srcs = {{n.P(mname(m.idx, "weight")), n.P(mname(m.idx, "bias")), 0, m.cout, 0, m.cin}};
-      n.pconv_by_name[std::to_string(m.idx)] = (int)n.pconvs.size();
-      n.pconvs.push_back(pc);
-    } else {
+    if (!stem_layout(m)) {
       rc = add_conv(std::to_string(m.idx), n.in_cpad, 0, m.cout, 9,
                     {{n.P(mname(m.idx, "weight")), n.P(mname(m.idx, "bias")), 0, m.cout, 0, m.cin}});
       if (rc) return rc;
@@ -709,7 +713,10 @@ static int build_packed_layout(Net& n) {
       add_copy(mname(m.idx, "weight"));
       add_copy(mname(m.idx, "bias"));
     }
-    if ((rc = conv3_layout(nextm(), n.in_cpad, false))) return rc;      // stem: Cin padded to 8
+    {
+      Module& ms = nextm();                                              // stem: Cin padded to 8
+      if (!stem_layout(ms) && (rc = conv3_layout(ms, n.in_cpad, false))) return rc;
+    }
     std::vector<int> hc{c.nf};
     int ich = c.nf;
     for (int l = 0; l < c.n_levels; ++l) {
@@ -1044,6 +1051,25 @@ struct Builder {
     return o.out;
   }
 
+  // the fused first layer (stem.hip): x, y (+ sigma z) in the caller's NCHW -> nf channels NHWC + tile partials for the next GroupNorm
+  size_t stem(const PackedConv& pc, const Module& m, int S) {
+    const csd_unet_config& c = n.cfg;
+    Op o;
+    o.kind = OP_STEM;
+    o.pk0 = pc.w_off; o.pk1 = pc.b_off;
+    o.i0 = m.cout; o.i4 = pc.ns;
+    const size_t out_elems = (size_t)B * S * S * m.cout;
+    o.out = alloc_(out_elems);
+    const int tpi = stem_tiles_per_image(S);
+    o.stats = alloc_((size_t)B * tpi * m.cout * 2 * 2);      // doubles; never released (small)
+    tile_stats[o.out] = TileStats{o.stats, tpi};
+    o.cls = CSD_PROF_CONV3X3;
+    pl.ops.push_back(o);
+    const int cin = c.x_channels + c.y_channels;
+    count(2.0 * out_elems * cin * 9, ((double)B * S * S * cin + (double)out_elems) * 4);
+    return o.out;
+  }
+
   size_t res_block(const Module& m, size_t x0, size_t x1, int c0, int c1, int hw_side) {
     const std::string k = std::to_string(m.idx);
     const int hw = hw_side * hw_side;
@@ -1109,10 +1135,24 @@ struct Builder {
     const std::string k = std::to_string(m.idx);
     const int hw = side * side, os = m.up ? side * 2 : side / 2;
     gn(x, NONE, m.cin, 0, hw, mname(m.idx, "GroupNorm_0.weight"), mname(m.idx, "GroupNorm_0.bias"));
-    const size_t ha = gn_apply32(x, m.cin, hw, n.cfg.act);
-    const size_t hr = fir(ha, side, m.cin, m.up != 0);
-    ar.release(ha);
-    const size_t xr = fir(x, side, m.cin, m.up != 0);
+    size_t hr, xr;
+    if (m.cin % 4 == 0) {      // FIR(act(GroupNorm(x))) and FIR(x) in one pass over x (elementwise.hip: fir_resample2)
+      Op o;
+      o.kind = OP_FIR2;
+      o.a = x; o.d = nscale; o.e = nshift; o.i0 = side; o.i1 = m.cin; o.i2 = m.up ? 1 : 0; o.act = n.cfg.act;
+      o.out = alloc_((size_t)B * os * os * m.cin);       // FIR(h)
+      o.c = alloc_((size_t)B * os * os * m.cin);         // FIR(x)
+      o.cls = CSD_PROF_OTHER;
+      o.bytes = (double)B * (hw + 2.0 * os * os) * m.cin * 4;
+      pl.ops.push_back(o);
+      pl.launches += 1;
+      hr = o.out; xr = o.c;
+    } else {
+      const size_t ha = gn_apply32(x, m.cin, hw, n.cfg.act);
+      hr = fir(ha, side, m.cin, m.up != 0);
+      ar.release(ha);
+      xr = fir(x, side, m.cin, m.up != 0);
+    }
     const size_t tcol = (size_t)n.dense_col.at(m.idx);
     const size_t h1 = conv(k + ".Conv_0", hr, NONE, os, os, 1, 1, 0, false, 0, NONE, tcol, false);
     ar.release(hr);
@@ -1208,11 +1248,15 @@ static int build_plan(Net& n, int B, Plan** out) {
       for (int i = 0; i < c.n_attn; ++i) if (c.attn_resolutions[i] == res) return true;
       return false;
     };
+    const PackedConv& stem_pc = n.pconvs[n.pconv_by_name.at(std::to_string(n.mods[(c.embedding_type == 1 ? 1 : 0) + 2].idx))];
     Op as;
     as.kind = OP_ASSEMBLE;
-    as.out = bd.alloc_((size_t)B * S * S * n.in_cpad);
-    pl.ops.push_back(as);
-    pl.launches += 1;
+    as.out = NONE;
+    if (!stem_pc.stem || c.progressive_input == 1) {      // (the input pyramid reads the assembled tensor)
+      as.out = bd.alloc_((size_t)B * S * S * n.in_cpad);
+      pl.ops.push_back(as);
+      pl.launches += 1;
+    }
     // time embedding: Fourier features of the label (or the sinusoidal embedding), two Linear layers, all Dense_0
     size_t emb;
     int emb_dim = nf;
@@ -1267,7 +1311,8 @@ static int build_plan(Net& n, int B, Plan** out) {
     int pyr_side = S;
     {
       const Module& m = next_mod();
-      const size_t h0 = bd.conv(std::to_string(m.idx), as.out, NONE, S, S, 1, 1, 0, false, 0, NONE, NONE, false, channels);
+      const size_t h0 = stem_pc.stem ? bd.stem(stem_pc, m, S)
+                                     : bd.conv(std::to_string(m.idx), as.out, NONE, S, S, 1, 1, 0, false, 0, NONE, NONE, false, channels);
       hs.push_back({h0, m.cout});
     }
     int in_ch = nf;
@@ -1430,20 +1475,7 @@ static int build_plan(Net& n, int B, Plan** out) {
     const Module& m = next_mod();
     size_t h0;
     if (stem_pc.stem) {
-      Op o;
-      o.kind = OP_STEM;
-      o.pk0 = stem_pc.w_off; o.pk1 = stem_pc.b_off;
-      o.i0 = m.cout; o.i4 = stem_pc.ns;
-      const size_t out_elems = (size_t)B * S * S * m.cout;
-      o.out = bd.alloc_(out_elems);
-      const int tpi = stem_tiles_per_image(S);
-      o.stats = bd.alloc_((size_t)B * tpi * m.cout * 2 * 2);      // doubles; never released (small)
-      bd.tile_stats[o.out] = Builder::TileStats{o.stats, tpi};
-      o.cls = CSD_PROF_CONV3X3;
-      pl.ops.push_back(o);
-      const int cin = c.x_channels + c.y_channels;
-      bd.count(2.0 * out_elems * cin * 9, ((double)B * S * S * cin + (double)out_elems) * 4);
-      h0 = o.out;
+      h0 = bd.stem(stem_pc, m, S);
     } else {
       h0 = bd.conv(std::to_string(m.idx), as.out, NONE, S, S, 1, 1, 0, false, 0, NONE, NONE, false,
                    c.x_channels + c.y_channels);
@@ -1590,6 +1622,9 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         break;
       case OP_FIR:
         rc = fir_resample_nhwc_launch(W(o.a), W(o.out), B, o.i0, o.i0, o.i1, c.fir_kernel, o.i2, s);
+        break;
+      case OP_FIR2:
+        rc = fir_resample2_nhwc_launch(W(o.a), W(o.d), W(o.e), W(o.c), W(o.out), B, o.i0, o.i0, o.i1, c.fir_kernel, o.i2, o.act, s);
         break;
       case OP_GN_APPLY32:
         rc = gn_apply_launch(W(o.a), W(o.d), W(o.e), W(o.out), B, o.i1, o.i0, o.act, s);
