@@ -548,7 +548,10 @@ static int build_packed_layout(Net& n) {
     // stream itself: the gn_apply16 pass and its fp16 planes disappear)
     ConvPlan ffp = pc.proto;
     ffp.IH = ffp.IW = ffp.OH = ffp.OW = cur_res;
-    if (net_ns && normed && stride1 && !resample && n.cfg.act == CSD_ACT_SWISH && convff_supported(ffp, net_ns)) {
+    // (NCSN++ up / down blocks: Conv_0 reads FIR(act(GroupNorm(x))) - an fp32 tensor that is already normalised and activated, so the same
+    // kernel takes it with its NORM = false prologue (plain split; the values stay far inside e4m3): no split pass, no fp16 planes)
+    const bool fir_act_input = resample && !upsample && normed && n.cfg.arch == 1;
+    if (net_ns && normed && stride1 && (!resample || fir_act_input) && n.cfg.act == CSD_ACT_SWISH && convff_supported(ffp, net_ns)) {
       pc.ns = n.cfg.precision == CSD_PREC_F16F8 ? 3 : net_ns;      // 3: fp16 hi*hi + fp8 corrections (conv_ff.hip)
       pc.ff = true;
       pc.proto.KC = 16;
@@ -965,7 +968,7 @@ struct Builder {
     }
     if (fused) {
     } else if (pc.ff) {
-      if (external_nchw || !norm || stride != 1 || up) { set_error("fused-prologue conv on an unsupported layer"); rc = CSD_ERR_INVALID; return NONE; }
+      if (external_nchw || stride != 1 || up) { set_error("fused-prologue conv on an unsupported layer"); rc = CSD_ERR_INVALID; return NONE; }
       if (convff_plan_tiles(&o.cp, pc.ns)) { rc = CSD_ERR_INVALID; return NONE; }
     } else if (pc.q) {
       if (external_nchw || (!norm && o.cp.C1 != 0) || (stride == 2 && (norm || up))) { set_error("quad fp16 conv on an unsupported layer"); rc = CSD_ERR_INVALID; return NONE; }
