@@ -493,6 +493,74 @@ __global__ void fir_resample2_nhwc4_kernel(const float4* __restrict__ in, const 
     out_h[i] = ah;
   }
 }
+// LDS-tiled form of the same pass (C % 16 == 0, whole output tiles): a workgroup stages the raw input patch of a TO x TO output tile x 16
+// channels, activates every patch element ONCE (the per-output form recomputes the SiLU for each of an element's 4 (down) / 16 (up) uses
+// and stays vector-bound), then every thread gathers its taps of both tensors from LDS.  Same taps, same accumulation order.
+template <bool UP>
+__global__ __launch_bounds__(256) void fir_resample2_tiled_kernel(const float4* __restrict__ in, const float* __restrict__ nscale,
+                                                                  const float* __restrict__ nshift, float4* __restrict__ out_x,
+                                                                  float4* __restrict__ out_h, int H, int W, int C4, int act, Fir16 f) {
+  constexpr int TO = UP ? 16 : 8;                       // output tile
+  constexpr int PH = UP ? TO / 2 + 2 : 2 * TO + 2;      // input patch (rows = columns)
+  __shared__ float4 raw[PH * PH * 4], actv[PH * PH * 4];
+  const int OH = UP ? H * 2 : H / 2, OW = UP ? W * 2 : W / 2;
+  const int tiles_x = OW / TO, tiles_y = OH / TO, cgs = C4 / 4;
+  int t = blockIdx.x;
+  const int cg = t % cgs; t /= cgs;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y;
+  const size_t b = t / tiles_y;
+  const int oy0 = ty * TO, ox0 = tx * TO;
+  const int iy0 = UP ? oy0 / 2 - 1 : 2 * oy0 - 1, ix0 = UP ? ox0 / 2 - 1 : 2 * ox0 - 1;
+  const int tid = threadIdx.x;
+  const int c4 = tid & 3;                               // this thread's float4 of the 16-channel group (patch staging AND outputs)
+  const float4* src = in + b * (size_t)H * W * C4 + cg * 4 + c4;
+  const float4 sc = *reinterpret_cast<const float4*>(nscale + (b * C4 + cg * 4 + c4) * 4);
+  const float4 sh = *reinterpret_cast<const float4*>(nshift + (b * C4 + cg * 4 + c4) * 4);
+  auto actf = [&](float v) __attribute__((always_inline)) {
+    return act == CSD_ACT_SWISH ? v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)) : ew_act(v, act);
+  };
+  for (int p = tid >> 2; p < PH * PH; p += 64) {
+    const int py = p / PH, px = p - py * PH;
+    const int iy = iy0 + py, ix = ix0 + px;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), h = v;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {      // (outside the image both tensors contribute nothing)
+      v = src[((size_t)iy * W + ix) * C4];
+      h = make_float4(actf(v.x * sc.x + sh.x), actf(v.y * sc.y + sh.y), actf(v.z * sc.z + sh.z), actf(v.w * sc.w + sh.w));
+    }
+    raw[p * 4 + c4] = v;
+    actv[p * 4 + c4] = h;
+  }
+  __syncthreads();
+  for (int o = tid >> 2; o < TO * TO; o += 64) {
+    const int ly = o / TO, lx = o - ly * TO;
+    const int oy = oy0 + ly, ox = ox0 + lx;
+    float4 ax = make_float4(0.f, 0.f, 0.f, 0.f), ah = ax;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      const int my = UP ? oy + ky - 2 : oy * 2 + ky - 1;
+      if (my < 0 || (UP && (my & 1))) continue;
+      const int iy = UP ? my >> 1 : my;
+      if (iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const int mx = UP ? ox + kx - 2 : ox * 2 + kx - 1;
+        if (mx < 0 || (UP && (mx & 1))) continue;
+        const int ix = UP ? mx >> 1 : mx;
+        if (ix >= W) continue;
+        const int p = (iy - iy0) * PH + (ix - ix0);
+        const float4 v = raw[p * 4 + c4], h = actv[p * 4 + c4];
+        const float w = f.k[(3 - ky) * 4 + (3 - kx)];
+        ax.x += v.x * w; ax.y += v.y * w; ax.z += v.z * w; ax.w += v.w * w;
+        ah.x += h.x * w; ah.y += h.y * w; ah.z += h.z * w; ah.w += h.w * w;
+      }
+    }
+    const size_t oi = ((b * OH + oy) * OW + ox) * C4 + cg * 4 + c4;
+    out_x[oi] = ax;
+    out_h[oi] = ah;
+  }
+}
+
 int fir_resample2_nhwc_launch(const float* in, const float* nscale, const float* nshift, float* out_x, float* out_h, int B, int H, int W,
                               int C, const float* taps4, int up, int act, hipStream_t s) {
   CSD_REQUIRE(C % 4 == 0, "fir_resample2: C = %d is not a multiple of 4", C);
@@ -502,6 +570,18 @@ int fir_resample2_nhwc_launch(const float* in, const float* nscale, const float*
     for (int b = 0; b < 4; ++b) { f.k[a * 4 + b] = taps4[a] * taps4[b]; sum += f.k[a * 4 + b]; }
   for (int a = 0; a < 16; ++a) f.k[a] = f.k[a] / sum * (up ? 4.f : 1.f);
   const size_t total = (size_t)B * (up ? H * 2 : H / 2) * (up ? W * 2 : W / 2) * C;
+  {
+    const int OH = up ? H * 2 : H / 2, OW = up ? W * 2 : W / 2, TO = up ? 16 : 8;
+    // (measured at 160^2 / 80^2 x 96..192 channels: upsampling 713 -> 372 us, 328 -> 175; downsampling is faster on the per-output kernel -
+    // 467 against 563 us - whose 16 taps already hit L1: the tiled form is used for up only)
+    if (up && C % 16 == 0 && OH % TO == 0 && OW % TO == 0) {
+      const size_t nwg = (size_t)B * (OH / TO) * (OW / TO) * (C / 16);
+      hipLaunchKernelGGL(fir_resample2_tiled_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, s, reinterpret_cast<const float4*>(in), nscale,
+                         nshift, reinterpret_cast<float4*>(out_x), reinterpret_cast<float4*>(out_h), H, W, C / 4, act, f);
+      CSD_LAUNCH_CHECK();
+      return CSD_OK;
+    }
+  }
   hipLaunchKernelGGL(fir_resample2_nhwc4_kernel, dim3((unsigned)std::min<size_t>(cdiv64(total / 4, 256), 65536)), dim3(256), 0, s,
                      reinterpret_cast<const float4*>(in), nscale, nshift, reinterpret_cast<float4*>(out_x), reinterpret_cast<float4*>(out_h),
                      H, W, C / 4, up, act, f, total / 4);
