@@ -493,17 +493,17 @@ __global__ void fir_resample2_nhwc4_kernel(const float4* __restrict__ in, const 
     out_h[i] = ah;
   }
 }
-// LDS-tiled form of the same pass (C % 16 == 0, whole output tiles): a workgroup stages the raw input patch of a TO x TO output tile x 16
-// channels, activates every patch element ONCE (the per-output form recomputes the SiLU for each of an element's 4 (down) / 16 (up) uses
-// and stays vector-bound), then every thread gathers its taps of both tensors from LDS.  Same taps, same accumulation order.
-template <bool UP>
-__global__ __launch_bounds__(256) void fir_resample2_tiled_kernel(const float4* __restrict__ in, const float* __restrict__ nscale,
+// LDS-tiled form of the same pass for the UPSAMPLING blocks (C % 16 == 0, whole 16 x 16 output tiles): a workgroup stages the raw 10 x 10 input
+// patch x 16 channels, activates every patch element ONCE (the per-output form recomputes the SiLU for each of an element's 16 uses and stays
+// vector-bound: 713 us at 80^2 -> 160^2 against 372 here), then every thread gathers its taps of both tensors from LDS.  Same taps, same
+// accumulation order.  (Downsampling measured faster on the per-output kernel - 467 against 563 us - whose taps already hit L1.)
+__global__ __launch_bounds__(256) void fir_upsample2_tiled_kernel(const float4* __restrict__ in, const float* __restrict__ nscale,
                                                                   const float* __restrict__ nshift, float4* __restrict__ out_x,
                                                                   float4* __restrict__ out_h, int H, int W, int C4, int act, Fir16 f) {
-  constexpr int TO = UP ? 16 : 8;                       // output tile
-  constexpr int PH = UP ? TO / 2 + 2 : 2 * TO + 2;      // input patch (rows = columns)
+  constexpr int TO = 16;                                // output tile
+  constexpr int PH = TO / 2 + 2;                        // input patch (rows = columns)
   __shared__ float4 raw[PH * PH * 4], actv[PH * PH * 4];
-  const int OH = UP ? H * 2 : H / 2, OW = UP ? W * 2 : W / 2;
+  const int OH = H * 2, OW = W * 2;
   const int tiles_x = OW / TO, tiles_y = OH / TO, cgs = C4 / 4;
   int t = blockIdx.x;
   const int cg = t % cgs; t /= cgs;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void fir_resample2_tiled_kernel(const float4* 
   const int ty = t % tiles_y;
   const size_t b = t / tiles_y;
   const int oy0 = ty * TO, ox0 = tx * TO;
-  const int iy0 = UP ? oy0 / 2 - 1 : 2 * oy0 - 1, ix0 = UP ? ox0 / 2 - 1 : 2 * ox0 - 1;
+  const int iy0 = oy0 / 2 - 1, ix0 = ox0 / 2 - 1;
   const int tid = threadIdx.x;
   const int c4 = tid & 3;                               // this thread's float4 of the 16-channel group (patch staging AND outputs)
   const float4* src = in + b * (size_t)H * W * C4 + cg * 4 + c4;
@@ -538,15 +538,15 @@ __global__ __launch_bounds__(256) void fir_resample2_tiled_kernel(const float4* 
     float4 ax = make_float4(0.f, 0.f, 0.f, 0.f), ah = ax;
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
-      const int my = UP ? oy + ky - 2 : oy * 2 + ky - 1;
-      if (my < 0 || (UP && (my & 1))) continue;
-      const int iy = UP ? my >> 1 : my;
+      const int my = oy + ky - 2;
+      if (my < 0 || (my & 1)) continue;
+      const int iy = my >> 1;
       if (iy >= H) continue;
 #pragma unroll
       for (int kx = 0; kx < 4; ++kx) {
-        const int mx = UP ? ox + kx - 2 : ox * 2 + kx - 1;
-        if (mx < 0 || (UP && (mx & 1))) continue;
-        const int ix = UP ? mx >> 1 : mx;
+        const int mx = ox + kx - 2;
+        if (mx < 0 || (mx & 1)) continue;
+        const int ix = mx >> 1;
         if (ix >= W) continue;
         const int p = (iy - iy0) * PH + (ix - ix0);
         const float4 v = raw[p * 4 + c4], h = actv[p * 4 + c4];
@@ -570,17 +570,12 @@ int fir_resample2_nhwc_launch(const float* in, const float* nscale, const float*
     for (int b = 0; b < 4; ++b) { f.k[a * 4 + b] = taps4[a] * taps4[b]; sum += f.k[a * 4 + b]; }
   for (int a = 0; a < 16; ++a) f.k[a] = f.k[a] / sum * (up ? 4.f : 1.f);
   const size_t total = (size_t)B * (up ? H * 2 : H / 2) * (up ? W * 2 : W / 2) * C;
-  {
-    const int OH = up ? H * 2 : H / 2, OW = up ? W * 2 : W / 2, TO = up ? 16 : 8;
-    // (measured at 160^2 / 80^2 x 96..192 channels: upsampling 713 -> 372 us, 328 -> 175; downsampling is faster on the per-output kernel -
-    // 467 against 563 us - whose 16 taps already hit L1: the tiled form is used for up only)
-    if (up && C % 16 == 0 && OH % TO == 0 && OW % TO == 0) {
-      const size_t nwg = (size_t)B * (OH / TO) * (OW / TO) * (C / 16);
-      hipLaunchKernelGGL(fir_resample2_tiled_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, s, reinterpret_cast<const float4*>(in), nscale,
-                         nshift, reinterpret_cast<float4*>(out_x), reinterpret_cast<float4*>(out_h), H, W, C / 4, act, f);
-      CSD_LAUNCH_CHECK();
-      return CSD_OK;
-    }
+  if (up && C % 16 == 0 && (H * 2) % 16 == 0 && (W * 2) % 16 == 0) {
+    const size_t nwg = (size_t)B * (H * 2 / 16) * (W * 2 / 16) * (C / 16);
+    hipLaunchKernelGGL(fir_upsample2_tiled_kernel, dim3((unsigned)nwg), dim3(256), 0, s, reinterpret_cast<const float4*>(in), nscale, nshift,
+                       reinterpret_cast<float4*>(out_x), reinterpret_cast<float4*>(out_h), H, W, C / 4, act, f);
+    CSD_LAUNCH_CHECK();
+    return CSD_OK;
   }
   hipLaunchKernelGGL(fir_resample2_nhwc4_kernel, dim3((unsigned)std::min<size_t>(cdiv64(total / 4, 256), 65536)), dim3(256), 0, s,
                      reinterpret_cast<const float4*>(in), nscale, nshift, reinterpret_cast<float4*>(out_x), reinterpret_cast<float4*>(out_h),
