@@ -521,7 +521,10 @@ __global__ __launch_bounds__(256) void sum_inner_kernel(const float* __restrict_
 }
 
 // out[c] = sum_r x[r][c]  (fp64 accumulation, fixed order): 64 columns x 4 row lanes per workgroup, rows r = lane, lane+4, ...
-__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C) {
+// (blockIdx.y = 1: the second (x1, out1) pair of the same shape - the dgamma / dbeta rows of one GroupNorm backward in one launch)
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C,
+                                                       const float* __restrict__ x1, float* __restrict__ out1) {
+  if (blockIdx.y) { x = x1; out = out1; }
   __shared__ double sh[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -786,7 +789,14 @@ extern "C" int csd_sum_inner(const float* x, float* out, int64_t rows, int64_t i
 
 extern "C" int csd_sum_rows(const float* x, float* out, int R, int C, void* stream) {
   CSD_REQUIRE(x && out && R > 0 && C > 0, "sum_rows: bad arguments");
-  hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, x, out, R, C);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, x, out, R, C, nullptr, nullptr);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
+
+int csd::sum_rows2(const float* x0, float* out0, const float* x1, float* out1, int R, int C, void* stream) {
+  CSD_REQUIRE(x0 && out0 && x1 && out1 && R > 0 && C > 0, "sum_rows2: bad arguments");
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(cdiv(C, 64), 2), dim3(256), 0, (hipStream_t)stream, x0, out0, R, C, x1, out1);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }

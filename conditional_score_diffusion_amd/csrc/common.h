@@ -189,12 +189,19 @@ int gn_finalize_tiles_launch(const double* p0, int tpi0, int C0, const double* p
                              hipStream_t s);
 // stand-alone apply: y = act(x*scale + shift), NHWC
 // mask != null: y = dropout(act(x*scale + shift)) with the mask csd_dropout would draw for (seed, stream_id), written to mask
+// hi (/ lo) != null: the fp16 hi (| lo) planes of y too ([B*HW][C] halves each), as gn_apply16 would split y
 int gn_apply_launch(const float* x, const float* nscale, const float* nshift, float* y, int B, int HW,
-                    int C, int act, hipStream_t s, float* mask = nullptr, float p_drop = 0.f, uint64_t seed = 0, uint64_t stream_id = 0);
+                    int C, int act, hipStream_t s, float* mask = nullptr, float p_drop = 0.f, uint64_t seed = 0, uint64_t stream_id = 0,
+                    void* hi = nullptr, void* lo = nullptr);
+// two csd_sum_rows of one shape in one launch (backward.hip)
+int sum_rows2(const float* x0, float* out0, const float* x1, float* out1, int R, int C, void* stream);
 // csd_groupnorm_act_nhwc with the training forward's dropout fused into the apply pass (train_nhwc.hip)
 int groupnorm_act_dropout_nhwc(const float* x, const float* gamma, const float* beta, float* y, float* rs, float* ms, float* mask,
                                float p_drop, uint64_t seed, uint64_t stream_id, int B, int C, int HW, int groups, float eps, int act,
-                               void* scratch, void* stream);
+                               void* scratch, void* stream, void* planes = nullptr, int plane_count = 0);
+// the operand planes conv2d_impl would split an NHWC source into (quad schedule): 0 = it would not (other kernel), else 1 or 2 planes of
+// B*H*W*Cin halves each, hi first
+int conv2d_operand_planes(int B, int Cin, int Cout, int H, int W, int ksize, int stride, int pad_mode, int up2, int precision);
 
 // ---------------------------------------------------------------------------------------
 // attention core on NHWC qkv (attention.hip): qkv [B, L, ld] with q at +0, k at +C, v at +2C
@@ -222,7 +229,8 @@ int fourier_embedding_launch(const float* t, const float* W, float* out, int B, 
 // per-operator convolution of the C ABI (ops_api.hip) with an optional NHWC residual added in the epilogue; GroupNorm backward with
 // an optional addend (train_nhwc.hip): the fused forms the planned training graph (train_graph.h) uses
 int conv2d_impl(const float* x, const float* weight, const float* bias, const float* res, const float* temb, float* y, int B, int Cin,
-                int Cout, int H, int W, int ksize, int stride, int pad_mode, int up2, int precision, int layout, void* scratch, void* stream);
+                int Cout, int H, int W, int ksize, int stride, int pad_mode, int up2, int precision, int layout, void* scratch, void* stream,
+                const void* planes = nullptr);      // planes: the pre-split operand (conv2d_operand_planes() > 0), x is then not read
 int groupnorm_act_backward_nhwc_add(const float* x, const float* gamma, const float* beta, const float* rs, const float* ms,
                                     const float* dy, const float* add, float* dx, float* dgamma_rows, float* dbeta_rows,
                                     int row_stride, int B, int C, int HW, int groups, int act, void* scratch, void* stream);

@@ -203,9 +203,19 @@ __device__ __forceinline__ float gn_act(float v, int act) {
   }
 }
 
+// (hi != null: the fp16 hi | lo planes of y as well - what gn_apply16 would make of y in a second pass; the training forward's conv reads them)
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gn_store_planes(half4_t* __restrict__ hi, half4_t* __restrict__ lo, size_t i, const float4& o) {
+  half4_t h, l;
+  h[0] = (_Float16)o.x; h[1] = (_Float16)o.y; h[2] = (_Float16)o.z; h[3] = (_Float16)o.w;
+  l[0] = (_Float16)(o.x - (float)h[0]); l[1] = (_Float16)(o.y - (float)h[1]);
+  l[2] = (_Float16)(o.z - (float)h[2]); l[3] = (_Float16)(o.w - (float)h[3]);
+  hi[i] = h;
+  if (lo) lo[i] = l;
+}
 __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ nscale,
                                 const float* __restrict__ nshift, float* __restrict__ y, int HW, int C,
-                                int act, size_t total4) {
+                                int act, size_t total4, half4_t* __restrict__ hi, half4_t* __restrict__ lo) {
   const int C4 = C >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
        i += (size_t)gridDim.x * blockDim.x) {
@@ -221,6 +231,7 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
     o.z = gn_act(v.z * sc.z + sh.z, act);
     o.w = gn_act(v.w * sc.w + sh.w, act);
     reinterpret_cast<float4*>(y)[i] = o;
+    if (hi) gn_store_planes(hi, lo, i, o);
   }
 }
 
@@ -228,7 +239,7 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
 // i of (seed, stream) - element for element what csd_dropout (backward.hip) draws, so the fused and the two-launch form agree bitwise
 __global__ void gn_apply_dropout_kernel(const float* __restrict__ x, const float* __restrict__ nscale, const float* __restrict__ nshift,
                                         float* __restrict__ y, float* __restrict__ mask, int HW, int C, int act, size_t total4, float p,
-                                        uint64_t seed, uint64_t stream_id) {
+                                        uint64_t seed, uint64_t stream_id, half4_t* __restrict__ hi, half4_t* __restrict__ lo) {
   const int C4 = C >> 2;
   const float keep = 1.0f / (1.0f - p);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
@@ -259,6 +270,7 @@ __global__ void gn_apply_dropout_kernel(const float* __restrict__ x, const float
     o.w = gn_act(v.w * sc.w + sh.w, act) * m.w;
     reinterpret_cast<float4*>(y)[i] = o;
     reinterpret_cast<float4*>(mask)[i] = m;
+    if (hi) gn_store_planes(hi, lo, i, o);
   }
 }
 
@@ -524,14 +536,15 @@ int gn_finalize_tiles_launch(const double* p0, int tpi0, int C0, const double* p
 }
 
 int gn_apply_launch(const float* x, const float* nscale, const float* nshift, float* y, int B, int HW, int C,
-                    int act, hipStream_t s, float* mask, float p_drop, uint64_t seed, uint64_t stream_id) {
+                    int act, hipStream_t s, float* mask, float p_drop, uint64_t seed, uint64_t stream_id, void* hi, void* lo) {
   const size_t total4 = (size_t)B * HW * C / 4;
   const int grid = (int)std::min<size_t>(cdiv64(total4, 256), 2048 * 4);
   if (mask)
     hipLaunchKernelGGL(gn_apply_dropout_kernel, dim3(grid), dim3(256), 0, s, x, nscale, nshift, y, mask, HW, C, act, total4, p_drop, seed,
-                       stream_id);
+                       stream_id, static_cast<half4_t*>(hi), static_cast<half4_t*>(lo));
   else
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, s, x, nscale, nshift, y, HW, C, act, total4);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, s, x, nscale, nshift, y, HW, C, act, total4, static_cast<half4_t*>(hi),
+                       static_cast<half4_t*>(lo));
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }

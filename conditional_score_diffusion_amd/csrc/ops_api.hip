@@ -101,8 +101,19 @@ extern "C" size_t csd_conv_scratch_bytes(int B, int Cin, int Cout, int H, int W,
 // (the data gradient of a convolution, without materialising the flipped weight)
 // res: optional NHWC tensor of the output's shape added in the epilogue (y NHWC only) - the block's shortcut, the attention input;
 // temb: optional [B, Cout] row added per sample (Dense_0(act(temb))[:, :, None, None])
+int csd::conv2d_operand_planes(int B, int Cin, int Cout, int H, int W, int ksize, int stride, int pad_mode, int up2, int precision) {
+  ConvPlan p;
+  if (conv_api_plan(&p, B, Cin, Cout, H, W, ksize, stride, pad_mode, up2)) return 0;
+  const int ns = precision_ns(precision);
+  if (!ns || Cin % 32 != 0 || CSD_TUNE_ENV("CSD_NO_Q")) return 0;
+  ConvPlan q = p;
+  q.C0 = Cin; q.C1 = 0;
+  return (conv16q_supported(q, ns) && conv16q_plan_tiles(&q, ns) == CSD_OK) ? (ns >= 2 ? 2 : 1) : 0;
+}
+
 int csd::conv2d_impl(const float* x, const float* weight, const float* bias, const float* res, const float* temb, float* y, int B,
-                     int Cin, int Cout, int H, int W, int ksize, int stride, int pad_mode, int up2, int precision, int layout, void* scratch, void* stream) {
+                     int Cin, int Cout, int H, int W, int ksize, int stride, int pad_mode, int up2, int precision, int layout, void* scratch, void* stream,
+                     const void* planes) {
   CSD_REQUIRE(x && weight && y && scratch, "conv2d: null argument");
   CSD_REQUIRE(precision >= CSD_PREC_F32 && precision <= CSD_PREC_F16F8, "conv2d: bad precision id %d", precision);
   const bool in_nhwc = layout & 1, out_nhwc = layout & 2;
@@ -141,10 +152,11 @@ int csd::conv2d_impl(const float* x, const float* weight, const float* bias, con
   if (in_nhwc) xh = const_cast<float*>(x);
   else if ((rc = nchw_to_nhwc_launch(x, xh, B, Cin, H * W, p.C0, p.C0, s))) return rc;
   const int wl = (layout & 4) ? 2 : 0;
+  CSD_REQUIRE(!planes || quad, "conv2d: pre-split operand planes on a layer that does not take them");
   if (quad) {
-    void* hi = xh_scratch;
+    void* hi = planes ? const_cast<void*>(planes) : static_cast<void*>(xh_scratch);
     void* lo = ns == 2 ? static_cast<void*>(static_cast<char*>(hi) + (size_t)B * H * W * Cin * 2) : nullptr;
-    if ((rc = gn_apply16_launch(x, nullptr, Cin, 0, nullptr, nullptr, hi, lo, B, H * W, CSD_ACT_NONE, s))) return rc;
+    if (!planes && (rc = gn_apply16_launch(x, nullptr, Cin, 0, nullptr, nullptr, hi, lo, B, H * W, CSD_ACT_NONE, s))) return rc;
     if ((rc = conv16q_pack_weight(p, ns, weight, wl, Cin, Cout, 0, wp, s))) return rc;
     const bool bias_inplace = bias && Cout == p.CoutPad && (reinterpret_cast<uintptr_t>(bias) & 15) == 0;   // no padded copy needed
     if (bias && !bias_inplace) {

@@ -128,10 +128,10 @@ struct TG {
 
   // ---- operator wrappers (scratch is a temporary above `top`) ---------------------------------------------------------
   int conv(const float* x, const float* w, const float* b, float* y, int Cin, int Cout, int H, int k, int stride, int dpad,
-           int up2, int layout, const float* res = nullptr, const float* temb = nullptr) {
+           int up2, int layout, const float* res = nullptr, const float* temb = nullptr, const void* planes = nullptr) {
     const size_t m = top;
     float* sc = alloc_bytes(csd_conv_scratch_bytes(B, Cin, Cout, H, H, k, up2));
-    TG_RUN(conv2d_impl(x, w, b, res, temb, y, B, Cin, Cout, H, H, k, stride, dpad, up2, prec, layout, sc, s));
+    TG_RUN(conv2d_impl(x, w, b, res, temb, y, B, Cin, Cout, H, H, k, stride, dpad, up2, prec, layout, sc, s, planes));
     top = m;
     return CSD_OK;
   }
@@ -143,11 +143,13 @@ struct TG {
     return CSD_OK;
   }
   // (mask != null: nn.Dropout of the activated tensor in the same pass; the mask csd_dropout would draw for (seed, drop_id))
+  // (planes != null: the fp16 operand planes of y for the conv that follows, written by the same pass - conv2d_operand_planes())
   int gn(const float* x, const float* gamma, const float* beta, float* y, float* rs, float* ms, int C, int H, int a, float* mask = nullptr,
-         uint64_t drop_id = 0) {
+         uint64_t drop_id = 0, void* planes = nullptr, int plane_count = 0) {
     const size_t m = top;
     float* sc = alloc_bytes(csd_groupnorm_nhwc_scratch_bytes(B, C, H * H));
-    TG_RUN(groupnorm_act_dropout_nhwc(x, gamma, beta, y, rs, ms, mask, p_drop, seed, drop_id, B, C, H * H, 32, 1e-6f, a, sc, s));
+    TG_RUN(groupnorm_act_dropout_nhwc(x, gamma, beta, y, rs, ms, mask, p_drop, seed, drop_id, B, C, H * H, 32, 1e-6f, a, sc, s, planes,
+                                      plane_count));
     top = m;
     return CSD_OK;
   }
@@ -159,8 +161,7 @@ struct TG {
     float* brow = alloc((size_t)B * C);
     float* sc = alloc_bytes(csd_groupnorm_nhwc_scratch_bytes(B, C, H * H));
     TG_RUN(groupnorm_act_backward_nhwc_add(x, gamma, beta, rs, ms, dy, add, dx, grow, brow, C, B, C, H * H, 32, a, sc, s));
-    TG_RUN(csd_sum_rows(grow, dgamma, B, C, s));
-    TG_RUN(csd_sum_rows(brow, dbeta, B, C, s));
+    TG_RUN(sum_rows2(grow, dgamma, brow, dbeta, B, C, s));
     top = m;
     return CSD_OK;
   }
@@ -211,44 +212,53 @@ struct TG {
     const float* h = st.t[in].p;
     TStep sp;
     sp.kind = TS_RES; sp.mod = m.idx; sp.in0 = in;
+    // persistent tensors first (the backward reads them), temporaries - the convs' operand planes, the shortcut - above them
     float* a0 = alloc(act_n(H, cin));                // act(GroupNorm_0(h)): Conv_0's operand
     float* rs0 = alloc((size_t)B * cin); float* ms0 = alloc((size_t)B * cin);
-    int rc = gn(h, W(m.idx, "GroupNorm_0.weight"), W(m.idx, "GroupNorm_0.bias"), a0, rs0, ms0, cin, H, act);
-    if (rc) return rc;
     float* c0 = alloc(act_n(H, cout));               // Conv_0(.) + Dense_0(act(temb))[:, None, None, :]: GroupNorm_1's input
-    {
-      const size_t mk = top;
-      float* d = nullptr;
-      if (c.conditional) {                           // the time-embedding row rides in Conv_0's epilogue
-        d = alloc((size_t)B * cout);
-        // (act(temb) is computed once per forward: every block's Dense_0 used to redo it inside its own latency-bound launch)
-        TG_RUN(csd_linear(st.temb2_act, W(m.idx, "Dense_0.weight"), W(m.idx, "Dense_0.bias"), d, B, 4 * c.nf, cout, CSD_ACT_NONE, s));
-      }
-      rc = conv(a0, W(m.idx, "Conv_0.weight"), W(m.idx, "Conv_0.bias"), c0, cin, cout, H, 3, 1, 0, 0, 3, nullptr, d);
-      if (rc) return rc;
-      top = mk;
-    }
     float* a1 = alloc(act_n(H, cout));               // dropout(act(GroupNorm_1(.))): Conv_1's operand
     float* rs1 = alloc((size_t)B * cout); float* ms1 = alloc((size_t)B * cout);
     float* mask = nullptr;
     ++drop_count;
     sp.drop_id = (call << 16) + (uint64_t)drop_count;
     if (p_drop > 0.f) mask = alloc(act_n(H, cout));
-    rc = gn(c0, W(m.idx, "GroupNorm_1.weight"), W(m.idx, "GroupNorm_1.bias"), a1, rs1, ms1, cout, H, act, mask, sp.drop_id);   // (dropout in the apply pass)
-    if (rc) return rc;
     const int out = new_tensor(H, cout);
     float* o = st.t[out].p;
-    if (cin != cout) {                               // NIN shortcut: h . W + b through the transposed-weight flag (no W^T copy)
+    int rc;
+    {
       const size_t mk = top;
-      float* sc = alloc(act_n(H, cout));
-      rc = conv(h, W(m.idx, "NIN_0.W"), W(m.idx, "NIN_0.b"), sc, cin, cout, H, 1, 1, 0, 0, 3 | 4);
+      // the GroupNorm's apply pass also writes the fp16 operand planes Conv_0 would otherwise split a0 into in a pass of its own
+      const int np0 = conv2d_operand_planes(B, cin, cout, H, H, 3, 1, 0, 0, prec);
+      float* pl0 = np0 ? alloc_bytes((size_t)np0 * B * H * H * cin * 2) : nullptr;
+      rc = gn(h, W(m.idx, "GroupNorm_0.weight"), W(m.idx, "GroupNorm_0.bias"), a0, rs0, ms0, cin, H, act, nullptr, 0, pl0, np0);
       if (rc) return rc;
-      rc = conv(a1, W(m.idx, "Conv_1.weight"), W(m.idx, "Conv_1.bias"), o, cout, cout, H, 3, 1, 0, 0, 3, sc);   // + shortcut in the epilogue
+      float* d = nullptr;
+      if (c.conditional) {                           // the time-embedding row rides in Conv_0's epilogue
+        d = alloc((size_t)B * cout);
+        // (act(temb) is computed once per forward: every block's Dense_0 used to redo it inside its own latency-bound launch)
+        TG_RUN(csd_linear(st.temb2_act, W(m.idx, "Dense_0.weight"), W(m.idx, "Dense_0.bias"), d, B, 4 * c.nf, cout, CSD_ACT_NONE, s));
+      }
+      rc = conv(a0, W(m.idx, "Conv_0.weight"), W(m.idx, "Conv_0.bias"), c0, cin, cout, H, 3, 1, 0, 0, 3, nullptr, d, pl0);
       if (rc) return rc;
       top = mk;
-    } else {
-      rc = conv(a1, W(m.idx, "Conv_1.weight"), W(m.idx, "Conv_1.bias"), o, cout, cout, H, 3, 1, 0, 0, 3, h);
+    }
+    {
+      const size_t mk = top;
+      const int np1 = conv2d_operand_planes(B, cout, cout, H, H, 3, 1, 0, 0, prec);
+      float* pl1 = np1 ? alloc_bytes((size_t)np1 * B * H * H * cout * 2) : nullptr;
+      rc = gn(c0, W(m.idx, "GroupNorm_1.weight"), W(m.idx, "GroupNorm_1.bias"), a1, rs1, ms1, cout, H, act, mask, sp.drop_id, pl1, np1);   // (dropout in the apply pass)
       if (rc) return rc;
+      if (cin != cout) {                             // NIN shortcut: h . W + b through the transposed-weight flag (no W^T copy)
+        float* sc = alloc(act_n(H, cout));
+        rc = conv(h, W(m.idx, "NIN_0.W"), W(m.idx, "NIN_0.b"), sc, cin, cout, H, 1, 1, 0, 0, 3 | 4);
+        if (rc) return rc;
+        rc = conv(a1, W(m.idx, "Conv_1.weight"), W(m.idx, "Conv_1.bias"), o, cout, cout, H, 3, 1, 0, 0, 3, sc, nullptr, pl1);   // + shortcut in the epilogue
+        if (rc) return rc;
+      } else {
+        rc = conv(a1, W(m.idx, "Conv_1.weight"), W(m.idx, "Conv_1.bias"), o, cout, cout, H, 3, 1, 0, 0, 3, h, nullptr, pl1);
+        if (rc) return rc;
+      }
+      top = mk;
     }
     sp.out = out;
     sp.sv[0] = a0; sp.sv[1] = rs0; sp.sv[2] = ms0; sp.sv[3] = c0; sp.sv[4] = a1; sp.sv[5] = rs1; sp.sv[6] = ms1; sp.sv[7] = mask;

@@ -269,7 +269,7 @@ extern "C" int csd_groupnorm_act_nhwc(const float* x, const float* gamma, const 
 
 int csd::groupnorm_act_dropout_nhwc(const float* x, const float* gamma, const float* beta, float* y, float* rs, float* ms, float* mask,
                                     float p_drop, uint64_t seed, uint64_t stream_id, int B, int C, int HW, int groups, float eps,
-                                    int act, void* scratch, void* stream) {
+                                    int act, void* scratch, void* stream, void* planes, int plane_count) {
   CSD_REQUIRE(x && gamma && beta && y && rs && ms && scratch, "groupnorm_act_nhwc: null argument");
   CSD_REQUIRE(mask == nullptr || (p_drop > 0.f && p_drop < 1.f && ((size_t)B * HW * C) % 4 == 0), "groupnorm_act_nhwc: dropout p = %f", (double)p_drop);
   hipStream_t s = (hipStream_t)stream;
@@ -282,7 +282,9 @@ int csd::groupnorm_act_dropout_nhwc(const float* x, const float* gamma, const fl
   double* partial = reinterpret_cast<double*>(f);
   if ((rc = gn_stats_launch(g, x, nullptr, partial, s))) return rc;
   if ((rc = gn_finalize_launch(g, partial, gamma, beta, eps, sc, sh, s, rs, ms))) return rc;
-  return gn_apply_launch(x, sc, sh, y, B, HW, C, act, s, mask, p_drop, seed, stream_id);
+  void* hi = plane_count > 0 ? planes : nullptr;
+  void* lo = plane_count > 1 ? static_cast<void*>(static_cast<char*>(planes) + (size_t)B * HW * C * 2) : nullptr;
+  return gn_apply_launch(x, sc, sh, y, B, HW, C, act, s, mask, p_drop, seed, stream_id, hi, lo);
 }
 
 // dx = GroupNorm(+act) backward of dy (+ add, when given: the gradient arriving over the residual shortcut)
