@@ -5,12 +5,14 @@
 // Replaces assemble_input_kernel (83 us at 160^2, B = 64) + the generic fp16 conv on a 16-channel padded copy (310 us): the layer is
 // bound by its 629 MB of output, so the whole input side (6 of 8 channels real, 0.1 GB) is done inside the tile that needs it.
 //
-// One 4-wave workgroup per 16 x 8 pixel tile and 32 * NT couts (one 32-pixel M tile per wave: <= 128 VGPRs, four workgroups per CU - the
-// layer is a load-latency -> short K loop -> store sequence that only overlaps across workgroups).  The 18 x 10 patch is read from the NCHW sources (coalesced along W),
-// assembled, split into fp16 hi + lo ONCE per patch pixel and kept as two 16-byte planes in LDS; K = tap * 8 + channel (72, padded to 80 =
-// 5 MFMA K steps; the padding tap reads a zero pixel).  Weights (A fragments, 2^8-scaled hi + lo, 30 KB for 96 couts) stream from L2 into
-// registers.  Products: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (NS = 2: the fp16x3 / fp16f8 modes - the raw inputs are not
-// GroupNorm-ed, so the e4m3 correction form does not apply) or hi*hi only (NS = 1: the plain fp16 mode).
+// Persistent: four 4-wave workgroups per CU, each walking 16 x 8 pixel tiles of its XCD's contiguous share (one 32-pixel M tile per wave:
+// <= 128 VGPRs).  The packed weights of ALL cout groups (2^8-scaled hi + lo A/B fragments, 30 KB for 96 couts) and the bias stay in LDS for
+// the workgroup's run.  Per tile the 18 x 10 patch is read from the NCHW sources (coalesced along W, straight-line loads), assembled, split
+// into fp16 hi + lo ONCE per patch pixel and kept as two 16-byte planes in LDS; K = tap * 8 + channel (72, padded to 80 = 5 MFMA K steps;
+// the padding tap reads a zero pixel).  Products: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (NS = 2: the fp16x3 / fp16f8 modes - the
+// raw inputs are not GroupNorm-ed, so the e4m3 correction form does not apply) or hi*hi only (NS = 1: the plain fp16 mode); the pixels are
+// the M operand, so every output store covers whole 128-byte lines.  The loop's only wait on global memory (the next tile's patch, requested
+// before the K loop) sits after the K loop: gfx9's in-order vmcnt makes a load wait also a wait for every older store.
 #include <hip/hip_runtime.h>
 
 #include "common.h"
