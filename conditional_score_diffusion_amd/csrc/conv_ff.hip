@@ -262,6 +262,13 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           acc[mt][nt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(res_r, res_voff, (unsigned)(upix(mt, r) * kCout + nt * 32) * 4u, 0));
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
   }
 
   // ---- prologue: the first stage's patch (waves 1-3) and the first R-1 weight groups (wave 0) are requested before anything
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = has_res ? fmaf(acc[mt][nt][r], acc_in, b_in) : b_in;
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaf(acc[mt][nt][r], acc_in, b_in);      // (residual or 0) * 2^8 [/ -ln2] + (bias + temb) * ...
   }
   ff_barrier();
   FF_TS();
