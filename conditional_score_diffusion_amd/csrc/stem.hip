@@ -306,8 +306,11 @@ int stem_launch(const float* x, const float* y, const float* y_noise, float y_si
   const int want = n_cu * per_cu;
   const int grid = k.nblocks < want ? (k.nblocks + 7) / 8 * 8 : want;
   auto go = [&](auto kern) -> int {
-    if (lds > 64 * 1024)
+    static bool attr_set = false;      // (one flag per kernel instantiation: the lambda's operator() is a template)
+    if (!attr_set) {
       CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, k);
     return CSD_OK;
   };
