@@ -69,5 +69,8 @@ struct FFCfg {
 
 // conv_fx.hip: the fp16f8 form with one workgroup per CU (whole-stage weight buffers, one barrier per stage)
 int convfx_launch(const ConvFFArgs& k, int nt, hipStream_t s);
+// conv_xp.hip: the fp16x3 form as one software-pipelined stream per SIMD (one 4-wave workgroup per CU, persistent)
+bool convxp_supported(const ConvFFArgs& k, int nt);
+int convxp_launch(const ConvFFArgs& k, hipStream_t s);
 
 }  // namespace csd

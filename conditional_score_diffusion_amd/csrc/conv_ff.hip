@@ -635,6 +635,12 @@ int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
     const bool use_fx = fx ? atoi(fx) != 0 : k.nstage >= 12;
     if (ns == 3 && use_fx && k.nstage >= 2 * nt) return convfx_launch(k, nt, s);
   }
+  // conv_xp.hip (fp16x3: one persistent 4-wave workgroup per CU, the conversion / fragment reads / weight staging placed between
+  // the MFMA chains of ONE instruction stream per SIMD).  Tuning build: CSD_XP=0 disables it.
+  {
+    const char* xp = CSD_TUNE_ENV("CSD_XP");
+    if (ns == 2 && convxp_supported(k, nt) && !(xp && atoi(xp) == 0)) return convxp_launch(k, s);
+  }
   const bool norm = a.nscale != nullptr;
 #define FF_DISPATCH(NT_)                                                                                            \
   if (ns == 1) return norm ? launch_ff<1, NT_, false, true>(k, s) : launch_ff<1, NT_, false, false>(k, s);       \
