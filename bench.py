@@ -56,6 +56,14 @@ def sr3_160_config():
     return c
 
 
+_DTYPES = {'fp32': 'f32',
+           'fp16x3': 'f16x3 (every operand carried as hi + lo fp16 = 22 significand bits, 3 MFMAs per product, f32 accumulate; f32-class: the per-op '
+                     'test tolerance is the f32 kernel\'s, network error 1.9e-6 vs the reference)',
+           'fp16f8': 'f16+f8 (operands split hi+lo; hi*hi on the fp16 MFMA, the two correction products with e4m3 operands on the fp8 MFMA, f32 '
+                     'accumulate; ~15 significand bits per operand: narrower than the reference\'s f32)',
+           'fp16': 'f16 (f32 accumulate; narrower than the reference\'s f32, not certified)'}
+
+
 def _stable_hash(s):
     h = 2166136261
     for ch in s.encode():
@@ -133,24 +141,40 @@ def main():
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU')
-    ap.add_argument('--precision', default=os.environ.get('CSD_PRECISION', 'fp16f8'), choices=['fp32', 'fp16x3', 'fp16f8', 'fp16'],
-                    help='arithmetic of the 3x3 contractions (all modes pass the 1e-3 parity tests)')
+    ap.add_argument('--precision', default=os.environ.get('CSD_PRECISION', 'fp16x3'), choices=['fp32', 'fp16x3', 'fp16f8', 'fp16'],
+                    help='arithmetic of the 3x3 contractions; the default fp16x3 is fp32-class (operands carried as hi + lo fp16: 22 significand bits, '
+                         'per-op tolerance = the fp32 kernel\'s); fp16f8 / fp16 are narrower than the reference\'s fp32 and reported as side figures only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='tuning aid: time the loop without the in-library event profiler')
     ap.add_argument('--no-alt', action='store_true', help='skip the short side measurements of the other precision modes')
-    ap.add_argument('--cpu-steps', type=int, default=4)
+    ap.add_argument('--stub-sampler', action='store_true',
+                    help='test aid (tests/test_distributed_cpu.py): run the launch / barrier / all_gather / MAX-over-ranks logic on the CPU with '
+                         'the gloo backend and a stand-in for the HIP sampler (sleeps rank-dependent milliseconds per step); prints a reduced line')
+    ap.add_argument('--cpu-thread-sweep', action='store_true', help='cpu_baseline leg only: seconds per B = 4 evaluation by thread count (no GPU work), then exit')
+    ap.add_argument('--cpu-steps', type=int, default=50, help='PC steps of the CPU baseline sample (BASELINE.md section 4: B = 4, 50 steps)')
     args = ap.parse_args()
 
+    if args.cpu_thread_sweep:      # evidence for the thread count of the cpu_baseline leg (profiles/r04_cpu_thread_sweep.txt)
+        cfg = sr3_160_config()
+        for th in (8, 16, 32, 64, 128, os.cpu_count() or 1):
+            torch.set_num_threads(th)
+            r = cpu_baseline(cfg, steps=1)
+            print('threads %3d: %s' % (th, r['sample']), flush=True)
+        return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)' % args.gpus)
-    if not torch.cuda.is_available():
-        sys.exit('bench.py needs an MI355X: the HIP path has no CPU fallback')
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    stub = args.stub_sampler
+    if stub:
+        dev = torch.device('cpu')
+    else:
+        if not torch.cuda.is_available():
+            sys.exit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+        torch.cuda.set_device(local)
+        dev = torch.device('cuda', local)
     # one process per GPU under torch.distributed.run: the RCCL process group exists whenever the launcher set RANK - also for a
     # world of ONE (`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`), so that the barrier / all_gather / MAX-reduce
     # branch below is the SAME code at N = 1 and at N = 8
@@ -158,52 +182,72 @@ def main():
     if grouped:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if stub:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    from conditional_score_diffusion_amd import _lib, ops, sde_lib
-    from conditional_score_diffusion_amd.models import utils as mutils
-    from conditional_score_diffusion_amd.sampling import fused
-    import ctypes
-
-    cfg = sr3_160_config()
-    cfg.model.csd_precision = args.precision
     B = args.batch
-    torch.manual_seed(0)
-    model = mutils.create_model(cfg)
-    # random-init weights of that architecture; the reference's init_scale=0 layers are re-drawn at
-    # scale 1 so the sampler is not numerically degenerate - same FLOPs either way
-    model.load_state_dict(synth_weights({k: tuple(v.shape) for k, v in model.state_dict().items()}, 0))
-    model = model.to(dev).eval()
-    sde = sde_lib.cVESDE(cfg.model.sigma_min_x, cfg.model.sigma_max_x, cfg.model.num_scales)
-    y = synth_y(B, seed=123 + rank).to(dev)
-    ts, labels, std_x, G, _ = fused.step_scalars(sde, 1000, 1e-5)
+    if stub:
+        class _NoProfile:      # (the in-library event profiler belongs to the HIP library)
+            @staticmethod
+            def profile_select(*a): pass
+            @staticmethod
+            def profile_start(): pass
+            @staticmethod
+            def profile_stop(): return {'conv3x3': {'ms': 0.0, 'launches': 0, 'flops': 0.0, 'bytes': 0.0}}
+        _lib = _NoProfile
+        x = torch.full((B, 3, 8, 8), float(rank))
 
-    model._ensure_packed()
-    ws = model._workspace(B)
-    scratch = torch.empty(_lib.lib().csd_pc_scratch_bytes(model._h, B), dtype=torch.uint8, device=dev)
-    x = ops.randn((B, 3, 160, 160), 42 + rank, 0, dev)
-    x = ops.scale_rows(x, torch.full((B,), float(sde.sigma_max), device=dev))
+        def run_steps(first, n, seed):
+            time.sleep(0.002 * (1 + rank) * n)       # rank r is (r + 1) x slower: the reported time must be the slowest rank's
+            x.add_(float(n))
+    else:
+        from conditional_score_diffusion_amd import _lib, ops, sde_lib
+        from conditional_score_diffusion_amd.models import utils as mutils
+        from conditional_score_diffusion_amd.sampling import fused
+        import ctypes
 
-    def run_steps(first, n, seed):
-        p = _lib.PCParams()
-        p.n_steps = n
-        f = lambda t: ctypes.cast(t[first:first + n].contiguous().data_ptr(), ctypes.POINTER(ctypes.c_float))  # noqa: E731
-        keep = [labels[first:first + n].contiguous(), std_x[first:first + n].contiguous(), G[first:first + n].contiguous()]
-        p.labels, p.std_x, p.G = [ctypes.cast(k.data_ptr(), ctypes.POINTER(ctypes.c_float)) for k in keep]
-        p.std_y = None
-        p.snr = float(cfg.sampling.snr)
-        p.denoise = 0
-        p.noise_tape = None
-        p.seed = seed
-        p.record = None
-        _lib.check(_lib.lib().csd_pc_sample(model._h, _lib.ptr(model._packed), _lib.ptr(ws), ws.numel(),
-                                            _lib.ptr(scratch), scratch.numel(), _lib.ptr(x), _lib.ptr(y), B,
-                                            ctypes.byref(p), _lib.current_stream(dev)), 'pc_sample')
+        cfg = sr3_160_config()
+        cfg.model.csd_precision = args.precision
+        B = args.batch
+        torch.manual_seed(0)
+        model = mutils.create_model(cfg)
+        # random-init weights of that architecture; the reference's init_scale=0 layers are re-drawn at
+        # scale 1 so the sampler is not numerically degenerate - same FLOPs either way
+        model.load_state_dict(synth_weights({k: tuple(v.shape) for k, v in model.state_dict().items()}, 0))
+        model = model.to(dev).eval()
+        sde = sde_lib.cVESDE(cfg.model.sigma_min_x, cfg.model.sigma_max_x, cfg.model.num_scales)
+        y = synth_y(B, seed=123 + rank).to(dev)
+        ts, labels, std_x, G, _ = fused.step_scalars(sde, 1000, 1e-5)
+
+        model._ensure_packed()
+        ws = model._workspace(B)
+        scratch = torch.empty(_lib.lib().csd_pc_scratch_bytes(model._h, B), dtype=torch.uint8, device=dev)
+        x = ops.randn((B, 3, 160, 160), 42 + rank, 0, dev)
+        x = ops.scale_rows(x, torch.full((B,), float(sde.sigma_max), device=dev))
+
+        def run_steps(first, n, seed):
+            p = _lib.PCParams()
+            p.n_steps = n
+            f = lambda t: ctypes.cast(t[first:first + n].contiguous().data_ptr(), ctypes.POINTER(ctypes.c_float))  # noqa: E731
+            keep = [labels[first:first + n].contiguous(), std_x[first:first + n].contiguous(), G[first:first + n].contiguous()]
+            p.labels, p.std_x, p.G = [ctypes.cast(k.data_ptr(), ctypes.POINTER(ctypes.c_float)) for k in keep]
+            p.std_y = None
+            p.snr = float(cfg.sampling.snr)
+            p.denoise = 0
+            p.noise_tape = None
+            p.seed = seed
+            p.record = None
+            _lib.check(_lib.lib().csd_pc_sample(model._h, _lib.ptr(model._packed), _lib.ptr(ws), ws.numel(),
+                                                _lib.ptr(scratch), scratch.numel(), _lib.ptr(x), _lib.ptr(y), B,
+                                                ctypes.byref(p), _lib.current_stream(dev)), 'pc_sample')
 
     def barrier():
         if grouped:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
     K, W = args.steps, args.warmup
     if W > 0:
@@ -219,7 +263,7 @@ def main():
     t0 = time.perf_counter()
     run_steps(W, K, 2000 + rank)
     if grouped:     # the one collective of the sampling path: gather the finished samples
-        out = torch.empty((world * B, 3, 160, 160), dtype=torch.float32, device=dev)
+        out = torch.empty((world * B,) + tuple(x.shape[1:]), dtype=torch.float32, device=dev)
         torch.distributed.all_gather_into_tensor(out, x)
     barrier()
     dt = time.perf_counter() - t0
@@ -242,6 +286,17 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
+    if stub:
+        if rank == 0:
+            gathered = out[:, 0, 0, 0].reshape(world, B)[:, 0].tolist() if grouped else [float(x[0, 0, 0, 0])]
+            print(json.dumps({'metric': 'stub', 'value': B * world / (1000.0 * dt / args.steps), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+                              'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+                              'config': {'workload': 'stub sampler (CPU, gloo)', 'images_per_gpu': B, 'global_batch': B * world},
+                              'gathered_first_element_per_rank': gathered}))
+        if grouped:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
     if not os.environ.get('CSD_LIB_PATH'):      # (tuning builds with ablated kernels produce garbage on purpose)
         assert torch.isfinite(x).all(), 'sampler state became non-finite'
 
@@ -252,27 +307,27 @@ def main():
         dom = prof['conv3x3']
         dom_tf = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 else 0.0
         kernel_ms = sum(v['ms'] for v in prof_all.values())
-        if args.precision == 'fp32':
-            dom_kernel, dom_peak = 'conv_f32_kernel (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)', F32_MFMA_PEAK_TF
-            dom_note = 'fp32 MFMA dense peak'
-        elif args.precision == 'fp16x3':
-            dom_kernel, dom_peak = ('3x3 stride-1 convolution class: conv_ff_kernel<NS=2> (fused GroupNorm+SiLU+split prologue, LDS-DMA weight '
-                                    'ring, 3x v_mfma_f32_32x32x16_f16 per product; the 160^2 / 80^2 levels = 70 % of the class time) + '
-                                    'conv_f16_q_kernel<NS=2> (40^2 and below)'), F16_MFMA_PEAK_TF / 3
-            dom_note = 'fp16 MFMA dense peak (2500 TF) / 3 MFMAs per algorithmic product; achieved counts algorithmic flops'
-        elif args.precision == 'fp16f8':
-            dom_kernel, dom_peak = ('3x3 stride-1 convolution class: conv_ff_kernel<NS=2,F8> (fused GroupNorm+SiLU+split prologue, LDS-DMA weight '
-                                    'ring; hi*hi on v_mfma_f32_32x32x16_f16, the two correction products K-concatenated on '
-                                    'v_mfma_scale_f32_32x32x64_f8f6f4; the 160^2 / 80^2 levels; its persistent matrix-wave / producer-wave form conv_fx_kernel on '
-                                    'the >= 192-channel layers) + conv_f16_q_kernel<NS=2> (40^2 and below, '
-                                    '3 fp16 MFMAs per product)'), F16_MFMA_PEAK_TF / 2
-            dom_note = ('fp16 MFMA dense peak (2500 TF) / 2: one fp16 MFMA per product + two correction products at the fp8 rate '
-                        '(half an fp16 MFMA each); achieved counts algorithmic flops')
-        else:
-            dom_kernel, dom_peak = ('3x3 stride-1 convolution class: conv_ff_kernel<NS=1> (fused GroupNorm+SiLU prologue, v_mfma_f32_32x32x16_f16) '
-                                    '+ conv_f16_lc_kernel<NS=1> (40^2 and below)'), F16_MFMA_PEAK_TF
-            dom_note = 'fp16 MFMA dense peak'
-        # which roof bounds the dominant kernel: arithmetic intensity of its launches vs the ridge of its MFMA peak
+        # Roofline of the dominant kernel class, priced against the guide's peaks only (MI355X_MICROARCH.md: HBM3E 8 TB/s; dense MFMA
+        # peak of the instruction the mode multiplies on): arithmetic intensity = ALGORITHMIC flops / ALGORITHMIC bytes of the class's
+        # launches (SURVEY.md 8d definitions, counted by the library per launch); ridge = MFMA peak / HBM peak.  AI < ridge -> the class
+        # is HBM-bound by the roofline model and frac = algorithmic bytes / event-measured duration / 8 TB/s; otherwise frac = algorithmic
+        # flops / duration / MFMA peak.  What the split arithmetic costs on the matrix pipe (3 MFMAs per algorithmic product in fp16x3)
+        # is charged to the kernel, not to the roof: it is reported separately under `matrix_pipe`.
+        modes = {
+            'fp32': dict(peak=F32_MFMA_PEAK_TF, mfma_per_product=1.0, operand='fp32 (24 significand bits)',
+                         kernel='conv_f32_kernel (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)'),
+            'fp16x3': dict(peak=F16_MFMA_PEAK_TF, mfma_per_product=3.0, operand='hi + lo fp16 per operand (22 significand bits; the lo*lo term, 2^-22 relative, is dropped)',
+                           kernel='3x3 stride-1 convolution class: conv_xp_kernel (fused GroupNorm+SiLU+split prologue as fillers between the MFMAs of one '
+                                  'software-pipelined stream per SIMD, persistent 4-wave workgroup per CU, 3x v_mfma_f32_32x32x16_f16 per product; the 160^2 / 80^2 '
+                                  'levels) + conv_f16_q_kernel<NS=2> (40^2 and below)'),
+            'fp16f8': dict(peak=F16_MFMA_PEAK_TF, mfma_per_product=2.0, operand='fp16 hi x fp16 hi + two correction products with e4m3 operands (~15 significand bits per operand: '
+                                                                                  'NARROWER than the reference\'s fp32)',
+                           kernel='3x3 stride-1 convolution class: conv_ff_kernel<NS=2,F8> / conv_fx_kernel (hi*hi on v_mfma_f32_32x32x16_f16, corrections on '
+                                  'v_mfma_scale_f32_32x32x64_f8f6f4) + conv_f16_q_kernel<NS=2>'),
+            'fp16': dict(peak=F16_MFMA_PEAK_TF, mfma_per_product=1.0, operand='fp16 (11 significand bits: NARROWER than the reference\'s fp32, not certified)',
+                         kernel='3x3 stride-1 convolution class: conv_ff_kernel<NS=1> + conv_f16_lc_kernel<NS=1>'),
+        }[args.precision]
+        dom_kernel, dom_peak = modes['kernel'], modes['peak']
         dom_gbs = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9 if dom['ms'] > 0 else 0.0
         dom_ai = dom['flops'] / max(dom['bytes'], 1.0)
         ridge = dom_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
@@ -283,16 +338,22 @@ def main():
         # HBM traffic of the same kernel class from PMC counters (a separate rocprofv3 pass cannot run inside this
         # process): the committed summary of tools/pmc_hbm.sh for this mode, bytes per launch like `achieved`
         traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_hbm_traffic_%s.json' % args.precision)
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            traffic = tj['conv3x3_class']['hbm_bytes_per_launch']
-            traffic_src = 'profiles/' + os.path.basename(tpath) + ' (' + tj['source'] + ')'
+        for rnd in ('r04', 'r03'):
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', '%s_hbm_traffic_%s.json' % (rnd, args.precision))
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                traffic = tj['conv3x3_class']['hbm_bytes_per_launch']
+                traffic_src = 'profiles/' + os.path.basename(tpath) + ' (' + tj['source'] + ')'
+                break
         roof.update({'kernel': dom_kernel, 'traffic': traffic, 'traffic_unit': 'bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)',
                      'traffic_source': traffic_src,
-                     'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1), 'peak_note': dom_note,
+                     'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
+                     'peak_note': 'guide peaks: HBM3E 8000 GB/s; dense MFMA %.1f TFLOP/s for this mode\'s matrix instruction' % dom_peak,
                      'arithmetic_intensity_flop_per_byte': dom_ai, 'ridge_flop_per_byte': ridge,
                      'achieved_TFLOPs': dom_tf, 'achieved_GBs': dom_gbs,
+                     'matrix_pipe': {'mfma_per_algorithmic_product': modes['mfma_per_product'],
+                                     'issued_TFLOPs': dom_tf * modes['mfma_per_product'], 'peak_TFLOPs': dom_peak,
+                                     'frac': dom_tf * modes['mfma_per_product'] / dom_peak},
                      'launches': dom['launches'], 'avg_launch_ms': dom['ms'] / max(dom['launches'], 1),
                      'sampling': 'events on every 8th PC step of the timed region (dominant class only)' if not args.no_profile else 'off',
                      'share_of_kernel_time': prof_all['conv3x3']['ms'] / max(kernel_ms, 1e-9)})
@@ -304,10 +365,7 @@ def main():
             'metric': 'images/sec for 1000-step PC sampling, ddpm_paired_SR3 score net of celebA_SR3_160 (BASELINE configs[1]), 160x160',
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'fp32': 'f32', 'fp16x3': 'f16x3 (split hi+lo fp16 operands, 3 MFMAs, f32 accumulate; f32-class error)',
-                      'fp16f8': 'f16+f8 (operands split hi+lo; hi*hi on the fp16 MFMA, the two correction products with e4m3 operands on the '
-                                'fp8 MFMA, f32 accumulate; 1.3e-5 norm-wise / 4.5e-5 element-wise per evaluation, certified to 1e-3 over 1000 steps)',
-                      'fp16': 'f16 (f32 accumulate)'}[args.precision], 'data': 'synthetic',
+            'dtype': _DTYPES[args.precision], 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: celebA_SR3_160 (ddpm_paired_SR3, nf=96, ch_mult (1,1,2,2,3,3), '
                                    'attn 20/10/5), 1000-step PC (reverse_diffusion + langevin, snr 0.15), '
                                    'batch %d per GPU, random-init weights, synthetic LR inputs' % B,
@@ -324,8 +382,8 @@ def main():
             'kernel_time_fraction_of_wall': kernel_ms / ((prof_all_ms or (dt / K * 1e3)) * K),
         }
         if not args.no_cpu_baseline and world == 1:
-            # oneDNN conv scaling collapses past ~16-32 threads on this host (measured: 16 thr 0.12 s, 64 thr
-            # 0.38 s, 256 thr 45 s per evaluation), so the baseline uses the best setting, not all cores
+            # oneDNN conv scaling collapses past ~16-32 threads on this host (profiles/r04_cpu_thread_sweep.txt, tools/cpu_threads.py:
+            # seconds per B = 4 evaluation by thread count), so the baseline uses the best setting, not all cores
             torch.set_num_threads(min(16, os.cpu_count() or 1))
             res['cpu_baseline'] = cpu_baseline(cfg, steps=args.cpu_steps)
         else:
@@ -343,7 +401,8 @@ def main():
                                        capture_output=True, text=True, timeout=600)
                     j = json.loads(r.stdout.strip().splitlines()[-1])
                     alt[mode] = {'value': j['value'], 'unit': j['unit'], 'ms_per_step': j['ms_per_step'], 'dtype': j['dtype'],
-                                 'hbm_roofline_frac': j['hbm_roofline']['frac'], 'steps': 10}
+                                 'hbm_roofline_frac': j['hbm_roofline']['frac'], 'steps': 10,
+                                 'creditable_as_headline': mode in ('fp32', 'fp16x3')}
                 except Exception as e:      # a side measurement must never break the bench line
                     alt[mode] = {'error': str(e)[:200]}
             res['other_precision_modes'] = alt

@@ -87,6 +87,7 @@ SIGNATURES = {
     'csd_unet_train_workspace_bytes': (_sz, [_vp, _i, _f]),
     'csd_unet_train_forward': (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _i, _f, ctypes.c_uint64, ctypes.c_uint64, _vp]),
     'csd_unet_backward': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _i, ctypes.c_uint64, _vp]),
+    'csd_unet_train_release': (_i, [_vp, _vp]),
     'csd_update_scratch_bytes': (_sz, [_i]),
     'csd_langevin_step': (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _i64, _vp, _vp]),
     'csd_reverse_diffusion_step': (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i64, _vp]),

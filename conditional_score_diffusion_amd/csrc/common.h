@@ -49,6 +49,36 @@ const char* get_error();
     }                                                                               \
   } while (0)
 
+// Per-device launch state (a process may drive several GPUs): the CU count of the current device, rounded down to a multiple of the 8
+// XCDs, and a per-(kernel instantiation, device) flag for attributes that are per device (hipFuncAttributeMaxDynamicSharedMemorySize).
+#define CSD_MAX_DEVICES 64
+static inline int current_device_index() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CSD_MAX_DEVICES) dev = 0;
+  return dev;
+}
+static inline int device_cu_count8() {
+  static int n_cu[CSD_MAX_DEVICES] = {0};
+  const int dev = current_device_index();
+  if (!n_cu[dev]) {
+    hipDeviceProp_t prop;
+    int n = 8;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount / 8 * 8;
+    n_cu[dev] = n < 8 ? 8 : n;
+  }
+  return n_cu[dev];
+}
+// once per (call site = kernel instantiation, device): allow up to 160 KB of dynamic LDS
+#define CSD_SET_MAX_LDS_ONCE(kern)                                                                                       \
+  do {                                                                                                                   \
+    static bool _set[CSD_MAX_DEVICES] = {false};                                                                         \
+    const int _dev = csd::current_device_index();                                                                        \
+    if (!_set[_dev]) {                                                                                                   \
+      CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      _set[_dev] = true;                                                                                                 \
+    }                                                                                                                    \
+  } while (0)
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

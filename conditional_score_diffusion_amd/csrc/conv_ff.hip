@@ -592,11 +592,11 @@ int convff_plan_tiles(ConvPlan* p, int ns) {
 template <int NS, int NT, bool F8, bool NORM>
 static int launch_ff(const ConvFFArgs& k, hipStream_t s) {
   auto kern = conv_ff_kernel<NS, NT, F8, NORM>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-    if (CSD_TUNE_ENV("CSD_FF_OCC")) {
+  CSD_SET_MAX_LDS_ONCE(kern);
+  {
+    static bool occ_shown = false;
+    if (!occ_shown && CSD_TUNE_ENV("CSD_FF_OCC")) {
+      occ_shown = true;
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), FF_THREADS, FFCfg<NS, NT>::LDS);
       fprintf(stderr, "conv_ff<%d,%d>: %d workgroups per CU (LDS %zu B)\n", NS, NT, nb, (size_t)FFCfg<NS, NT>::LDS);

@@ -465,20 +465,8 @@ __global__ __launch_bounds__(FX_THREADS, 1) void conv_fx_kernel(const char* __re
 template <int NT, bool NORM>
 static int launch_fx(const ConvFFArgs& k, hipStream_t s) {
   auto kern = conv_fx_kernel<NT, NORM>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    CSD_CHECK_HIP(hipGetDevice(&dev));
-    CSD_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-    n_cu = prop.multiProcessorCount / 8 * 8;         // persistent: one workgroup per CU, a multiple of the 8 XCDs
-    if (n_cu < 8) n_cu = 8;
-  }
+  CSD_SET_MAX_LDS_ONCE(kern);
+  const int n_cu = device_cu_count8();               // persistent: one workgroup per CU, a multiple of the 8 XCDs
   const int grid = k.nblocks < n_cu ? (k.nblocks + 7) / 8 * 8 : n_cu;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(FX_THREADS), FXCfg<NT>::LDS, s, reinterpret_cast<const char*>(k.a.wpack), k);
   CSD_LAUNCH_CHECK();

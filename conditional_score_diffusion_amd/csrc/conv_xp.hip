@@ -54,6 +54,7 @@ __device__ __forceinline__ float xp_lo(int hp, float v) {      // v - (float)hal
 }
 
 #define XP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define XP_SADD(x, y) asm volatile("s_add_u32 %0, %0, %1" : "+s"(x) : "s"(y) : "scc")
 // tuning aids (never in the product library): XP_ABL bits remove parts of the stream at compile time (results are then garbage):
 // 1 conversion, 2 weight staging, 4 fragment reads, 8 epilogue stores, 16 patch requests, 32 residual requests, 64 barriers
 #ifndef XP_ABL
@@ -184,93 +185,111 @@ __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __re
       shn = __builtin_amdgcn_raw_buffer_load_b128(nsh_r, (unsigned)(lg * 16), so, 0);
     }
   };
-  auto cvt_prep = [&]() __attribute__((always_inline)) {       // once per stage: the affine in the exp2 domain
+  auto cvt_prep_half = [&](int h) __attribute__((always_inline)) {       // once per stage: the affine in the exp2 domain
     if constexpr (NORM) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 2 * h; q < 2 * h + 2; ++q) {
         msc[q] = __uint_as_float(scn[q]) * NLOG2E;
         msh[q] = __uint_as_float(shn[q]) * NLOG2E;
       }
+      asm volatile("" : "+v"(msc[2 * h]), "+v"(msc[2 * h + 1]), "+v"(msh[2 * h]), "+v"(msh[2 * h + 1]));
     }
   };
-  // weights of a stage: piece i (1 KiB, fragment order = linear); this wave takes pieces wave, wave + 4, ... in two halves of 7
+  auto cvt_prep = [&]() __attribute__((always_inline)) { cvt_prep_half(0); cvt_prep_half(1); };
+  // weights of a stage: piece i = q * 4 + wave (1 KiB, fragment order = linear; 54 pieces: the last two waves' piece 13 repeats piece
+  // 53), in two halves of 7; the scalar offset runs (asm add: hipcc would otherwise precompute 14 offsets per stage ahead of the stream)
   const __amdgpu_buffer_rsrc_t w_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g_wpack), 0, OOB, RSRC_FLAGS);
+  const int wvoff = lane * 16 + wave * 1024;
+  const int w13 = wave < 2 ? 13 * 4096 : (PIECES - 1 - wave) * 1024;      // offset of the wave's last piece relative to the stage
   xp_u4 wr[WH];
-  auto req_w = [&](int q, int wso) __attribute__((always_inline)) {      // q: 0 .. 13
+  int w_run = 0, w_base = 0;
+  const int c4096 = 4096;
+  auto w_begin = [&](int wso) __attribute__((always_inline)) { w_base = wso; w_run = wso; };
+  auto req_w = [&](int q) __attribute__((always_inline)) {      // q: 0 .. 13, in order
     if (XP_ABL & 2) return;
-    int i = q * 4 + wave;
-    i = i < PIECES ? i : PIECES - 1;
-    wr[q % WH] = __builtin_amdgcn_raw_buffer_load_b128(w_r, (unsigned)(lane * 16), wso + i * 1024, 0);
+    if (q < 13) {
+      wr[q % WH] = __builtin_amdgcn_raw_buffer_load_b128(w_r, (unsigned)wvoff, w_run, 0);
+      XP_SADD(w_run, c4096);
+    } else {
+      wr[q % WH] = __builtin_amdgcn_raw_buffer_load_b128(w_r, (unsigned)wvoff, w_base + w13, 0);
+    }
   };
   auto put_w = [&](int q, int par) __attribute__((always_inline)) {
     if (XP_ABL & 2) return;
-    int i = q * 4 + wave;
-    i = i < PIECES ? i : PIECES - 1;
-    *reinterpret_cast<xp_u4*>(smem + OFF_W + par * STB + i * 1024 + lane * 16) = wr[q % WH];
+    *reinterpret_cast<xp_u4*>(smem + OFF_W + par * STB + (q < 13 ? q * 4096 : w13) + wvoff) = wr[q % WH];
   };
 
   // ---- conversion of slot j into patch buffer `par`, in five pieces that sit between MFMA chains ----
   float cu[4], cv[4];
-  int chp0, chp1;
-  // (every piece opens with an empty asm statement on its inputs: hipcc's instruction selection otherwise sinks the whole conversion
-  // to its one use, the LDS store, and the five pieces land in ONE gap; the statement on pf[j] is also where the wait for the
-  // request lands)
-#define XP_PIN4(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
-  auto cvt_piece = [&](int j, int piece, int par, int m) __attribute__((always_inline)) {
+  int chp0, chp1, clp0, clp1;
+  // The conversion of a slot is cut into 17 micro-steps of 2-3 instructions, one per gap between two MFMAs of a tap.  Every step
+  // opens with an empty asm statement on its inputs: hipcc's instruction selection otherwise sinks the whole dependency chain to its
+  // one use (the LDS store) and everything lands in ONE gap; the statement on pf[j] is also where the wait for the request lands.
+#define XP_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+  auto cvt_step = [&](int j, int g, int par, int m) __attribute__((always_inline)) {
     if (XP_ABL & 1) return;
-    if (piece == 0) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) cu[q] = __uint_as_float(pf[j][q]);
-      XP_PIN4(cu);
-      if constexpr (NORM) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cu[q] = fmaf(cu[q], msc[q], msh[q]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cv[q] = __builtin_amdgcn_exp2f(cu[q]);
-      }
-    } else if (piece == 1) {
-      if constexpr (NORM) {
-        XP_PIN4(cv);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cv[q] = __builtin_amdgcn_rcpf(1.0f + cv[q]);
-      }
-    } else if (piece == 2) {
-      if constexpr (NORM) {
-        XP_PIN4(cv);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cu[q] = cu[q] * cv[q];
-      } else {
-        XP_PIN4(cu);
-      }
+    const int h = (g & 1) * 2;                       // steps 0 .. 9 work on channels (h, h + 1)
+    if (g < 2) {
+      cu[h] = __uint_as_float(pf[j][h]); cu[h + 1] = __uint_as_float(pf[j][h + 1]);
+      XP_PIN2(cu[h], cu[h + 1]);
+      if constexpr (NORM) { cu[h] = fmaf(cu[h], msc[h], msh[h]); cu[h + 1] = fmaf(cu[h + 1], msc[h + 1], msh[h + 1]); }
+    } else if (g < 4) {
+      if constexpr (NORM) { XP_PIN2(cu[h], cu[h + 1]); cv[h] = __builtin_amdgcn_exp2f(cu[h]); cv[h + 1] = __builtin_amdgcn_exp2f(cu[h + 1]); }
+    } else if (g < 6) {
+      if constexpr (NORM) { XP_PIN2(cv[h], cv[h + 1]); cv[h] = 1.0f + cv[h]; cv[h + 1] = 1.0f + cv[h + 1]; }
+    } else if (g < 8) {
+      if constexpr (NORM) { XP_PIN2(cv[h], cv[h + 1]); cv[h] = __builtin_amdgcn_rcpf(cv[h]); cv[h + 1] = __builtin_amdgcn_rcpf(cv[h + 1]); }
+    } else if (g < 10) {
+      if constexpr (NORM) { XP_PIN2(cv[h], cv[h + 1]); cu[h] = cu[h] * cv[h]; cu[h + 1] = cu[h + 1] * cv[h + 1]; }
+    } else if (g == 10) {
+      XP_PIN2(cu[0], cu[1]); XP_PIN2(cu[2], cu[3]);
       chp0 = xp_pack_f16(cu[0], cu[1]);
       chp1 = xp_pack_f16(cu[2], cu[3]);
-    } else if (piece == 3) {
-      asm volatile("" : "+v"(chp0), "+v"(chp1));
+    } else if (g == 11) {
+      XP_PIN2(chp0, chp1);
       cv[0] = xp_lo<false>(chp0, cu[0]); cv[1] = xp_lo<true>(chp0, cu[1]);
+    } else if (g == 12) {
+      XP_PIN2(chp0, chp1);
       cv[2] = xp_lo<false>(chp1, cu[2]); cv[3] = xp_lo<true>(chp1, cu[3]);
+    } else if (g == 13) {
+      XP_PIN2(chp0, chp1);
       char* const rec = smem + par * FF_PATCH_BYTES + s_dst[j];
       *reinterpret_cast<int2*>(rec) = make_int2(chp0 & m, chp1 & m);      // padding applies to the ACTIVATED tensor: exactly 0
-    } else {
-      XP_PIN4(cv);
+    } else if (g == 14) {
+      XP_PIN2(cv[0], cv[1]); XP_PIN2(cv[2], cv[3]);
+      clp0 = xp_pack_f16(cv[0], cv[1]);
+      clp1 = xp_pack_f16(cv[2], cv[3]);
+    } else if (g == 15) {
+      XP_PIN2(clp0, clp1);
       char* const rec = smem + par * FF_PATCH_BYTES + s_dst[j];
-      *reinterpret_cast<int2*>(rec + 32) = make_int2(xp_pack_f16(cv[0], cv[1]) & m, xp_pack_f16(cv[2], cv[3]) & m);
+      *reinterpret_cast<int2*>(rec + 32) = make_int2(clp0 & m, clp1 & m);
     }
+  };
+  auto cvt_all = [&](int j, int par, int m) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) cvt_step(j, g, par, m);
   };
 
   // ---- fragments ----
   half8 xh[2][2], xl[2][2], wh[2][NT], wl[2][NT];    // [register buffer][M tile | cout tile]
+  // one fragment per call, in the order the next tap's MFMAs need them: xh0 wl0 wl1 wl2 xh1 | xl0 wh0 wh1 wh2 xl1
   auto rd_frag = [&](int buf, int par, int tap, int which) __attribute__((always_inline)) {
     if (XP_ABL & 4) return;
     const int r = tap / 3, sx = tap - r * 3;
     const char* const pb = smem + par * FF_PATCH_BYTES + r * FF_RS + sx * FF_PSB;
     const char* const wb = smem + wbase + par * STB + tap * TAPB;
     switch (which) {
-      case 0: xh[buf][0] = *reinterpret_cast<const half8*>(pb + xbase[0]); xl[buf][0] = *reinterpret_cast<const half8*>(pb + xbase[0] + 32); break;
-      case 1: wh[buf][0] = *reinterpret_cast<const half8*>(wb); wl[buf][0] = *reinterpret_cast<const half8*>(wb + 1024); break;
-      case 2: xh[buf][1] = *reinterpret_cast<const half8*>(pb + xbase[1]); xl[buf][1] = *reinterpret_cast<const half8*>(pb + xbase[1] + 32); break;
-      case 3: wh[buf][1] = *reinterpret_cast<const half8*>(wb + 2048); wl[buf][1] = *reinterpret_cast<const half8*>(wb + 3072); break;
-      case 4: wh[buf][2] = *reinterpret_cast<const half8*>(wb + 4096); break;
-      default: wl[buf][2] = *reinterpret_cast<const half8*>(wb + 5120); break;
+      case 0: xh[buf][0] = *reinterpret_cast<const half8*>(pb + xbase[0]); break;
+      case 1: wl[buf][0] = *reinterpret_cast<const half8*>(wb + 1024); break;
+      case 2: wl[buf][1] = *reinterpret_cast<const half8*>(wb + 3072); break;
+      case 3: wl[buf][2] = *reinterpret_cast<const half8*>(wb + 5120); break;
+      case 4: xh[buf][1] = *reinterpret_cast<const half8*>(pb + xbase[1]); break;
+      case 5: xl[buf][0] = *reinterpret_cast<const half8*>(pb + xbase[0] + 32); break;
+      case 6: wh[buf][0] = *reinterpret_cast<const half8*>(wb); break;
+      case 7: wh[buf][1] = *reinterpret_cast<const half8*>(wb + 2048); break;
+      case 8: wh[buf][2] = *reinterpret_cast<const half8*>(wb + 4096); break;
+      case 9: xl[buf][1] = *reinterpret_cast<const half8*>(pb + xbase[1] + 32); break;
+      default: break;
     }
   };
 
@@ -290,20 +309,122 @@ __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __re
       for (int nt = 0; nt < NT; ++nt) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, 0" : "=a"(acc[mt][nt]) : "v"(z));
   };
   zero_acc();
-  auto chain = [&](int buf, int i) __attribute__((always_inline)) {
+  // One MFMA per statement, round robin over the six accumulators: product p of a tap (0: hi * lo, 1: lo * hi, 2: hi * hi - small terms
+  // first) for all six, then the next product.  Consecutive MFMAs are independent, so the wave is free to issue the gap's fillers while
+  // the matrix pipe works (tools/xp_order_probe.hip: ~80 fillers per tap ride for +5 % here; with three dependent MFMAs back to back
+  // the wave sits in the dependency stall and 46 fillers per tap already cost +22 %).  Per accumulator the order of the additions is
+  // unchanged.
+  auto mm = [&](int buf, int p, int i) __attribute__((always_inline)) {
     const int mt = i / NT, nt = i - mt * NT;
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\t"       // small terms first: hi * lo, lo * hi, then hi * hi
-                 "v_mfma_f32_32x32x16_f16 %0, %3, %4, %0\n\t"
-                 "v_mfma_f32_32x32x16_f16 %0, %1, %4, %0"
-                 : "+a"(acc[mt][nt])
-                 : "v"(xh[buf][mt]), "v"(wl[buf][nt]), "v"(xl[buf][mt]), "v"(wh[buf][nt]));
+    if (p == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(xh[buf][mt]), "v"(wl[buf][nt]));
+    else if (p == 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(xl[buf][mt]), "v"(wh[buf][nt]));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(xh[buf][mt]), "v"(wh[buf][nt]));
   };
 
-  // epilogue operands of the tile being multiplied (requested in its last stage)
+  // ---- epilogue operands of a tile (requested while its last stage is multiplied, used after that stage's last tap) ----
+  // Element (mt, r) of a lane: pixel row 4 wave + r / 4, column 8 mt + 4 kh + r % 4 of the tile, cout nt * 32 + p32 of the group: the
+  // lane part (kh, cout, the wave's first row) is one voffset per tensor, nt * 128 an immediate, and the (mt, r) part a RUNNING
+  // scalar offset advanced by one of three strides (next column, next row, next M tile) - 96 precomputed scalar offsets per tensor
+  // do not fit the scalar registers and came back from spill lanes with a v_readlane + wait states in front of every access.
   float rs[2][NT][16];
   float bv[NT], tv[NT];
-  // element (mt, r) of a lane: pixel row 4 wave + r / 4, column 8 mt + 4 kh + r % 4 (kh rides in the lane's voffset)
-  auto e_off = [&](int mt, int r, int stride) __attribute__((always_inline)) { return ((4 * wave + (r >> 2)) * kW + 8 * mt + (r & 3)) * stride * 4; };
+  __amdgpu_buffer_rsrc_t res_r, out_r;
+  unsigned res_voff = 0, out_voff = 0;
+  int e_tile = 0, e_ng = 0;
+  struct Steps { int col, row, mtile; };
+  auto steps_of = [&](int stride) __attribute__((always_inline)) {
+    Steps t;
+    t.col = stride * 4;
+    t.row = (kW - 3) * stride * 4;                   // from column 3 of a row to column 0 of the next
+    t.mtile = (8 - 3 * kW - 3) * stride * 4;         // from (row 3, column 3) of M tile 0 to (row 0, column 0) of M tile 1
+    return t;
+  };
+  const Steps st_res = steps_of(kCout), st_out = steps_of(a_out_stride);
+  auto e_advance = [&](int& run, int idx, const Steps& st) __attribute__((always_inline)) {      // from element idx = mt * 16 + r to idx + 1
+    const int r = idx & 15;
+    if ((r & 3) != 3) XP_SADD(run, st.col);
+    else if (r != 15) XP_SADD(run, st.row);
+    else XP_SADD(run, st.mtile);
+  };
+  int res_run = 0;
+  auto epi_setup = [&](const Tile& t) __attribute__((always_inline)) {      // in the tile's last unit
+    const size_t tile_pix = (size_t)t.b * kH * kW + (size_t)t.ty0 * kW + t.tx0;
+    const int c_lane = t.ng * NT * 32 + p32;
+    out_r = __builtin_amdgcn_make_buffer_rsrc(a_out + tile_pix * a_out_stride + a_out_coff, 0, OOB, RSRC_FLAGS);
+    out_voff = (unsigned)((4 * wave * kW + 4 * kh) * a_out_stride + c_lane) * 4u;
+    e_tile = t.tile; e_ng = t.ng;
+    if constexpr (RES) {
+      res_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_res + tile_pix * kCout), 0, OOB, RSRC_FLAGS);
+      res_voff = (unsigned)((4 * wave * kW + 4 * kh) * kCout + c_lane) * 4u;
+      res_run = 0;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bv[nt] = a_bias ? a_bias[c_lane + nt * 32] : 0.f;      // (summed in the epilogue: an add here would wait for both requests at once)
+      tv[nt] = a_temb ? a_temb[(size_t)t.b * a_temb_stride + c_lane + nt * 32] : 0.f;
+    }
+  };
+  auto req_res = [&](int e) __attribute__((always_inline)) {      // e = (mt * 16 + r) * 3 + nt
+    if constexpr (RES) {
+      if (XP_ABL & 32) return;
+      const int idx = e / 3, nt = e - idx * 3;
+      rs[idx / 16][nt][idx % 16] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(res_r, res_voff + nt * 128, res_run, 0));
+      if (nt == 2 && idx < 31) e_advance(res_run, idx, st_res);
+    }
+  };
+  float* const red = reinterpret_cast<float*>(smem + OFF_RED);      // [4 waves][NT*32 couts][2]: statistics hand-over
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    // (hipcc does not know the asm statements are MFMAs: without this their results would be read a few cycles after issue; the
+    // operands tie every accumulator to the statement so that no read can move above it)
+    asm volatile("s_nop 15\n\ts_nop 7"
+                 : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]));
+    XP_TS(22);
+    float vs[NT], vq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) vs[nt] = vq[nt] = 0.f;
+    int out_run = 0;
+#pragma unroll
+    for (int idx = 0; idx < 32; ++idx) {
+      const int mt = idx / 16, r = idx % 16;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float bs = (bv[nt] + tv[nt]) * a_out_scale;
+        float v;
+        if constexpr (RES) v = fmaf(acc[mt][nt][r], ka, fmaf(rs[mt][nt][r], a_out_scale, bs));
+        else v = fmaf(acc[mt][nt][r], ka, bs);
+        if (!(XP_ABL & 8)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), out_r, out_voff + nt * 128, out_run, 0);
+        vs[nt] += v;
+        vq[nt] = fmaf(v, v, vq[nt]);
+      }
+      if (idx < 31) e_advance(out_run, idx, st_out);
+    }
+    zero_acc();
+    XP_TS(23);
+    if (a_stats) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        vs[nt] += __shfl_xor(vs[nt], 32);
+        vq[nt] += __shfl_xor(vq[nt], 32);
+        if (kh == 0) {
+          red[(wave * NT * 32 + nt * 32 + p32) * 2 + 0] = vs[nt];
+          red[(wave * NT * 32 + nt * 32 + p32) * 2 + 1] = vq[nt];
+        }
+      }
+      ff_barrier();
+      if (tid < NT * 32) {
+        double sm = 0.0, sq = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) {
+          sm += (double)red[(wv * NT * 32 + tid) * 2 + 0];
+          sq += (double)red[(wv * NT * 32 + tid) * 2 + 1];
+        }
+        double* dst = a_stats + ((size_t)e_tile * kCout + e_ng * NT * 32 + tid) * 2;
+        dst[0] = sm;
+        dst[1] = sq;
+      }
+    }
+    XP_TS(24);
+  };
 
   Tile tc = tile_at(0), tn = tile_at(1);
   Geom gc = geom_of(tc), gn = gc;
@@ -316,190 +437,154 @@ __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __re
   for (int j = 0; j < NSLOT; ++j) req_slot(j, gc);
   req_norm(tc, 0);
   {
-    const int wso = (tc.ng * (Cin / 16) + 0) * STB;
+    w_begin((tc.ng * (Cin / 16) + 0) * STB);
     cvt_prep();
     req_norm(tc, 1);
     src_of(tc, 1);
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
-#pragma unroll
-      for (int piece = 0; piece < 5; ++piece) cvt_piece(j, piece, 0, gc.msk[j]);
+      cvt_all(j, 0, gc.msk[j]);
       req_slot(j, gc);
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
-      for (int q = 0; q < WH; ++q) req_w(h * WH + q, wso);
+      for (int q = 0; q < WH; ++q) req_w(h * WH + q);
 #pragma unroll
       for (int q = 0; q < WH; ++q) put_w(h * WH + q, 0);
     }
   }
   ff_barrier();
 #pragma unroll
-  for (int wch = 0; wch < 6; ++wch) rd_frag(0, 0, 0, wch);
+  for (int wch = 0; wch < 10; ++wch) rd_frag(0, 0, 0, wch);
 
   // =========================================================================================================================
-  // one stage = 9 taps x 6 chains.  While stage s of tile tc is multiplied (buffers `par`), stage X = s + 1 is converted into the
-  // other buffers from the registers requested a stage ago, its weights fetched and stored, and stage L = s + 2 is requested.
+  // One unit = [barrier | tap 8 of the PREVIOUS stage | (first unit of a tile: the previous tile's epilogue) | taps 0 .. 7 of stage s].
+  // A stage has 9 taps x 18 MFMAs; while stage s of tile tc is multiplied (buffers `par`), stage X = s + 1 is converted into the other
+  // buffers from the registers requested a stage ago, its weights fetched and stored, and stage L = s + 2 is requested.  The unit is
+  // cut in front of tap 8 because that is where the barrier sits (every wave holds tap 8's fragments in registers: the previous
+  // stage's buffers are dead, this stage's complete), and tap 8's gaps - free apart from the first fragment reads of stage s - take
+  // the stage's scalar set-up (descriptors, offsets, the GroupNorm affine in the exp2 domain) instead of a preamble in front of the
+  // first MFMA.
   // POS 0: s + 2 < NS (X and L in this tile); POS 1: s = NS - 2 (L = stage 0 of the next tile); POS 2: s = NS - 1, the tile's last
   // stage (X = stage 0, L = stage 1 of the next tile; the epilogue's requests ride along).  FLIP: nine taps per stage - the
-  // fragment register buffer of tap 0 alternates from stage to stage.
+  // fragment register buffer of tap 0 alternates from stage to stage.  FIRST: stage 0 of a tile.
   // =========================================================================================================================
-  int par = 0;                                       // buffer parity of the stage being multiplied
-  auto stage = [&](auto flip_tag, auto pos_tag, int s) __attribute__((always_inline)) {
+  int par = 0;                                       // buffer parity of the stage whose taps 0 .. 7 run (or ran last)
+  auto unit = [&](auto flip_tag, auto pos_tag, auto first_tag, int s, bool head) __attribute__((always_inline)) {
     constexpr int FLIP = decltype(flip_tag)::value, POS = decltype(pos_tag)::value;
-    const int npar = par ^ 1;
+    constexpr bool FIRST = decltype(first_tag)::value;
     const Tile& tx = POS == 2 ? tn : tc;             // tile of stage X
     const Tile& tl = POS >= 1 ? tn : tc;             // tile of stage L
     const Geom& gx = POS == 2 ? gn : gc;
     const Geom& gl = POS >= 1 ? gn : gc;
     const int sx = POS == 2 ? 0 : s + 1, sl = POS == 0 ? s + 2 : POS - 1;
-    cvt_prep();                                      // stage X's scale / shift (requested a stage ago)
-    req_norm(tl, sl);
-    src_of(tl, sl);
-    const int wso = (tx.ng * (Cin / 16) + sx) * STB;
-    unsigned res_voff = 0;
-    __amdgpu_buffer_rsrc_t res_r = w_r;
-    if constexpr (POS == 2) {
-      const size_t tile_pix = (size_t)tc.b * kH * kW + (size_t)tc.ty0 * kW + tc.tx0;
-      const int c_lane = tc.ng * NT * 32 + p32;
-      if constexpr (RES) {
-        res_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_res + tile_pix * kCout), 0, OOB, RSRC_FLAGS);
-        res_voff = (unsigned)(4 * kh * kCout + c_lane) * 4u;
-      }
+    auto setup = [&](int g) __attribute__((always_inline)) {      // the stage's set-up in pieces g = 0 .. 7
+      if (g == 0) cvt_prep_half(0);                  // stage X's scale / shift (requested a stage ago)
+      else if (g == 1) cvt_prep_half(1);
+      else if (g == 2) req_norm(tl, sl);
+      else if (g == 3) src_of(tl, sl);
+      else if (g == 4) w_begin((tx.ng * (Cin / 16) + sx) * STB);
+      else if (g == 5) { if constexpr (POS == 1) epi_setup(tc); }
+    };
+    if (!FIRST || head) {
+      par ^= 1;
+      XP_FENCE();
+      if (s == 2) XP_TS(20);
+      if (!(XP_ABL & 64)) ff_barrier();
+      if (s == 2) XP_TS(21);
+      XP_FENCE();
+      constexpr int buf = 1 - FLIP;                  // (= (8 + the previous stage's FLIP) & 1)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        bv[nt] = a_bias ? a_bias[c_lane + nt * 32] : 0.f;      // (summed in the epilogue: an add here would wait for both requests at once)
-        tv[nt] = a_temb ? a_temb[(size_t)tc.b * a_temb_stride + c_lane + nt * 32] : 0.f;
+      for (int g = 0; g < 18; ++g) {
+        XP_FENCE();
+        mm(buf, g / 6, g % 6);
+        XP_FENCE();
+        if (g < 10) rd_frag(buf ^ 1, par, 0, g);
+        else setup(g - 10);
       }
+      XP_FENCE();
+      if constexpr (FIRST) epilogue();
+    } else {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) setup(g);
     }
+    XP_TS(0 + s);
+    const int npar = par ^ 1;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < 8; ++tap) {
       const int buf = (tap + FLIP) & 1;
-      if (tap == 8) {                                // every wave holds tap 8's fragments: the stage's buffers are dead, the next stage's complete
-        XP_FENCE();
-        if (s == 2) XP_TS(20);
-        if (!(XP_ABL & 64)) ff_barrier();
-        if (s == 2) XP_TS(21);
-        XP_FENCE();
-      }
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      for (int g = 0; g < 18; ++g) {
         XP_FENCE();
-        chain(buf, i);
+        mm(buf, g / 6, g % 6);
         XP_FENCE();
-        // ---- fillers of gap (tap, i) ----
-        if (tap < 8) rd_frag(buf ^ 1, par, tap + 1, i);
-        else rd_frag(buf ^ 1, npar, 0, i);
+        // ---- fillers of gap (tap, g) ----
+        if (g < 10) rd_frag(buf ^ 1, par, tap + 1, g);
         if (tap >= 1 && tap <= 6) {                  // conversion of slot tap - 1 (stage X), then the request of the same slot for stage L
-          if (i < 5) cvt_piece(tap - 1, i, npar, gx.msk[tap - 1]);
-          else req_slot(tap - 1, gl);
+          if (g < 16) cvt_step(tap - 1, g, npar, gx.msk[tap - 1]);
+          else if (g == 16) req_slot(tap - 1, gl);
         }
         // stage X's weights: first half requested in tap 0, stored in tap 3; second half requested in tap 4, stored in tap 7
-        if (tap == 0 || tap == 4) {
-          constexpr int n0[7] = {0, 2, 4, 5, 6, 7, 7};
-#pragma unroll
-          for (int q = n0[i]; q < n0[i + 1]; ++q) req_w((tap / 4) * WH + q, wso);
-        } else if (tap == 3 || tap == 7) {
-          constexpr int n3[7] = {0, 2, 4, 5, 6, 7, 7};
-#pragma unroll
-          for (int q = n3[i]; q < n3[i + 1]; ++q) put_w((tap / 4) * WH + q, npar);
-        }
-        if constexpr (POS == 2 && RES) {
-          if (tap < 8 && !(XP_ABL & 32)) {           // 96 residual requests, 2 per gap
-            const int g0 = (tap * 6 + i) * 2;
-#pragma unroll
-            for (int e = g0; e < g0 + 2; ++e) {
-              const int mt = e / 48, nt = (e / 16) % 3, r = e % 16;
-              rs[mt][nt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(res_r, res_voff + nt * 128, e_off(mt, r, kCout), 0));
-            }
+        if (tap == 0 && g >= 10 && g < 10 + WH) req_w(g - 10);
+        if (tap == 4 && (g & 1) == 0 && g < 2 * WH) req_w(WH + g / 2);
+        if (tap == 3 && (g & 1) == 1 && g < 2 * WH) put_w(g / 2, npar);
+        if (tap == 7 && g < WH) put_w(WH + g, npar);
+        // 96 residual requests over the tile's last two units, in taps 1-2 and 5-6 only (two of every three gaps).  The memory counter
+        // retires in order: a weight piece (an L2 hit, stored to LDS three taps after its request) cannot retire before an OLDER request
+        // that went to HBM - so no slow request may be issued in the ~3 taps in front of a weight request (taps 0 and 4).
+        if constexpr (POS >= 1) {
+          if ((tap == 1 || tap == 2 || tap == 5 || tap == 6) && g % 3 != 0) {
+            const int w = (tap == 1 ? 0 : tap == 2 ? 1 : tap == 5 ? 2 : 3);
+            req_res((POS - 1) * 48 + w * 12 + (g / 3) * 2 + (g % 3 - 1));
           }
         }
       }
     }
     XP_FENCE();
-    XP_TS(1 + s);
-    par = npar;
   };
   using F0 = std::integral_constant<int, 0>;
   using F1 = std::integral_constant<int, 1>;
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
   using P2 = std::integral_constant<int, 2>;
+  using Yes = std::true_type;
+  using No = std::false_type;
 
   // =========================================================================================================================
-  // persistent loop (NS even): stage pairs, the last pair peeled
+  // persistent loop (NS even, >= 4): stage pairs, the first and the last pair of a tile peeled
   // =========================================================================================================================
-  float* const red = reinterpret_cast<float*>(smem + OFF_RED);      // [4 waves][NT*32 couts][2]: statistics hand-over
   for (int it = 0; it < n_my; ++it) {
 #ifdef CSD_FF_TUNE
     ts_on = it == 1;
+    if (it == 1) XP_WALL(28);
+    if (it == 2) XP_WALL(29);
+    if (it == 1 && a_dbg && tid == 0) a_dbg[blockIdx.x * 32 + 26] = clock64();
+    if (it == 2 && a_dbg && tid == 0) a_dbg[blockIdx.x * 32 + 27] = clock64();
 #endif
-    XP_TS(0);
-    for (int s = 0; s + 2 < NS; s += 2) {
-      stage(F0{}, P0{}, s);
-      stage(F1{}, P0{}, s + 1);
+    unit(F0{}, P0{}, Yes{}, 0, it > 0);
+    unit(F1{}, P0{}, No{}, 1, true);
+    for (int s = 2; s + 2 < NS; s += 2) {
+      unit(F0{}, P0{}, No{}, s, true);
+      unit(F1{}, P0{}, No{}, s + 1, true);
     }
     gn = geom_of(tn);
-    stage(F0{}, P1{}, NS - 2);
-    stage(F1{}, P2{}, NS - 1);
-    // ---- epilogue of tile tc ----
-    {
-      // (hipcc does not know the asm statements are MFMAs: without this their results would be read a few cycles after issue; the
-      // operands tie every accumulator to the statement so that no read can move above it)
-      asm volatile("s_nop 15\n\ts_nop 7"
-                   : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]));
-      XP_TS(22);
-      const size_t tile_pix = (size_t)tc.b * kH * kW + (size_t)tc.ty0 * kW + tc.tx0;
-      const int c_lane = tc.ng * NT * 32 + p32;
-      const __amdgpu_buffer_rsrc_t out_r =
-          __builtin_amdgcn_make_buffer_rsrc(a_out + tile_pix * a_out_stride + a_out_coff, 0, OOB, RSRC_FLAGS);
-      const unsigned out_voff = (unsigned)(4 * kh * a_out_stride + c_lane) * 4u;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const float bs = (bv[nt] + tv[nt]) * a_out_scale;
-        float vs = 0.f, vq = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v;
-            if constexpr (RES) v = fmaf(acc[mt][nt][r], ka, fmaf(rs[mt][nt][r], a_out_scale, bs));
-            else v = fmaf(acc[mt][nt][r], ka, bs);
-            if (!(XP_ABL & 8)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), out_r, out_voff + nt * 128, e_off(mt, r, a_out_stride), 0);
-            vs += v;
-            vq = fmaf(v, v, vq);
-          }
-        if (a_stats) {
-          vs += __shfl_xor(vs, 32);
-          vq += __shfl_xor(vq, 32);
-          if (kh == 0) {
-            red[(wave * NT * 32 + nt * 32 + p32) * 2 + 0] = vs;
-            red[(wave * NT * 32 + nt * 32 + p32) * 2 + 1] = vq;
-          }
-        }
-      }
-      zero_acc();
-      XP_TS(23);
-      if (a_stats) {
-        ff_barrier();
-        if (tid < NT * 32) {
-          double sm = 0.0, sq = 0.0;
-#pragma unroll
-          for (int wv = 0; wv < 4; ++wv) {
-            sm += (double)red[(wv * NT * 32 + tid) * 2 + 0];
-            sq += (double)red[(wv * NT * 32 + tid) * 2 + 1];
-          }
-          double* dst = a_stats + ((size_t)tc.tile * kCout + tc.ng * NT * 32 + tid) * 2;
-          dst[0] = sm;
-          dst[1] = sq;
-        }
-      }
-    }
-    XP_TS(24);
+    unit(F0{}, P1{}, No{}, NS - 2, true);
+    unit(F1{}, P2{}, No{}, NS - 1, true);
+    XP_TS(0 + NS);
     tc = tn;
     gc = gn;
     tn = tile_at(it + 2);
+  }
+  // the last tile's last tap and epilogue
+  {
+#pragma unroll
+    for (int g = 0; g < 18; ++g) {
+      XP_FENCE();
+      mm(1, g / 6, g % 6);                           // (the last stage of a tile has FLIP = 1: its tap 8 sits in fragment buffer (8 + 1) & 1)
+      XP_FENCE();
+    }
+    epilogue();
   }
   XP_WALL(31);
 }
@@ -507,25 +592,16 @@ __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __re
 template <bool NORM, bool RES>
 static int launch_xp(const ConvFFArgs& k, hipStream_t s) {
   auto kern = conv_xp_kernel<NORM, RES>;
-  int dev = 0;
-  CSD_CHECK_HIP(hipGetDevice(&dev));
-  static int n_cu[64] = {0};
-  if (dev < 0 || dev >= 64) dev = 0;
-  if (!n_cu[dev]) {
-    CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipDeviceProp_t prop;
-    CSD_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-    int n = prop.multiProcessorCount / 8 * 8;        // persistent: one workgroup per CU, a multiple of the 8 XCDs
-    n_cu[dev] = n < 8 ? 8 : n;
-  }
-  const int grid = k.nblocks < n_cu[dev] ? (k.nblocks + 7) / 8 * 8 : n_cu[dev];
+  CSD_SET_MAX_LDS_ONCE(kern);
+  const int n_cu = device_cu_count8();               // persistent: one workgroup per CU, a multiple of the 8 XCDs
+  const int grid = k.nblocks < n_cu ? (k.nblocks + 7) / 8 * 8 : n_cu;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(XP_THREADS), XPCfg::LDS, s, reinterpret_cast<const char*>(k.a.wpack), k);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
 
 // the fp16x3 (ns = 2) layers conv_ff covers with 96-cout groups and >= 2 stages; same packed weights, same arguments
-bool convxp_supported(const ConvFFArgs& k, int nt) { return nt == 3 && k.nstage >= 2 && k.nstage % 2 == 0; }
+bool convxp_supported(const ConvFFArgs& k, int nt) { return nt == 3 && k.nstage >= 4 && k.nstage % 2 == 0; }
 
 int convxp_launch(const ConvFFArgs& k, hipStream_t s) {
   const bool norm = k.a.nscale != nullptr, res = k.a.res != nullptr;

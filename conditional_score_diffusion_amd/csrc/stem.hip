@@ -291,26 +291,14 @@ int stem_launch(const float* x, const float* y, const float* y_noise, float y_si
   const int planes = ns >= 2 ? 2 : 1;
   const size_t lds = 2 * ST_PLANE * 16 + 4 * (size_t)nt * 32 * 2 * 4 + (size_t)k.n_groups * ST_KSTEPS * nt * planes * 1024 + (size_t)Cout * 4;
   CSD_REQUIRE(lds <= 160 * 1024, "stem: %d couts need %zu bytes of LDS", Cout, lds);
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    CSD_CHECK_HIP(hipGetDevice(&dev));
-    CSD_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-    n_cu = prop.multiProcessorCount / 8 * 8;
-    if (n_cu < 8) n_cu = 8;
-  }
+  const int n_cu = device_cu_count8();
   int per_cu = (int)((160 * 1024) / lds);      // persistent: as many workgroups per CU as LDS (and 128 VGPRs) allow, a multiple of the 8 XCDs
   if (per_cu > 4) per_cu = 4;
   if (per_cu < 1) per_cu = 1;
   const int want = n_cu * per_cu;
   const int grid = k.nblocks < want ? (k.nblocks + 7) / 8 * 8 : want;
   auto go = [&](auto kern) -> int {
-    static bool attr_set = false;      // (one flag per kernel instantiation: the lambda's operator() is a template)
-    if (!attr_set) {
-      CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
-    }
+    CSD_SET_MAX_LDS_ONCE(kern);           // (one flag array per kernel instantiation: the lambda's operator() is a template)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, k);
     return CSD_OK;
   };

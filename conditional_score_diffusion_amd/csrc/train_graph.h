@@ -50,6 +50,17 @@ static TrainState* train_state_find(const Net* n, const void* ws) {
   auto it = g_train.find(std::make_pair(n, ws));
   return it == g_train.end() ? nullptr : &it->second;
 }
+static void train_state_erase_one(const Net* n, const void* ws) {
+  std::lock_guard<std::mutex> lk(g_train_mu);
+  g_train.erase(std::make_pair(n, ws));
+}
+// records whose forward has been consumed (or failed) and whose workspace is not `keep`: a long run with monitoring forwards in
+// private workspaces must not grow the map without bound (each record holds pointers into a workspace that may be gone)
+static void train_state_purge_stale(const Net* n, const void* keep) {
+  std::lock_guard<std::mutex> lk(g_train_mu);
+  for (auto it = g_train.begin(); it != g_train.end();)
+    it = (it->first.first == n && it->first.second != keep && !it->second.valid) ? g_train.erase(it) : std::next(it);
+}
 static void train_state_erase(const Net* n) {
   std::lock_guard<std::mutex> lk(g_train_mu);
   for (auto it = g_train.begin(); it != g_train.end();) it = it->first.first == n ? g_train.erase(it) : std::next(it);
@@ -702,6 +713,7 @@ extern "C" int csd_unet_train_forward(csd_unet* net, const float* const* params,
   }
   for (size_t i = 0; i < net->net.params.size(); ++i)
     CSD_REQUIRE(params[i], "train_forward: parameter %zu (%s) is null", i, net->net.params[i].name.c_str());
+  train_state_purge_stale(&net->net, workspace);
   TrainState& st = train_state_of(&net->net, workspace);
   st.valid = false;
   TG g(net->net, st, B, (hipStream_t)stream, false, params, nullptr, static_cast<float*>(workspace));
@@ -709,6 +721,13 @@ extern "C" int csd_unet_train_forward(csd_unet* net, const float* const* params,
   rc = g.forward(x, y, labels, out);
   if (rc) return rc;
   st.valid = true; st.B = B; st.ws = workspace; st.p_drop = dropout_p; st.call = call_index;
+  return CSD_OK;
+}
+
+extern "C" int csd_unet_train_release(csd_unet* net, const void* workspace) {
+  int rc = train_check(net);
+  if (rc) return rc;
+  train_state_erase_one(&net->net, workspace);
   return CSD_OK;
 }
 

@@ -77,9 +77,13 @@ def sample_sharded(sampler, model, y_global=None, n_total=None, seed=None, group
             shape_tail = tuple(x_local.shape[1:]) if x_local is not None else tuple(pad_shape or ())
             if x_local is None and not shape_tail:
                 raise ValueError('an empty shard needs pad_shape=(C, H, W) to take part in the gather')
-            pad = torch.zeros((per,) + shape_tail, dtype=torch.float32, device=y_global.device)
+            # the padding block lives where the samples live (an empty shard: on the model's device), in their dtype - the gather needs
+            # matching tensors on every rank, whatever device y_global happens to be on
             if x_local is not None:
+                pad = x_local.new_zeros((per,) + shape_tail)
                 pad[:x_local.shape[0]] = x_local
+            else:
+                pad = torch.zeros((per,) + shape_tail, dtype=torch.float32, device=getattr(model, 'device', y_global.device))
             x_local = pad
     x_local = x_local.contiguous()
     out = torch.empty((world * x_local.shape[0],) + tuple(x_local.shape[1:]), dtype=x_local.dtype,

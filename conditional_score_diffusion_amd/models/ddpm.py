@@ -48,13 +48,14 @@ class HipUNet(nn.Module):
     def __init__(self, config, precision=None):
         super().__init__()
         m, d = config.model, config.data
-        # arithmetic of the 3x3 contractions: 'fp32' (exact fp32 MFMA), 'fp16x3' (split-fp16, fp32-class accuracy), 'fp16f8' (split
-        # operands, correction products on the fp8 matrix cores: 1e-5-class accuracy, certified to the 1e-3 tolerance), 'fp16'.
-        # Not a reference key: config.model.csd_precision or $CSD_PRECISION select it.
+        # arithmetic of the 3x3 contractions: 'fp32' (exact fp32 MFMA), 'fp16x3' (split-fp16 operands, three fp16 MFMAs per product:
+        # fp32-class accuracy - the DEFAULT: a model built from an unchanged reference config computes in the reference's precision
+        # class), 'fp16f8' (split operands, correction products with e4m3 operands on the fp8 matrix cores: 1e-5-class accuracy on the
+        # tested weights, opt-in), 'fp16' (opt-in, not certified).  Not a reference key: config.model.csd_precision or $CSD_PRECISION.
         if precision is None:
             precision = m.get('csd_precision', None) if hasattr(m, 'get') else getattr(m, 'csd_precision', None)
         if precision is None:
-            precision = os.environ.get('CSD_PRECISION', 'fp16f8')     # the fastest certified mode (1.3e-5 norm-wise / 4.5e-5 element-wise per evaluation)
+            precision = os.environ.get('CSD_PRECISION', 'fp16x3')
         if precision not in _lib.PREC_IDS:
             raise ValueError('unknown csd precision %r (choose from %s)' % (precision, sorted(_lib.PREC_IDS)))
         self.precision = precision
@@ -76,6 +77,7 @@ class HipUNet(nn.Module):
         self.train_executor = os.environ.get('CSD_TRAIN_EXECUTOR', 'planned')   # 'planned' (csd_unet_backward) | 'operators' (autograd)
         self._train_ws = None
         self._train_ws_busy = False        # a forward whose backward has not run yet holds the shared training workspace
+        self._train_ws_owner = None        # ... identified by its call index
         self.dropout_seed = int(getattr(config, 'seed', 0) or 0)   # Philox key of the dropout masks
         cfg = _lib.UNetConfig()
         cfg.arch = self.arch
@@ -366,11 +368,21 @@ class HipUNet(nn.Module):
         return G.conv2d(h, m[i + 1].weight, m[i + 1].bias, precision=prec)
 
 
-def _release_shared_ws(model_ref, ws_ptr):
-    """the forward that held the model's shared training workspace is done with it (its backward ran, or its graph was dropped)"""
+def _release_shared_ws(model_ref, owner):
+    """the forward that held the model's shared training workspace is done with it (its backward ran, or its graph was dropped).
+    Ownership is keyed by the forward's call index, not by the buffer: the graph of iteration N is usually freed only after
+    iteration N + 1's forward has taken the (same) workspace, and a release keyed by the pointer would then free it under the new owner."""
     model = model_ref()
-    if model is not None and model._train_ws is not None and model._train_ws.data_ptr() == ws_ptr:
+    if model is not None and model._train_ws_busy and getattr(model, '_train_ws_owner', None) == owner:
         model._train_ws_busy = False
+        model._train_ws_owner = None
+
+
+def _release_private_ws(model_ref, handle, ws_ptr):
+    """a monitoring forward's private workspace is about to be freed: drop the library's record of it (csd_unet_train_release)"""
+    model = model_ref()
+    if model is not None and getattr(model, '_h', None) is handle and handle is not None:
+        lib().csd_unet_train_release(handle, ctypes.c_void_p(ws_ptr))
 
 
 class _PlannedNet(torch.autograd.Function):
@@ -393,10 +405,15 @@ class _PlannedNet(torch.autograd.Function):
                                            ptr(labels), ptr(out), B, model._dropout, model.dropout_seed, model._train_calls,
                                            current_stream(x.device)), 'unet_train_forward')
         ctx.model, ctx.table, ctx.ws, ctx.B, ctx.call = model, table, ws, B, model._train_calls
+        ctx.fin = None
         if shared:
             model._train_ws_busy = True
+            model._train_ws_owner = ctx.call
             import weakref
-            weakref.finalize(ctx, _release_shared_ws, weakref.ref(model), ws.data_ptr())
+            ctx.fin = weakref.finalize(ctx, _release_shared_ws, weakref.ref(model), ctx.call)
+        else:
+            import weakref
+            weakref.finalize(ctx, _release_private_ws, weakref.ref(model), model._h, ws.data_ptr())
         ctx.shapes = [(p.shape, p.numel()) for p in params]
         ctx.sink = [p.grad for p in params] if getattr(model, 'grad_sink', False) else None
         return out
@@ -417,7 +434,9 @@ class _PlannedNet(torch.autograd.Function):
         gtable = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
         check(lib().csd_unet_backward(model._h, ctx.table, gtable, ptr(ctx.ws), ctx.ws.numel(), ptr(dout), B, ctx.call,
                                       current_stream(dout.device)), 'unet_backward')
-        _release_shared_ws(lambda: model, ctx.ws.data_ptr())
+        if ctx.fin is not None:          # (the backward releases the workspace itself; the finalizer of this context must not fire later)
+            ctx.fin.detach()
+            _release_shared_ws(lambda: model, ctx.call)
         if direct:
             return (None, None, None, None) + (None,) * len(grads)
         return (None, None, None, None) + tuple(grads)

@@ -42,7 +42,7 @@ class NCSNpp(nn.Module):
         m, d = config.model, config.data
         get = (lambda k, dflt=None: m.get(k, dflt)) if hasattr(m, 'get') else (lambda k, dflt=None: getattr(m, k, dflt))
         if precision is None:
-            precision = get('csd_precision') or os.environ.get('CSD_PRECISION', 'fp16f8')
+            precision = get('csd_precision') or os.environ.get('CSD_PRECISION', 'fp16x3')
         if precision not in _lib.PREC_IDS:
             raise ValueError('unknown csd precision %r' % (precision,))
         self.precision = precision

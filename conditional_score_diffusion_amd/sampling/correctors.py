@@ -46,7 +46,11 @@ def _alpha(sde, t):
     """sampling/correctors.py:63-67,94-98: alphas[timestep] for the VP / subVP SDEs, 1 for the VE SDEs.  One host scalar per call:
     the samplers pass the same time for every sample of the batch (sampling/conditional.py:206, unconditional.py:211)."""
     if isinstance(sde, (sde_lib.VPSDE, sde_lib.cVPSDE, sde_lib.subVPSDE)):
-        timestep = (t[:1].detach().float().cpu() * (sde.N - 1) / sde.T).long()
+        tt = t.detach().float()
+        if tt.numel() > 1 and not bool((tt == tt.reshape(-1)[0]).all()):
+            # the reference's alpha is per sample (alphas[timestep] of shape [B]); this mirror carries ONE scalar into the kernel
+            raise NotImplementedError('Langevin corrector for VP / subVP SDEs: the time must be the same for every sample of the batch')
+        timestep = (tt.reshape(-1)[:1].cpu() * (sde.N - 1) / sde.T).long()
         return float(sde.alphas[timestep])
     return 1.0
 

@@ -6,8 +6,10 @@ Replaces ``BaseSdeGenerativeModel.training_step`` / ``configure_optimizers`` (li
 
 * forward + backward as ONE planned graph behind csd_unet_train_forward / csd_unet_backward (DDPM family; csrc/train_graph.h) or
   on the differentiable HIP operators of grad_ops (NCSN++; csrc/backward.hip);
-* gradients accumulate into ONE flat buffer, all-reduced in 32 MiB buckets that are launched from autograd hooks while the
-  backward of earlier layers is still running (distributed.GradSync);
+* gradients live in ONE flat buffer, all-reduced in 32 MiB buckets (distributed.GradSync).  On the operator-granular executor
+  (NCSN++) the buckets are launched from autograd hooks while the backward of earlier layers is still running; on the planned graph
+  (DDPM family: the whole backward is ONE csd_unet_backward call that only enqueues kernels) every bucket is reduced after that
+  call - there is no overlap with the backward in that mode, and none is claimed (115 MB of gradients per step at configs[3]);
 * ONE fused kernel applies clipping + Adam + EMA (optim.FusedAdam / csd_adam_step).
 """
 import torch

@@ -402,6 +402,9 @@ int csd_unet_train_forward(csd_unet* net, const float* const* params, void* work
                            uint64_t call_index, void* stream);
 int csd_unet_backward(csd_unet* net, const float* const* params, float* const* grads, void* workspace, size_t workspace_bytes,
                       const float* d_out, int B, uint64_t call_index, void* stream);
+/* The library keeps one recorded training graph per (handle, workspace).  A caller that frees a workspace (a monitoring forward's
+ * private one) tells the library so: the record is dropped (no error if there is none).  csd_unet_destroy drops all of a handle's. */
+int csd_unet_train_release(csd_unet* net, const void* workspace);
 
 #ifdef __cplusplus
 }

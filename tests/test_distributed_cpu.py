@@ -250,3 +250,27 @@ def test_two_rank_bucketed_gradient_allreduce_gloo():
         for r in range(world):
             assert torch.allclose(res[r][1][it], flat.grad, rtol=1e-5, atol=1e-7)
         assert torch.equal(res[0][1][it], res[1][1][it])   # every rank holds the same reduced gradient
+
+
+def test_bench_grouped_branch_two_ranks_gloo():
+    """bench.py's N > 1 protocol exactly as the driver launches it (torch.distributed.run, one process per rank): process group,
+    W untimed + K timed steps between barriers, the ONE all_gather of the finished samples, MAX of the ranks' times, rank 0's line -
+    on the CPU with gloo and a stand-in for the HIP sampler (`--stub-sampler`: rank r sleeps 2 (r + 1) ms per step)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    K, W, B = 6, 2, 3
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', str(K),
+                        '--warmup', str(W), '--batch', str(B), '--stub-sampler'], capture_output=True, text=True, timeout=600, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-2000:]      # ONE line, from rank 0
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['steps'] == K and j['warmup'] == W and j['scaling'] == 'weak'
+    assert j['config']['global_batch'] == 2 * B
+    # the timed region is the slowest rank's (rank 1: 4 ms per step), not rank 0's 2 ms
+    assert 3.9 <= j['ms_per_step'] < 40.0
+    assert abs(j['value'] - 2 * B / (1000.0 * j['ms_per_step'] * 1e-3)) < 1e-9 * max(1.0, j['value'])
+    # the gather placed rank r's samples in block r: x started at r and every step added 1
+    assert j['gathered_first_element_per_rank'] == [0.0 + K + W, 1.0 + K + W]

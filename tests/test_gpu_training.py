@@ -293,6 +293,41 @@ def test_two_live_forwards_of_one_model_keep_their_own_activations():
     assert torch.equal(grads_of(xs), ref1)                   # the shared workspace is free again
 
 
+def test_stale_finalizer_does_not_release_the_next_forwards_workspace():
+    """in an ordinary loop (`loss = f(model(x)); loss.backward()`) the graph of iteration N is freed only after iteration
+    N + 1's forward has taken the shared workspace; the old context's finalizer must not hand that workspace to a monitoring forward
+    that runs before backward N + 1 (ownership is keyed by the forward's call index)"""
+    cfg, B, x, y, u, tape = cases.grad_case('sr3_tiny')
+    cfg, nc, p, model = build(cfg)
+    model.train()
+    model._dropout = 0.0
+    xs, ys = x.to(dev()), y.to(dev())
+    lab = torch.full((B,), 3., device=dev())
+
+    def grads():
+        return torch.cat([q.grad.reshape(-1) for q in model.parameters()]).clone()
+
+    for q in model.parameters():
+        q.grad = None
+    model({'x': xs, 'y': ys}, lab).square().sum().backward()
+    ref = grads()
+    loss = None
+    for it in range(3):
+        for q in model.parameters():
+            q.grad = None
+        loss = model({'x': xs, 'y': ys}, lab).square().sum()      # rebinding `loss` frees iteration it - 1's graph AFTER this forward
+        assert model._train_ws_busy
+        mon = model({'x': xs * 0.5, 'y': ys}, lab)                # monitoring forward before the backward: must get its own workspace
+        assert model._train_ws_busy
+        loss.backward()
+        assert torch.equal(grads(), ref)
+        del mon
+    del loss
+    import gc
+    gc.collect()
+    assert not model._train_ws_busy
+
+
 def test_training_fp16x3_grads_close_to_fp32():
     """the split-fp16 convolutions in forward and data-gradient (weight gradient stays fp32 MFMA): fp32-class gradients"""
     g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'grads.npz'))

@@ -12,7 +12,7 @@ import conditional_score_diffusion_amd.models.ddpm      # noqa: F401  (registers
 import conditional_score_diffusion_amd.models.ncsnpp    # noqa: F401
 
 dev = torch.device('cuda:0')
-prec = sys.argv[1] if (len(sys.argv) > 1 and __name__ == '__main__') else 'fp16f8'
+prec = sys.argv[1] if (len(sys.argv) > 1 and __name__ == '__main__') else 'fp16x3'
 
 
 def cmde128_config():

@@ -14,7 +14,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define MFMA(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 
 template <int ORDER, int F, int R>
-__global__ __launch_bounds__(256, 1) void probe(float* out, int iters) {
+__global__ __launch_bounds__(256, 1) void probe(float* out, int iters, long long* clk) {
+  const long long c0 = clock64(), w0 = wall_clock64();
   __shared__ __attribute__((aligned(16))) char lds[65536];
   const int lane = threadIdx.x & 63;
   for (int i = threadIdx.x; i < 16384; i += 256) reinterpret_cast<float*>(lds)[i] = i * 1e-6f;
@@ -77,33 +78,36 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, int iters) {
   for (int i = 0; i < 6; ++i)
     for (int r = 0; r < 16; ++r) s += acc[i][r];
   out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (threadIdx.x == 0) { clk[blockIdx.x * 2] = clock64() - c0; clk[blockIdx.x * 2 + 1] = wall_clock64() - w0; }
 }
 
 template <int ORDER, int F, int R>
-void run(float* out) {
+void run(float* out, long long* clk) {
   const int iters = 400;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((probe<ORDER, F, R>), dim3(256), dim3(256), 0, 0, out, 10);
+  hipLaunchKernelGGL((probe<ORDER, F, R>), dim3(256), dim3(256), 0, 0, out, 10, clk);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL((probe<ORDER, F, R>), dim3(256), dim3(256), 0, 0, out, iters);
+  hipLaunchKernelGGL((probe<ORDER, F, R>), dim3(256), dim3(256), 0, 0, out, iters, clk);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double mf = (double)iters * 9 * 18;
   const double tf = mf * 256 * 4 * 32768.0 / (ms * 1e-3) / 1e12;
-  printf("order %d  fma %3d  ds_read %2d per tap (18 MFMAs): %7.1f us  %6.0f TF/s  %5.1f ns per MFMA\n", ORDER, F, R, ms * 1e3, tf, ms * 1e6 / mf);
+  long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+  printf("order %d  fma %3d  ds_read %2d per tap (18 MFMAs): %7.1f us  %6.0f TF/s  %5.1f ns per MFMA  | %.1f cycles per MFMA at %.3f GHz\n", ORDER, F, R, ms * 1e3, tf, ms * 1e6 / mf, h[0] / mf, h[0] / (h[1] * 10.0));
 }
 
 int main() {
   float* out; hipMalloc(&out, 256 * 256 * 4);
-  run<0, 0, 0>(out); run<1, 0, 0>(out); run<2, 0, 0>(out);
-  run<0, 18, 10>(out); run<1, 18, 10>(out); run<2, 18, 10>(out);
-  run<0, 36, 10>(out); run<1, 36, 10>(out); run<2, 36, 10>(out);
-  run<0, 54, 10>(out); run<1, 54, 10>(out); run<2, 54, 10>(out);
-  run<0, 72, 10>(out); run<1, 72, 10>(out); run<2, 72, 10>(out);
-  run<0, 90, 10>(out); run<1, 90, 10>(out); run<2, 90, 10>(out);
-  run<1, 108, 10>(out); run<1, 36, 18>(out);
+  long long* clk; hipMalloc(&clk, 256 * 16);
+  run<0, 0, 0>(out, clk); run<1, 0, 0>(out, clk); run<2, 0, 0>(out, clk);
+  run<0, 18, 10>(out, clk); run<1, 18, 10>(out, clk); run<2, 18, 10>(out, clk);
+  run<0, 36, 10>(out, clk); run<1, 36, 10>(out, clk); run<2, 36, 10>(out, clk);
+  run<0, 54, 10>(out, clk); run<1, 54, 10>(out, clk); run<2, 54, 10>(out, clk);
+  run<0, 72, 10>(out, clk); run<1, 72, 10>(out, clk); run<2, 72, 10>(out, clk);
+  run<0, 90, 10>(out, clk); run<1, 90, 10>(out, clk); run<2, 90, 10>(out, clk);
+  run<1, 108, 10>(out, clk); run<1, 36, 18>(out, clk);
   return 0;
 }

@@ -25,10 +25,12 @@ NS = Cin // 16
 st = t[:, :NS + 1]
 d = np.diff(st, axis=1)
 print('shape C %d+%d -> %d @%d res=%d: %d workgroups sampled (their second tile)' % (C0, C1, Cout, H, res, len(t)))
-print('stage cycles (mean): ' + ' '.join('%6.0f' % v for v in d.mean(0)) + '   (MFMA floor 5184)')
-print('stage cycles (max) : ' + ' '.join('%6.0f' % v for v in d.max(0)))
-print('barrier wait in stage 2: %.0f' % (t[:, 21] - t[:, 20]).mean())
-print('tile: K loop %.0f, last stage end -> epilogue start %.0f, stores %.0f, statistics %.0f | total %.0f' % (
-    (t[:, NS] - t[:, 0]).mean(), (t[:, 22] - t[:, NS]).mean(), (t[:, 23] - t[:, 22]).mean(), (t[:, 24] - t[:, 23]).mean(), (t[:, 24] - t[:, 0]).mean()))
+print('unit cycles, start of taps 0-7 of stage s -> of stage s + 1 (the last: taps 0-7 only), mean: ' + ' '.join('%6.0f' % v for v in d.mean(0)) + '   (MFMA floor 5184 / 4608)')
+print('            max : ' + ' '.join('%6.0f' % v for v in d.max(0)))
+print('barrier wait in front of stage 2: %.0f' % (t[:, 21] - t[:, 20]).mean())
+print('previous tile\'s epilogue: stores %.0f, statistics %.0f | this tile, first tap 0 -> last tap 7: %.0f' % (
+    (t[:, 23] - t[:, 22]).mean(), (t[:, 24] - t[:, 23]).mean(), (t[:, NS] - t[:, 0]).mean()))
+ghz = ((t[:, 27] - t[:, 26]) / ((t[:, 29] - t[:, 28]) * 10.0)).mean()
+print('one tile: %.0f cycles in %.2f us -> shader clock %.3f GHz' % ((t[:, 27] - t[:, 26]).mean(), (t[:, 29] - t[:, 28]).mean() * 0.01, ghz))
 wall = (t[:, 31] - t[:, 30]).mean() * 10.0
 print('kernel wall per workgroup %.1f us' % (wall / 1e3))
