@@ -40,6 +40,52 @@ def test_metrics_match_the_reference(golden_dir):
         ev.get_calculate_consistency_fn('image-to-image')
 
 
+def test_ssim_against_an_independent_scipy_restatement():
+    """SSIM pin.  The reference's calculate_ssim needs OpenCV, which this image lacks: the fixture value in eval_tools.npz came from
+    the reference's function running on a builder-written cv2 stand-in (oracle/make_goldens.py) - i.e. NOT pinned to OpenCV itself.
+    Second opinion here: the published formula (Wang et al. 2004: 11 x 11 Gaussian window, sigma 1.5, K1 = 0.01, K2 = 0.03, L = 255,
+    'valid' region, mean over the map, mean over the channels) restated with scipy's 2-D convolution, independent of the module's
+    torch code.  SSIM therefore stays 'unpinned against OpenCV', cross-checked against scipy."""
+    from scipy.signal import convolve2d
+    from conditional_score_diffusion_amd import evaluation as ev
+    x, s, _ = eval_case()
+    a, b = (s * 255).double().numpy(), (x * 255).double().numpy()
+    g = np.exp(-((np.arange(11) - 5.0) ** 2) / (2 * 1.5 ** 2))
+    g /= g.sum()
+    win = np.outer(g, g)
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    want = []
+    for i in range(a.shape[0]):
+        per_c = []
+        for c in range(a.shape[1]):
+            f = lambda t: convolve2d(t, win, mode='valid')      # noqa: E731
+            m1, m2 = f(a[i, c]), f(b[i, c])
+            s1, s2, s12 = f(a[i, c] ** 2) - m1 * m1, f(b[i, c] ** 2) - m2 * m2, f(a[i, c] * b[i, c]) - m1 * m2
+            per_c.append((((2 * m1 * m2 + C1) * (2 * s12 + C2)) / ((m1 * m1 + m2 * m2 + C1) * (s1 + s2 + C2))).mean())
+        want.append(np.mean(per_c))
+    assert np.allclose(ev.ssim_per_image(s * 255, x * 255).numpy(), want, rtol=1e-9)
+    assert ev.ssim_per_image(x * 255, x * 255).numpy() == pytest.approx(1.0, abs=1e-12)
+
+
+@pytest.mark.gpu
+def test_metrics_match_the_reference_on_device_tensors(golden_dir):
+    """the same reference values with the images ON THE GPU (what the evaluator sees after sample()): the metrics are torch code
+    (F.conv2d / matmul in float64 on the samples' device - plumbing around the HIP path, not part of it)"""
+    from conditional_score_diffusion_amd import evaluation as ev
+    g = np.load(os.path.join(golden_dir, 'eval_tools.npz'))
+    d = torch.device('cuda:0')
+    x, s, mask_info = eval_case()
+    x, s = x.to(d), s.to(d)
+    assert np.allclose(ev.psnr_per_image(s * 255, x * 255).cpu().numpy(), g['psnr_each'], rtol=1e-5)
+    assert np.allclose(ev.ssim_per_image(s * 255, x * 255).cpu().numpy(), g['ssim_each'], rtol=1e-5)
+    for scale in (0.25, 0.125, 2.0):
+        ref = g['resize_%g' % scale]
+        got = ev.resize(x, scale).cpu().numpy()
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 5e-6, scale
+    assert ev.get_calculate_consistency_fn('super-resolution')(s, x, 4) == pytest.approx(float(g['consistency_sr']), rel=1e-4)
+    assert ev.get_calculate_consistency_fn('inpainting')(s, x, mask_info) == pytest.approx(float(g['consistency_inp']), rel=1e-5)
+
+
 def test_png_writer_roundtrip(tmp_path):
     from conditional_score_diffusion_amd import evaluation as ev
     t = torch.rand(3, 7, 5, generator=torch.Generator().manual_seed(0))
