@@ -18,7 +18,13 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, int iters, long long
   const long long c0 = clock64(), w0 = wall_clock64();
   __shared__ __attribute__((aligned(16))) char lds[65536];
   const int lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < 16384; i += 256) reinterpret_cast<float*>(lds)[i] = i * 1e-6f;
+  for (int i = threadIdx.x; i < 16384; i += 256) {
+    // ORDER 3: random fp16 pairs (what real operands look like to the matrix pipe: every bit toggles); otherwise a smooth ramp
+    unsigned h = (i + blockIdx.x * 16384) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    const unsigned lo16 = (h & 0x3ff) | (((h >> 10) % 12 + 9) << 10) | ((h >> 20 & 1) << 15), hi16 = (h >> 21 & 0x3ff) | (((h >> 3) % 12 + 9) << 10) | ((h >> 31) << 15);
+    if (ORDER == 3) reinterpret_cast<unsigned*>(lds)[i] = lo16 | (hi16 << 16);
+    else reinterpret_cast<float*>(lds)[i] = i * 1e-6f;
+  }
   __syncthreads();
   floatx16 acc[6];
   for (int i = 0; i < 6; ++i)
@@ -50,6 +56,23 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, int iters, long long
                        : "+a"(acc[i]) : "v"(a[i / 3]), "v"(b[i % 3]), "v"(a[1 - i / 3]), "v"(b[(i + 1) % 3]));
           fill(i, 6);
         }
+      } else if (ORDER == 3) {
+        // operands of this tap come from LDS (10 fragments, a different 10 KB window per tap), read during the previous tap
+        half8 fa[2][2], fb[2][3];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) fa[q][m] = *reinterpret_cast<const half8*>(lds + ((tap * 10 + q * 2 + m) & 63) * 1024 + lane * 16);
+#pragma unroll
+          for (int m = 0; m < 3; ++m) fb[q][m] = *reinterpret_cast<const half8*>(lds + ((tap * 10 + 4 + q * 3 + m) & 63) * 1024 + lane * 16);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            MFMA(acc[i], fa[p == 1 ? 1 : 0][i / 3], fb[p == 0 ? 1 : 0][i % 3]);
+            fill(p * 6 + i, 18);
+          }
       } else if (ORDER == 1) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
@@ -109,5 +132,6 @@ int main() {
   run<0, 72, 10>(out, clk); run<1, 72, 10>(out, clk); run<2, 72, 10>(out, clk);
   run<0, 90, 10>(out, clk); run<1, 90, 10>(out, clk); run<2, 90, 10>(out, clk);
   run<1, 108, 10>(out, clk); run<1, 36, 18>(out, clk);
+  run<3, 0, 0>(out, clk); run<3, 36, 0>(out, clk); run<3, 54, 0>(out, clk);
   return 0;
 }
