@@ -251,7 +251,9 @@ int linear_launch(const float* in, const float* W, const float* bias, float* out
 int assemble_input_launch(const float* x, const float* y, const float* y_noise, float y_sigma,
                           float* out, int B, int Cx, int Cy, int HW, int Cpad, int centered,
                           hipStream_t s);
-int fir_resample_nhwc_launch(const float* in, float* out, int B, int H, int W, int C, const float* taps4, int up, hipStream_t s);
+// scale multiplies the kernel (after the forward gain), flip reverses the taps: the transposed operators of the training graph
+int fir_resample_nhwc_launch(const float* in, float* out, int B, int H, int W, int C, const float* taps4, int up, hipStream_t s,
+                             float scale = 1.f, int flip = 0);
 // out_x = FIR(in), out_h = FIR(act(in * nscale + nshift)) in one pass (the up / down BigGAN block's two resampled tensors)
 int fir_resample2_nhwc_launch(const float* in, const float* nscale, const float* nshift, float* out_x, float* out_h, int B, int H, int W,
                               int C, const float* taps4, int up, int act, hipStream_t s);

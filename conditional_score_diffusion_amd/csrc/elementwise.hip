@@ -584,13 +584,14 @@ int fir_resample2_nhwc_launch(const float* in, const float* nscale, const float*
   return CSD_OK;
 }
 
-int fir_resample_nhwc_launch(const float* in, float* out, int B, int H, int W, int C, const float* taps4, int up, hipStream_t s) {
+int fir_resample_nhwc_launch(const float* in, float* out, int B, int H, int W, int C, const float* taps4, int up, hipStream_t s,
+                             float scale, int flip) {
   // _setup_kernel (up_or_down_sampling.py:181-189): outer product, normalised, times the gain (factor^2 when upsampling)
   Fir16 f;
   float sum = 0.f;
   for (int a = 0; a < 4; ++a)
-    for (int b = 0; b < 4; ++b) { f.k[a * 4 + b] = taps4[a] * taps4[b]; sum += f.k[a * 4 + b]; }
-  for (int a = 0; a < 16; ++a) f.k[a] = f.k[a] / sum * (up ? 4.f : 1.f);
+    for (int b = 0; b < 4; ++b) { f.k[a * 4 + b] = taps4[flip ? 3 - a : a] * taps4[flip ? 3 - b : b]; sum += f.k[a * 4 + b]; }
+  for (int a = 0; a < 16; ++a) f.k[a] = f.k[a] / sum * (up ? 4.f : 1.f) * scale;
   const size_t total = (size_t)B * (up ? H * 2 : H / 2) * (up ? W * 2 : W / 2) * C;
   if (C % 4 == 0) {
     hipLaunchKernelGGL(fir_resample_nhwc4_kernel, dim3((unsigned)std::min<size_t>(cdiv64(total / 4, 256), 65536)), dim3(256), 0, s,

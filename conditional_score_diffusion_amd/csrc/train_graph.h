@@ -1,5 +1,9 @@
-// train_graph.h - the DDPM-family training step as ONE planned graph behind the C ABI: csd_unet_train_forward /
-// csd_unet_backward.  Included at the end of unet.hip (shares Net / Module / Param).
+// train_graph.h - the training step of BOTH network families (arch 0: DDPM family, arch 1: NCSN++) as ONE planned graph behind the C
+// ABI: csd_unet_train_forward / csd_unet_backward.  Included at the end of unet.hip (shares Net /
+// Module / Param).  NCSN++ (models/ncsnpp.py:238-388, models/layerspp.py:44-91,212-274): BigGAN blocks with FIR up / down sampling of
+// both branches (backward = the transposed FIR: the other direction's geometry with the flipped taps, op/upfirdn2d.py:20-87), the
+// Conv_2 shortcut, (x + h) / sqrt(2), AttnBlockpp, Combine 'sum' of the input pyramid, the output pyramid, Fourier or positional
+// embedding, GroupNorm(min(C / 4, 32)).
 //
 // What it replaces: torch autograd over models/ddpm.py:149-213 + models/layers.py:524-675 in training mode (run_lib.py:55-73).
 // The forward runs the reference's layer sequence on the NHWC operators of this library with nn.Dropout active and keeps
@@ -16,12 +20,13 @@
 namespace csd {
 
 struct TT { float* p = nullptr; int H = 0, C = 0; float* g = nullptr; };          // tensor [B, H, H, C]: data, gradient
-enum TSKind { TS_STEM, TS_RES, TS_ATTN, TS_DOWN, TS_UP, TS_CAT, TS_HEAD };
+enum TSKind { TS_STEM, TS_RES, TS_ATTN, TS_DOWN, TS_UP, TS_CAT, TS_HEAD, TS_COMBINE, TS_PYR };
 struct TStep {
   TSKind kind;
   int mod = -1, in0 = -1, in1 = -1, out = -1;
-  float* sv[8] = {};
+  float* sv[10] = {};
   uint64_t drop_id = 0;
+  int flag = 0;                 // TS_PYR: 1 = the pyramid level above adds FIR-up of the previous level (in1)
 };
 
 struct TrainState {
@@ -34,6 +39,7 @@ struct TrainState {
   std::vector<TT> t;
   std::vector<TStep> steps;
   float *xin = nullptr, *emb = nullptr, *temb1 = nullptr, *temb2 = nullptr, *temb2_act = nullptr;
+  int lin0 = 0, emb_dim = 0, fourier_mod = -1;      // module index of the embedding MLP's first Linear; width of the embedding; NCSN++ Fourier module
 };
 
 // one recorded forward per (network handle, workspace): two forwards of one network may be alive at once (a monitoring forward
@@ -125,6 +131,8 @@ struct TG {
     return p;
   }
   float* alloc_bytes(size_t bytes) { return alloc((bytes + 3) / 4); }
+  int G_of(int C) const { return n.cfg.arch == 1 ? std::min(C / 4, 32) : 32; }      // GroupNorm groups (layerspp.py:67,219,231)
+  float skip_scale() const { return (n.cfg.arch == 1 && n.cfg.skip_rescale) ? 0.70710678118654752440f : 1.f; }
   size_t act_n(int H, int C) const { return (size_t)B * H * H * C; }
   const float* W(int mod, const char* sub) const { const int i = n.P(mname(mod, sub)); return (dry || i < 0) ? nullptr : P[i]; }
   float* DW(int mod, const char* sub) const { const int i = n.P(mname(mod, sub)); return (dry || i < 0) ? nullptr : G[i]; }
@@ -159,7 +167,7 @@ struct TG {
          uint64_t drop_id = 0, void* planes = nullptr, int plane_count = 0) {
     const size_t m = top;
     float* sc = alloc_bytes(csd_groupnorm_nhwc_scratch_bytes(B, C, H * H));
-    TG_RUN(groupnorm_act_dropout_nhwc(x, gamma, beta, y, rs, ms, mask, p_drop, seed, drop_id, B, C, H * H, 32, 1e-6f, a, sc, s, planes,
+    TG_RUN(groupnorm_act_dropout_nhwc(x, gamma, beta, y, rs, ms, mask, p_drop, seed, drop_id, B, C, H * H, G_of(C), 1e-6f, a, sc, s, planes,
                                       plane_count));
     top = m;
     return CSD_OK;
@@ -171,7 +179,7 @@ struct TG {
     float* grow = alloc((size_t)B * C);
     float* brow = alloc((size_t)B * C);
     float* sc = alloc_bytes(csd_groupnorm_nhwc_scratch_bytes(B, C, H * H));
-    TG_RUN(groupnorm_act_backward_nhwc_add(x, gamma, beta, rs, ms, dy, add, dx, grow, brow, C, B, C, H * H, 32, a, sc, s));
+    TG_RUN(groupnorm_act_backward_nhwc_add(x, gamma, beta, rs, ms, dy, add, dx, grow, brow, C, B, C, H * H, G_of(C), a, sc, s));
     TG_RUN(sum_rows2(grow, dgamma, brow, dbeta, B, C, s));
     top = m;
     return CSD_OK;
@@ -198,6 +206,15 @@ struct TG {
     return CSD_OK;
   }
   int add_into(float* dst, const float* src, size_t nfl) { TG_RUN(csd_axpby(dst, src, dst, 1.f, 1.f, 0.f, 1.f, (int64_t)nfl, s)); return CSD_OK; }
+  // FIR resampling by 2 of [Bn, H, H, C] (upsample_2d / downsample_2d, up_or_down_sampling.py:196-257).  adjoint: the gradient of
+  // the OTHER direction's forward = this geometry with the flipped taps and the other gain (op/upfirdn2d.py:20-87: up and down
+  // swapped, kernel flipped, pads g_pad): d upsample = down geometry x 4, d downsample = up geometry / 4.
+  int fir(const float* x, float* y, int Bn, int H, int C, bool up_geometry, bool adjoint) {
+    TG_RUN(fir_resample_nhwc_launch(x, y, Bn, H, H, C, n.cfg.fir_kernel, up_geometry ? 1 : 0, s,
+                                    adjoint ? (up_geometry ? 0.25f : 4.f) : 1.f, adjoint ? 1 : 0));
+    return CSD_OK;
+  }
+  int scale_into(const float* src, float* dst, float f, size_t nfl) { TG_RUN(csd_axpby(src, nullptr, dst, f, 0.f, 0.f, 1.f, (int64_t)nfl, s)); return CSD_OK; }
   int launch_blocks(size_t n) const { return (int)std::min<size_t>((n + 255) / 256, 256 * 16); }
 
   // gradient routing: the first contribution becomes the tensor's gradient buffer, later ones are added
@@ -278,6 +295,71 @@ struct TG {
     return CSD_OK;
   }
 
+  // ResnetBlockBigGANpp.forward (models/layerspp.py:242-274): h = act(GroupNorm_0(x)); up / down: h, x = FIR(h), FIR(x); h = Conv_0(h)
+  // + Dense_0(act(temb)); h = Conv_1(dropout(act(GroupNorm_1(h)))); x = Conv_2(x) if the shape changes; (x + h) / sqrt(2)
+  int respp_fwd(const Module& m, int in, int* out_tid) {
+    const csd_unet_config& c = n.cfg;
+    const int H = st.t[in].H, cin = m.cin, cout = m.cout;
+    const int Ho = m.up ? 2 * H : (m.down ? H / 2 : H);
+    const bool resample = m.up || m.down, has_sc = cin != cout || resample;
+    const float* h = st.t[in].p;
+    TStep sp;
+    sp.kind = TS_RES; sp.mod = m.idx; sp.in0 = in;
+    float* a0 = alloc(act_n(H, cin));                // act(GroupNorm_0(x))
+    float* rs0 = alloc((size_t)B * cin); float* ms0 = alloc((size_t)B * cin);
+    float *hr = a0, *xr = nullptr;
+    if (resample) { hr = alloc(act_n(Ho, cin)); xr = alloc(act_n(Ho, cin)); }
+    float* c0 = alloc(act_n(Ho, cout));
+    float* a1 = alloc(act_n(Ho, cout));
+    float* rs1 = alloc((size_t)B * cout); float* ms1 = alloc((size_t)B * cout);
+    float* mask = nullptr;
+    ++drop_count;
+    sp.drop_id = (call << 16) + (uint64_t)drop_count;
+    if (p_drop > 0.f) mask = alloc(act_n(Ho, cout));
+    const int out = new_tensor(Ho, cout);
+    float* o = st.t[out].p;
+    int rc;
+    {
+      const size_t mk = top;
+      const int np0 = resample ? 0 : conv2d_operand_planes(B, cin, cout, H, H, 3, 1, 0, 0, prec);
+      float* pl0 = np0 ? alloc_bytes((size_t)np0 * B * H * H * cin * 2) : nullptr;
+      rc = gn(h, W(m.idx, "GroupNorm_0.weight"), W(m.idx, "GroupNorm_0.bias"), a0, rs0, ms0, cin, H, act, nullptr, 0, pl0, np0);
+      if (rc) return rc;
+      if (resample) {
+        rc = fir(a0, hr, B, H, cin, m.up != 0, false); if (rc) return rc;
+        rc = fir(h, xr, B, H, cin, m.up != 0, false); if (rc) return rc;
+      }
+      float* d = alloc((size_t)B * cout);            // (time-conditional networks only: build_modules_ncsnpp)
+      TG_RUN(csd_linear(st.temb2_act, W(m.idx, "Dense_0.weight"), W(m.idx, "Dense_0.bias"), d, B, 4 * c.nf, cout, CSD_ACT_NONE, s));
+      rc = conv(hr, W(m.idx, "Conv_0.weight"), W(m.idx, "Conv_0.bias"), c0, cin, cout, Ho, 3, 1, 0, 0, 3, nullptr, d, pl0);
+      if (rc) return rc;
+      top = mk;
+    }
+    {
+      const size_t mk = top;
+      const int np1 = conv2d_operand_planes(B, cout, cout, Ho, Ho, 3, 1, 0, 0, prec);
+      float* pl1 = np1 ? alloc_bytes((size_t)np1 * B * Ho * Ho * cout * 2) : nullptr;
+      rc = gn(c0, W(m.idx, "GroupNorm_1.weight"), W(m.idx, "GroupNorm_1.bias"), a1, rs1, ms1, cout, Ho, act, mask, sp.drop_id, pl1, np1);
+      if (rc) return rc;
+      const float* shortcut = h;
+      if (has_sc) {                                  // Conv_2: 1x1 on the (resampled) block input
+        float* sc = alloc(act_n(Ho, cout));
+        rc = conv(resample ? xr : h, W(m.idx, "Conv_2.weight"), W(m.idx, "Conv_2.bias"), sc, cin, cout, Ho, 1, 1, 0, 0, 3);
+        if (rc) return rc;
+        shortcut = sc;
+      }
+      rc = conv(a1, W(m.idx, "Conv_1.weight"), W(m.idx, "Conv_1.bias"), o, cout, cout, Ho, 3, 1, 0, 0, 3, shortcut, nullptr, pl1);
+      if (rc) return rc;
+      if (skip_scale() != 1.f) { rc = scale_into(o, o, skip_scale(), act_n(Ho, cout)); if (rc) return rc; }
+      top = mk;
+    }
+    sp.out = out;
+    sp.sv[0] = hr; sp.sv[1] = rs0; sp.sv[2] = ms0; sp.sv[3] = c0; sp.sv[4] = a1; sp.sv[5] = rs1; sp.sv[6] = ms1; sp.sv[7] = mask; sp.sv[8] = xr;
+    st.steps.push_back(sp);
+    *out_tid = out;
+    return CSD_OK;
+  }
+
   int attn_fwd(const Module& m, int in, int* out_tid) {
     const int H = st.t[in].H, C = m.cin;
     const float* h = st.t[in].p;
@@ -309,6 +391,7 @@ struct TG {
     float* o = st.t[out].p;
     rc = conv(a, W(m.idx, "NIN_3.W"), W(m.idx, "NIN_3.b"), o, C, C, H, 1, 1, 0, 0, 3 | 4, h);      // + h in the epilogue
     if (rc) return rc;
+    if (skip_scale() != 1.f) { rc = scale_into(o, o, skip_scale(), act_n(H, C)); if (rc) return rc; }      // AttnBlockpp: (x + h) / sqrt(2)
     sp.out = out;
     sp.sv[0] = t; sp.sv[1] = rs; sp.sv[2] = ms; sp.sv[3] = qkv; sp.sv[4] = a;
     st.steps.push_back(sp);
@@ -335,9 +418,11 @@ struct TG {
 
   int forward(const float* x, const float* y, const float* labels, float* out) {
     const csd_unet_config& c = n.cfg;
+    if (c.arch == 1) return forward_ncsnpp(x, y, labels, out);
     const int S = c.image_size, cx = c.x_channels, cy = c.y_channels, cio = cx + cy, nf = c.nf;
     st.t.clear(); st.steps.clear();
     drop_count = 0;
+    st.lin0 = 0; st.emb_dim = nf; st.fourier_mod = -1;
     // network input: cat(x, y) NCHW (models/ddpm.py:275-298 wrappers), 2h - 1 for data in [0, 1] (:163-168)
     const size_t hw = (size_t)S * S;
     st.xin = alloc((size_t)B * cio * hw);
@@ -437,6 +522,143 @@ struct TG {
   }
 
   // =====================================================================================================================
+  // forward, NCSN++ (models/ncsnpp.py:238-388 with model.train(); the module walk of build_modules_ncsnpp)
+  // =====================================================================================================================
+  int forward_ncsnpp(const float* x, const float* y, const float* labels, float* out) {
+    const csd_unet_config& c = n.cfg;
+    const int S = c.image_size, cx = c.x_channels, cy = c.y_channels, cio = cx + cy, nf = c.nf;
+    st.t.clear(); st.steps.clear();
+    drop_count = 0;
+    const size_t hw = (size_t)S * S;
+    st.xin = alloc((size_t)B * cio * hw);            // cat(x, y) NCHW, 2h - 1 for data in [0, 1] (ncsnpp.py:266-268)
+    if (!dry) {
+      CSD_CHECK_HIP(hipMemcpy2DAsync(st.xin, cio * hw * 4, x, cx * hw * 4, cx * hw * 4, B, hipMemcpyDeviceToDevice, s));
+      if (cy) CSD_CHECK_HIP(hipMemcpy2DAsync(st.xin + cx * hw, cio * hw * 4, y, cy * hw * 4, cy * hw * 4, B, hipMemcpyDeviceToDevice, s));
+      if (!c.centered) TG_RUN(csd_axpby(st.xin, nullptr, st.xin, 2.f, 0.f, -1.f, 1.f, (int64_t)((size_t)B * cio * hw), s));
+    }
+    size_t mi = 0;
+    st.fourier_mod = -1;
+    st.emb_dim = nf;
+    if (c.embedding_type == 1) {                     // Gaussian Fourier features of the label (layerspp.py:32-41; W is a fixed buffer)
+      const Module& fm = n.mods[mi++];
+      st.fourier_mod = fm.idx;
+      st.emb_dim = 2 * nf;
+      st.emb = alloc((size_t)B * 2 * nf);
+      TG_RUN(csd_fourier_embedding(labels, W(fm.idx, "W"), st.emb, B, nf, s));
+    } else {
+      st.emb = alloc((size_t)B * nf);
+      TG_RUN(csd_timestep_embedding(labels, st.emb, B, nf, s));
+    }
+    st.lin0 = (int)mi;
+    st.temb1 = alloc((size_t)B * 4 * nf); st.temb2 = alloc((size_t)B * 4 * nf);
+    TG_RUN(csd_linear(st.emb, W((int)mi, "weight"), W((int)mi, "bias"), st.temb1, B, st.emb_dim, 4 * nf, CSD_ACT_NONE, s));
+    TG_RUN(csd_linear(st.temb1, W((int)mi + 1, "weight"), W((int)mi + 1, "bias"), st.temb2, B, 4 * nf, 4 * nf, act, s));
+    st.temb2_act = alloc((size_t)B * 4 * nf);
+    TG_RUN(csd_act(st.temb2, nullptr, st.temb2_act, act, (int64_t)B * 4 * nf, s));
+    mi += 2;
+    int rc;
+    std::vector<int> hs;
+    {                                                // first conv: NCHW in, NHWC out
+      const Module& m = n.mods[mi++];
+      const int t0 = new_tensor(S, nf);
+      rc = conv(st.xin, W(m.idx, "weight"), W(m.idx, "bias"), st.t[t0].p, cio, nf, S, 3, 1, 0, 0, 2);
+      if (rc) return rc;
+      TStep sp;
+      sp.kind = TS_STEM; sp.mod = m.idx; sp.out = t0;
+      st.steps.push_back(sp);
+      hs.push_back(t0);
+    }
+    auto is_attn = [&](int res) {
+      for (int i = 0; i < c.n_attn; ++i) if (c.attn_resolutions[i] == res) return true;
+      return false;
+    };
+    const float* pyr_in = st.xin;                    // input pyramid (NCHW = [B * cio] single-channel images for the FIR pass)
+    int pyr_side = S;
+    int h = -1;
+    for (int l = 0; l < c.n_levels; ++l) {
+      for (int b = 0; b < c.num_res_blocks; ++b) {
+        rc = respp_fwd(n.mods[mi++], hs.back(), &h); if (rc) return rc;
+        if (is_attn(st.t[h].H)) { rc = attn_fwd(n.mods[mi++], h, &h); if (rc) return rc; }
+        hs.push_back(h);
+      }
+      if (l != c.n_levels - 1) {
+        rc = respp_fwd(n.mods[mi++], hs.back(), &h); if (rc) return rc;      // the down block
+        if (c.progressive_input == 1) {              // pyramid_downsample + Combine 'sum': Conv_0(pyramid) + h (layerspp.py:44-59)
+          const Module& cm = n.mods[mi++];
+          const int side = st.t[h].H, C = cm.cout;
+          float* pn = alloc((size_t)B * cio * side * side);
+          rc = fir(pyr_in, pn, B * cio, pyr_side, 1, false, false); if (rc) return rc;
+          pyr_in = pn; pyr_side = side;
+          const int o = new_tensor(side, C);
+          rc = conv(pn, W(cm.idx, "Conv_0.weight"), W(cm.idx, "Conv_0.bias"), st.t[o].p, cio, C, side, 1, 1, 0, 0, 2); if (rc) return rc;
+          rc = add_into(st.t[o].p, st.t[h].p, act_n(side, C)); if (rc) return rc;
+          TStep sp;
+          sp.kind = TS_COMBINE; sp.mod = cm.idx; sp.in0 = h; sp.out = o; sp.sv[0] = pn;
+          st.steps.push_back(sp);
+          h = o;
+        }
+        hs.push_back(h);
+      }
+    }
+    h = hs.back();
+    rc = respp_fwd(n.mods[mi++], h, &h); if (rc) return rc;
+    rc = attn_fwd(n.mods[mi++], h, &h); if (rc) return rc;
+    rc = respp_fwd(n.mods[mi++], h, &h); if (rc) return rc;
+    int pyr = -1;                                    // output pyramid: tensor id of the previous (coarser) level, NCHW data
+    for (int l = c.n_levels - 1; l >= 0; --l) {
+      for (int b = 0; b < c.num_res_blocks + 1; ++b) {
+        int cat;
+        rc = cat_fwd(h, hs.back(), &cat); if (rc) return rc;
+        hs.pop_back();
+        rc = respp_fwd(n.mods[mi++], cat, &h); if (rc) return rc;
+      }
+      if (is_attn(st.t[h].H)) { rc = attn_fwd(n.mods[mi++], h, &h); if (rc) return rc; }
+      if (c.progressive == 1) {                      // output_skip: pyramid = Conv(act(GroupNorm(h))) + pyramid_upsample(pyramid) (ncsnpp.py:340-352)
+        const Module& mg = n.mods[mi++];
+        const Module& mc = n.mods[mi++];
+        const int H = st.t[h].H, C = mg.cin;
+        float* g = alloc(act_n(H, C));
+        float* rs = alloc((size_t)B * C); float* ms = alloc((size_t)B * C);
+        rc = gn(st.t[h].p, W(mg.idx, "weight"), W(mg.idx, "bias"), g, rs, ms, C, H, act); if (rc) return rc;
+        const int pt = new_tensor(H, cio, false);
+        st.t[pt].p = l == 0 ? out : alloc((size_t)B * cio * H * H);
+        rc = conv(g, W(mc.idx, "weight"), W(mc.idx, "bias"), st.t[pt].p, C, cio, H, 3, 1, 0, 0, 1); if (rc) return rc;
+        TStep sp;
+        sp.kind = TS_PYR; sp.mod = mg.idx; sp.in0 = h; sp.in1 = pyr; sp.out = pt;
+        sp.sv[0] = g; sp.sv[1] = rs; sp.sv[2] = ms;
+        sp.flag = (pyr >= 0 ? 1 : 0) | (l == 0 ? 2 : 0);
+        if (pyr >= 0) {
+          const size_t mk = top;
+          float* up = alloc((size_t)B * cio * H * H);
+          rc = fir(st.t[pyr].p, up, B * cio, H / 2, 1, true, false); if (rc) return rc;
+          rc = add_into(st.t[pt].p, up, (size_t)B * cio * H * H); if (rc) return rc;
+          top = mk;
+        }
+        st.steps.push_back(sp);
+        pyr = pt;
+      }
+      if (l != 0) { rc = respp_fwd(n.mods[mi++], h, &h); if (rc) return rc; }      // the up block
+    }
+    if (c.progressive != 1) {                        // act(GroupNorm) + conv, NHWC in, NCHW out
+      const Module& mg = n.mods[mi];
+      const Module& mc = n.mods[mi + 1];
+      mi += 2;
+      const int H = st.t[h].H, C = mg.cin;
+      float* g = alloc(act_n(H, C));
+      float* rs = alloc((size_t)B * C); float* ms = alloc((size_t)B * C);
+      rc = gn(st.t[h].p, W(mg.idx, "weight"), W(mg.idx, "bias"), g, rs, ms, C, H, act); if (rc) return rc;
+      rc = conv(g, W(mc.idx, "weight"), W(mc.idx, "bias"), out, C, c.out_channels, H, 3, 1, 0, 0, 1); if (rc) return rc;
+      TStep sp;
+      sp.kind = TS_HEAD; sp.mod = mg.idx; sp.in0 = h;
+      sp.sv[0] = g; sp.sv[1] = rs; sp.sv[2] = ms;
+      st.steps.push_back(sp);
+    }
+    CSD_REQUIRE(hs.empty() && mi == n.mods.size(), "train_forward (ncsnpp): module walk out of step (%zu of %zu)", mi, n.mods.size());
+    st.fwd_top = top;
+    return CSD_OK;
+  }
+
+  // =====================================================================================================================
   // backward
   // =====================================================================================================================
   // Linear y = act_in(x) W^T + b with x [B, K], W [N, K]: dW, db from dy; dact (gradient w.r.t. act_in(x)) is ADDED to dact_acc
@@ -517,6 +739,72 @@ struct TG {
     return contribute(sp.in0, dh);
   }
 
+  int respp_bwd(const TStep& sp, float* dtemb_act) {
+    const csd_unet_config& c = n.cfg;
+    const Module& m = n.mods[sp.mod];
+    const TT& tin = st.t[sp.in0];
+    const int H = tin.H, cin = m.cin, cout = m.cout;
+    const int Ho = m.up ? 2 * H : (m.down ? H / 2 : H);
+    const bool resample = m.up || m.down, has_sc = cin != cout || resample;
+    const float* h = tin.p;
+    float *op0 = sp.sv[0], *rs0 = sp.sv[1], *ms0 = sp.sv[2], *c0 = sp.sv[3], *a1 = sp.sv[4], *rs1 = sp.sv[5], *ms1 = sp.sv[6], *mask = sp.sv[7],
+          *xr = sp.sv[8];
+    float* dh = alloc(act_n(H, cin));
+    const size_t mk = top;
+    int rc;
+    float* dout = st.t[sp.out].g;
+    if (skip_scale() != 1.f) {                       // out = (x + h) / sqrt(2)
+      float* ds = alloc(act_n(Ho, cout));
+      rc = scale_into(dout, ds, skip_scale(), act_n(Ho, cout)); if (rc) return rc;
+      dout = ds;
+    }
+    // Conv_1
+    rc = wgrad(a1, dout, DW(m.idx, "Conv_1.weight"), cout, cout, Ho, 3, 1, 0, 0, 3); if (rc) return rc;
+    rc = bias_grad(dout, DW(m.idx, "Conv_1.bias"), cout, Ho); if (rc) return rc;
+    float* d1 = alloc(act_n(Ho, cout));
+    rc = conv(dout, W(m.idx, "Conv_1.weight"), nullptr, d1, cout, cout, Ho, 3, 1, 0, 0, 3 | 4); if (rc) return rc;
+    if (mask) TG_RUN(csd_mul(d1, mask, d1, (int64_t)act_n(Ho, cout), s));
+    float* d1b = alloc(act_n(Ho, cout));
+    rc = gn_bwd(c0, W(m.idx, "GroupNorm_1.weight"), W(m.idx, "GroupNorm_1.bias"), rs1, ms1, d1, d1b, DW(m.idx, "GroupNorm_1.weight"),
+                DW(m.idx, "GroupNorm_1.bias"), cout, Ho, act);
+    if (rc) return rc;
+    d1 = d1b;
+    {
+      float* dd = alloc((size_t)B * cout);
+      rc = sum_pixels(d1, dd, cout, Ho); if (rc) return rc;
+      TG_RUN(csd_sum_rows(dd, DW(m.idx, "Conv_0.bias"), B, cout, s));
+      rc = linear_bwd(st.temb2_act, CSD_ACT_NONE, W(m.idx, "Dense_0.weight"), dd, DW(m.idx, "Dense_0.weight"), DW(m.idx, "Dense_0.bias"), dtemb_act,
+                      4 * c.nf, cout);
+      if (rc) return rc;
+    }
+    rc = wgrad(op0, d1, DW(m.idx, "Conv_0.weight"), cin, cout, Ho, 3, 1, 0, 0, 3); if (rc) return rc;
+    float* d0 = alloc(act_n(Ho, cin));
+    rc = conv(d1, W(m.idx, "Conv_0.weight"), nullptr, d0, cout, cin, Ho, 3, 1, 0, 0, 3 | 4); if (rc) return rc;
+    if (resample) {                                  // through the FIR of the h branch: the other direction's geometry, flipped taps
+      float* d0l = alloc(act_n(H, cin));
+      rc = fir(d0, d0l, B, Ho, cin, m.up == 0, true); if (rc) return rc;
+      d0 = d0l;
+    }
+    const float* add = dout;                         // the identity shortcut's gradient
+    if (has_sc) {                                    // Conv_2 (1x1 OIHW) on the (resampled) block input
+      rc = wgrad(resample ? xr : h, dout, DW(m.idx, "Conv_2.weight"), cin, cout, Ho, 1, 1, 0, 0, 3); if (rc) return rc;
+      rc = bias_grad(dout, DW(m.idx, "Conv_2.bias"), cout, Ho); if (rc) return rc;
+      float* dsc = alloc(act_n(Ho, cin));
+      rc = conv(dout, W(m.idx, "Conv_2.weight"), nullptr, dsc, cout, cin, Ho, 1, 1, 0, 0, 3 | 4); if (rc) return rc;
+      if (resample) {
+        float* dscl = alloc(act_n(H, cin));
+        rc = fir(dsc, dscl, B, Ho, cin, m.up == 0, true); if (rc) return rc;
+        dsc = dscl;
+      }
+      add = dsc;
+    }
+    rc = gn_bwd(h, W(m.idx, "GroupNorm_0.weight"), W(m.idx, "GroupNorm_0.bias"), rs0, ms0, d0, dh, DW(m.idx, "GroupNorm_0.weight"),
+                DW(m.idx, "GroupNorm_0.bias"), cin, H, act, add);
+    if (rc) return rc;
+    top = mk;
+    return contribute(sp.in0, dh);
+  }
+
   int attn_bwd(const TStep& sp) {
     const Module& m = n.mods[sp.mod];
     const TT& tin = st.t[sp.in0];
@@ -527,6 +815,11 @@ struct TG {
     float* dh = alloc(act_n(H, C));
     const size_t mk = top;
     int rc;
+    if (skip_scale() != 1.f) {                       // AttnBlockpp: out = (x + h) / sqrt(2)
+      float* ds = alloc(act_n(H, C));
+      rc = scale_into(dout, ds, skip_scale(), act_n(H, C)); if (rc) return rc;
+      dout = ds;
+    }
     // NIN_3
     rc = wgrad(dout, a, DW(m.idx, "NIN_3.W"), C, C, H, 1, 1, 0, 0, 3); if (rc) return rc;
     rc = bias_grad(dout, DW(m.idx, "NIN_3.b"), C, H); if (rc) return rc;
@@ -598,7 +891,42 @@ struct TG {
           rc = contribute(sp.in0, dh); if (rc) return rc;
           break;
         }
-        case TS_RES: rc = res_bwd(sp, dtemb_act); if (rc) return rc; break;
+        case TS_RES: rc = (c.arch == 1 ? respp_bwd(sp, dtemb_act) : res_bwd(sp, dtemb_act)); if (rc) return rc; break;
+        case TS_COMBINE: {                           // out = Conv_0(pyramid) + h: the pyramid is data (no gradient), h's gradient is dout
+          const Module& m = n.mods[sp.mod];
+          const TT& to = st.t[sp.out];
+          const int cio = c.x_channels + c.y_channels;
+          rc = wgrad(sp.sv[0], to.g, DW(m.idx, "Conv_0.weight"), cio, m.cout, to.H, 1, 1, 0, 0, 2); if (rc) return rc;
+          rc = bias_grad(to.g, DW(m.idx, "Conv_0.bias"), m.cout, to.H); if (rc) return rc;
+          rc = contribute(sp.in0, to.g); if (rc) return rc;
+          break;
+        }
+        case TS_PYR: {                               // pyramid level: Conv(act(GroupNorm(h))) (+ FIR-up of the coarser level), NCHW
+          const Module& mg = n.mods[sp.mod];
+          const Module& mc = n.mods[sp.mod + 1];
+          const TT& tin = st.t[sp.in0];
+          const int H = tin.H, C = mg.cin, Co = c.x_channels + c.y_channels;
+          const float* dP = (sp.flag & 2) ? d_out : st.t[sp.out].g;
+          float* dh = alloc(act_n(H, C));
+          float* dprev = (sp.flag & 1) ? alloc((size_t)B * Co * (H / 2) * (H / 2)) : nullptr;
+          const size_t mk = top;
+          rc = wgrad(sp.sv[0], dP, DW(mc.idx, "weight"), C, Co, H, 3, 1, 0, 0, 1); if (rc) return rc;
+          {
+            float* bc = alloc((size_t)B * Co);
+            TG_RUN(csd_sum_inner(dP, bc, (int64_t)B * Co, (int64_t)H * H, s));
+            TG_RUN(csd_sum_rows(bc, DW(mc.idx, "bias"), B, Co, s));
+          }
+          float* dg = alloc(act_n(H, C));
+          rc = conv(dP, W(mc.idx, "weight"), nullptr, dg, Co, C, H, 3, 1, 0, 0, 2 | 4); if (rc) return rc;
+          rc = gn_bwd(tin.p, W(mg.idx, "weight"), W(mg.idx, "bias"), sp.sv[1], sp.sv[2], dg, dh, DW(mg.idx, "weight"), DW(mg.idx, "bias"), C,
+                      H, act);
+          if (rc) return rc;
+          if (dprev) { rc = fir(dP, dprev, B * Co, H, 1, false, true); if (rc) return rc; }      // d pyramid_upsample
+          top = mk;
+          rc = contribute(sp.in0, dh); if (rc) return rc;
+          if (dprev) st.t[sp.in1].g = dprev;         // (the coarser level's only consumer)
+          break;
+        }
         case TS_ATTN: rc = attn_bwd(sp); if (rc) return rc; break;
         case TS_CAT: {
           const TT& ta = st.t[sp.in0];
@@ -664,10 +992,13 @@ struct TG {
       TG_RUN(csd_act(st.temb2, dtemb_act, d2, act, (int64_t)B * 4 * nf, s));
       float* dact1 = alloc((size_t)B * 4 * nf);
       if (!dry) CSD_CHECK_HIP(hipMemsetAsync(dact1, 0, (size_t)B * 4 * nf * sizeof(float), s));
-      rc = linear_bwd(st.temb1, act, W(1, "weight"), d2, DW(1, "weight"), DW(1, "bias"), dact1, 4 * nf, 4 * nf); if (rc) return rc;
+      const int l0 = st.lin0, l1 = st.lin0 + 1;
+      rc = linear_bwd(st.temb1, act, W(l1, "weight"), d2, DW(l1, "weight"), DW(l1, "bias"), dact1, 4 * nf, 4 * nf); if (rc) return rc;
       float* d1 = alloc((size_t)B * 4 * nf);
       TG_RUN(csd_act(st.temb1, dact1, d1, act, (int64_t)B * 4 * nf, s));
-      rc = linear_bwd(st.emb, CSD_ACT_NONE, W(0, "weight"), d1, DW(0, "weight"), DW(0, "bias"), nullptr, nf, 4 * nf); if (rc) return rc;
+      rc = linear_bwd(st.emb, CSD_ACT_NONE, W(l0, "weight"), d1, DW(l0, "weight"), DW(l0, "bias"), nullptr, st.emb_dim, 4 * nf); if (rc) return rc;
+      if (st.fourier_mod >= 0 && !dry)               // the Fourier W is a fixed buffer of the reference (requires_grad = False): its slot reads zero
+        CSD_CHECK_HIP(hipMemsetAsync(DW(st.fourier_mod, "W"), 0, (size_t)nf * sizeof(float), s));
       top = mk;
     }
     return CSD_OK;
@@ -678,8 +1009,8 @@ struct TG {
 static int train_check(const csd_unet* net) {
   CSD_REQUIRE(net, "train: null handle");
   const csd_unet_config& c = net->net.cfg;
-  CSD_REQUIRE(c.arch == 0, "train graph: only the DDPM family (arch 0) has a planned training graph; NCSN++ trains on the differentiable operators");
-  CSD_REQUIRE(c.resamp_with_conv, "train graph: resamp_with_conv = False is not provided");
+  CSD_REQUIRE(c.arch == 0 || c.arch == 1, "train graph: arch %d has no planned training graph", c.arch);
+  if (c.arch == 0) CSD_REQUIRE(c.resamp_with_conv, "train graph: resamp_with_conv = False is not provided");
   CSD_REQUIRE((c.x_channels + c.y_channels) >= 1, "train graph: no input channels");
   return CSD_OK;
 }

@@ -447,8 +447,12 @@ class HipNCSNpp(HipUNet):
             cfg.fir_kernel[i] = float(v)
 
     def _train_forward(self, x, y, labels):
-        """training mode under autograd: the operator-granular NCSN++ (class NCSNpp above, differentiable HIP operators) on
+        """training mode under autograd.  ``train_executor == 'planned'`` (default): ONE autograd node over csd_unet_train_forward /
+        csd_unet_backward (csrc/train_graph.h, arch 1: BigGAN blocks with FIR resampling, Combine, pyramids - every parameter
+        gradient from one call).  ``'operators'``: the operator-granular NCSN++ (class NCSNpp above, differentiable HIP operators) on
         THIS model's parameters - a twin whose nn.Parameters are the same objects, so gradients land in ``self.parameters()``."""
+        if self.train_executor == 'planned':
+            return self._train_forward_planned(x, y, labels)
         twin = self.__dict__.get('_twin')
         if twin is None:
             twin = NCSNpp(self._config, precision=self.precision)

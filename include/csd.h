@@ -394,7 +394,8 @@ int csd_attention_backward_nhwc(const float* qkv, const float* dout, float* dqkv
  * One backward per forward, same handle / workspace / B / call_index; the workspace must not be touched in between: a second
  * forward into the same workspace before the backward makes that backward fail with CSD_ERR_STATE (it names the first forward's
  * call_index) - two forwards of one network may be alive at once when each has its own workspace.
- * csd_unet_train_workspace_bytes depends on B and on whether dropout_p > 0. arch 0 only (NCSN++ trains per operator).
+ * csd_unet_train_workspace_bytes depends on B and on whether dropout_p > 0.  Both architectures: arch 0 (models/ddpm.py:149-213) and
+ * arch 1 (NCSN++, models/ncsnpp.py:238-388: BigGAN blocks with FIR up / down sampling, Combine 'sum', input / output pyramids).
  * ---------------------------------------------------------------------------------------- */
 size_t csd_unet_train_workspace_bytes(csd_unet* net, int B, float dropout_p);
 int csd_unet_train_forward(csd_unet* net, const float* const* params, void* workspace, size_t workspace_bytes, const float* x,

@@ -197,11 +197,14 @@ def test_full_size_ncsnpp_160_vs_oracle(precision, tol):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('executor', ['planned', 'operators'])
 @pytest.mark.parametrize('case', list(cases.NCSNPP_CASES))
-def test_training_mode_gradients_vs_oracle_autograd(case):
-    """model.train() + autograd: the NCSN++ forward runs on the differentiable HIP operators (FIR resampling backward =
-    upfirdn2d with the flipped kernel, BigGAN blocks, Combine, pyramid) and d(sum(out * w))/d(parameters) matches torch autograd
-    over the oracle's restatement (pinned to the reference's forward by tests/test_oracle_golden.py)."""
+def test_training_mode_gradients_vs_oracle_autograd(case, executor):
+    """model.train() + autograd: EVERY parameter gradient of the NCSN++ configs against torch autograd over the oracle's restatement
+    (pinned to the reference's forward by tests/test_oracle_golden.py).  'planned': the whole forward / backward behind
+    csd_unet_train_forward / csd_unet_backward (csrc/train_graph.h arch 1: BigGAN blocks with FIR up / down sampling and their
+    transposes, Conv_2, (x + h) / sqrt(2), AttnBlockpp, Combine, input / output pyramids, Fourier / positional embedding);
+    'operators': autograd over the differentiable HIP operators (FIR backward = upfirdn2d with the flipped kernel)."""
     import score_oracle as so
     from conditional_score_diffusion_amd.models import utils as mutils
     cfg, B, x, labels = cases.ncsnpp_case(case)
@@ -212,6 +215,9 @@ def test_training_mode_gradients_vs_oracle_autograd(case):
     params = cases.ncsnpp_params(shapes, 5)
     model.load_state_dict(params)
     model = model.to(dev).train()
+    if executor == 'planned' and not hasattr(model, '_train_forward_planned'):
+        pytest.skip("progressive_input = 'residual' runs on the operator-granular class only")
+    model.train_executor = executor
     w = torch.from_numpy(np.random.RandomState(2).standard_normal(tuple(x.shape[:1]) + (cfg.data.num_channels,) + tuple(x.shape[2:]))
                          .astype(np.float32))
     xd, ld = x.to(dev), labels.to(dev)
@@ -221,6 +227,8 @@ def test_training_mode_gradients_vs_oracle_autograd(case):
     else:
         out = model(xd, ld)
     assert out.requires_grad
+    # the planned executor is ONE autograd node on the library's training workspace; the operator path never allocates it
+    assert (getattr(model, '_train_ws', None) is not None) == (executor == 'planned')
     (out * w.to(dev)).sum().backward()
     p = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in params.items()}
     ref = so.ncsnpp_forward(p, cfg, x, labels)
