@@ -421,6 +421,13 @@ def main():
                 j = json.loads(r.stdout.strip().splitlines()[-1])
                 res['training_side_bench']['per_gpu_batch_7_of_8way_dp'] = {'steps_per_sec': j['value'], 'ms_per_step': j['ms_per_step'],
                                                                             'images_per_sec': j['images_per_sec']}
+                # the same step on the architecture north_star names (ncsnpp_paired, planned training graph, csrc/train_graph.h arch 1)
+                r = subprocess.run([sys.executable, tool, '--precision', 'fp16x3', '--steps', '10', '--warmup', '3', '--model', 'ncsnpp_paired'],
+                                   capture_output=True, text=True, timeout=600)
+                j = json.loads(r.stdout.strip().splitlines()[-1])
+                res['training_side_bench']['ncsnpp_paired_same_shape'] = {'steps_per_sec': j['value'], 'ms_per_step': j['ms_per_step'],
+                                                                          'images_per_sec': j['images_per_sec'], 'params': j['params'],
+                                                                          'executor': j['executor']}
             except Exception as e:
                 res['training_side_bench'] = {'error': str(e)[:200]}
             # BASELINE configs[2] (CMDE inpainting 128x128, two SDEs) and the architecture north_star names (NCSN++ with the SR3-160

@@ -41,8 +41,24 @@ def make_config(precision):
     return c
 
 
+def make_ncsnpp_config(precision):
+    """the same work shape on the architecture north_star names: ncsnpp_paired (BigGAN blocks, FIR resampling, input / output skips,
+    skip_rescale) with the configs[3] hyper-parameters (64 x 64, nf = 128, ch_mult (1, 1, 2, 2), attention at 16, dropout 0.1)"""
+    c = make_config(precision)
+    m = c.model
+    m.name = 'ncsnpp_paired'
+    m.attn_resolutions = (16,)
+    for k, v in dict(fir=True, fir_kernel=[1, 3, 3, 1], skip_rescale=True, resblock_type='biggan', progressive='output_skip',
+                     progressive_input='input_skip', progressive_combine='sum', attention_type='ddpm', init_scale=0.,
+                     fourier_scale=16, conv_size=3, sigma_min=5e-3, sigma_max=m.sigma_max_x).items():
+        setattr(m, k, v)
+    return c
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--model', default='ddpm_paired', choices=['ddpm_paired', 'ncsnpp_paired'])
+    ap.add_argument('--executor', default=None, choices=['planned', 'operators'], help='training executor (default: the model\'s = planned)')
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=50, help='global batch')
@@ -57,7 +73,10 @@ def main():
     if grouped:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-    cfg = make_config(a.precision)
+    if a.executor:
+        os.environ['CSD_TRAIN_EXECUTOR'] = a.executor
+    cfg = make_config(a.precision) if a.model == 'ddpm_paired' else make_ncsnpp_config(a.precision)
+    import conditional_score_diffusion_amd.models.ncsnpp  # noqa: F401
     torch.manual_seed(0)
     model = mutils.create_model(cfg).to(dev)
     m = cfg.model
@@ -91,7 +110,8 @@ def main():
     dt = float(dt)
     if rank == 0:
         sps = a.steps / dt
-        print(json.dumps({'metric': 'training steps/sec, VS-CMDE edges2shoes 64x64 (ddpm_paired nf=128), fwd+bwd+all-reduce+Adam/EMA',
+        print(json.dumps({'metric': 'training steps/sec, VS-CMDE edges2shoes 64x64 (%s nf=128), fwd+bwd+all-reduce+Adam/EMA' % a.model,
+                          'executor': getattr(model, 'train_executor', None),
                           'value': sps, 'unit': 'steps/sec', 'images_per_sec': sps * a.batch, 'n_gpus': world,
                           'global_batch': a.batch, 'rank0_batch': B, 'ms_per_step': 1e3 * dt / a.steps, 'steps': a.steps, 'warmup': a.warmup,
                           'precision': a.precision, 'params': tr.flat.numel, 'loss': float(loss),
