@@ -71,6 +71,6 @@ struct FFCfg {
 int convfx_launch(const ConvFFArgs& k, int nt, hipStream_t s);
 // conv_xp.hip: the fp16x3 form as one software-pipelined stream per SIMD (one 4-wave workgroup per CU, persistent)
 bool convxp_supported(const ConvFFArgs& k, int nt);
-int convxp_launch(const ConvFFArgs& k, hipStream_t s);
+int convxp_launch(const ConvFFArgs& k, int nt, hipStream_t s);
 
 }  // namespace csd

@@ -639,7 +639,7 @@ int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
   // the MFMA chains of ONE instruction stream per SIMD).  Tuning build: CSD_XP=0 disables it.
   {
     const char* xp = CSD_TUNE_ENV("CSD_XP");
-    if (ns == 2 && convxp_supported(k, nt) && !(xp && atoi(xp) == 0)) return convxp_launch(k, s);
+    if (ns == 2 && convxp_supported(k, nt) && !(xp && atoi(xp) == 0)) return convxp_launch(k, nt, s);
   }
   const bool norm = a.nscale != nullptr;
 #define FF_DISPATCH(NT_)                                                                                            \

@@ -26,12 +26,16 @@ namespace csd {
 
 #define XP_THREADS 256
 
+template <int NT_>
 struct XPCfg {
-  static constexpr int NT = 3;                               // 32-cout tiles per workgroup (96 couts)
+  static constexpr int NT = NT_;                             // 32-cout tiles per workgroup (3: 96 couts, 2: 64 couts)
   static constexpr int TAPB = NT * 2 * 1024;                 // weight bytes per tap: NT cout tiles x (hi | lo) fragments
-  static constexpr int STB = 9 * TAPB;                       // per stage (55296)
-  static constexpr int PIECES = STB / 1024;                  // 1 KiB pieces per stage (54)
-  static constexpr int WPW = (PIECES + 3) / 4;               // pieces per wave (14; the last two waves repeat piece 53)
+  static constexpr int STB = 9 * TAPB;                       // per stage (55296 | 36864)
+  static constexpr int PIECES = STB / 1024;                  // 1 KiB pieces per stage (54 | 36)
+  static constexpr int WPW = (PIECES + 3) / 4;               // pieces per wave (14, the last two waves repeat piece 53 | 9)
+  static constexpr int WH0 = (WPW + 1) / 2, WH1 = WPW - WH0; // ... fetched in two halves (7 + 7 | 5 + 4)
+  static constexpr int GP = 6 * NT;                          // MFMAs (= filler gaps) per tap: 3 products x 2 M tiles x NT
+  static constexpr int NF = 4 + 2 * NT;                      // fragment reads per tap
   static constexpr int NSLOT = 6;                            // float4 conversion slots per thread and stage (1296 real slots of 1536)
   static constexpr int OFF_W = 2 * FF_PATCH_BYTES;
   static constexpr int OFF_RED = OFF_W + 2 * STB;
@@ -68,12 +72,12 @@ __device__ __forceinline__ float xp_lo(int hp, float v) {      // v - (float)hal
 #define XP_WALL(i) do { } while (0)
 #endif
 
-template <bool NORM, bool RES>
+template <int NT_, bool NORM, bool RES>
 __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __restrict__ g_wpack, const ConvFFArgs k) {
-  using C = XPCfg;
+  using C = XPCfg<NT_>;
   constexpr int NT = C::NT, TAPB = C::TAPB, STB = C::STB, PIECES = C::PIECES, WPW = C::WPW, NSLOT = C::NSLOT;
   constexpr int OFF_W = C::OFF_W, OFF_RED = C::OFF_RED;
-  constexpr int WH = WPW / 2;                        // weight pieces per half stage and wave (7)
+  constexpr int WH0 = C::WH0, WH1 = C::WH1, GP = C::GP, NF = C::NF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const float* const a_src0 = k.a.src0;
@@ -200,23 +204,24 @@ __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __re
   // 53), in two halves of 7; the scalar offset runs (asm add: hipcc would otherwise precompute 14 offsets per stage ahead of the stream)
   const __amdgpu_buffer_rsrc_t w_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g_wpack), 0, OOB, RSRC_FLAGS);
   const int wvoff = lane * 16 + wave * 1024;
-  const int w13 = wave < 2 ? 13 * 4096 : (PIECES - 1 - wave) * 1024;      // offset of the wave's last piece relative to the stage
-  xp_u4 wr[WH];
+  // offset of the wave's last piece relative to the stage (past the end: the stage's last piece again)
+  const int w_last = (((WPW - 1) * 4 + wave < PIECES ? (WPW - 1) * 4 + wave : PIECES - 1) - wave) * 1024;
+  xp_u4 wr[WH0];
   int w_run = 0, w_base = 0;
   const int c4096 = 4096;
   auto w_begin = [&](int wso) __attribute__((always_inline)) { w_base = wso; w_run = wso; };
-  auto req_w = [&](int q) __attribute__((always_inline)) {      // q: 0 .. 13, in order
+  auto req_w = [&](int q) __attribute__((always_inline)) {      // q: 0 .. WPW - 1, in order
     if (XP_ABL & 2) return;
-    if (q < 13) {
-      wr[q % WH] = __builtin_amdgcn_raw_buffer_load_b128(w_r, (unsigned)wvoff, w_run, 0);
+    if (q < WPW - 1) {
+      wr[q < WH0 ? q : q - WH0] = __builtin_amdgcn_raw_buffer_load_b128(w_r, (unsigned)wvoff, w_run, 0);
       XP_SADD(w_run, c4096);
     } else {
-      wr[q % WH] = __builtin_amdgcn_raw_buffer_load_b128(w_r, (unsigned)wvoff, w_base + w13, 0);
+      wr[q - WH0] = __builtin_amdgcn_raw_buffer_load_b128(w_r, (unsigned)wvoff, w_base + w_last, 0);
     }
   };
   auto put_w = [&](int q, int par) __attribute__((always_inline)) {
     if (XP_ABL & 2) return;
-    *reinterpret_cast<xp_u4*>(smem + OFF_W + par * STB + (q < 13 ? q * 4096 : w13) + wvoff) = wr[q % WH];
+    *reinterpret_cast<xp_u4*>(smem + OFF_W + par * STB + (q < WPW - 1 ? q * 4096 : w_last) + wvoff) = wr[q < WH0 ? q : q - WH0];
   };
 
   // ---- conversion of slot j into patch buffer `par`, in five pieces that sit between MFMA chains ----
@@ -272,25 +277,18 @@ __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __re
 
   // ---- fragments ----
   half8 xh[2][2], xl[2][2], wh[2][NT], wl[2][NT];    // [register buffer][M tile | cout tile]
-  // one fragment per call, in the order the next tap's MFMAs need them: xh0 wl0 wl1 wl2 xh1 | xl0 wh0 wh1 wh2 xl1
+  // one fragment per call (NF per tap): xh0 wl0 .. wl(NT-1) xh1 | xl0 wh0 .. wh(NT-1) xl1
   auto rd_frag = [&](int buf, int par, int tap, int which) __attribute__((always_inline)) {
     if (XP_ABL & 4) return;
     const int r = tap / 3, sx = tap - r * 3;
     const char* const pb = smem + par * FF_PATCH_BYTES + r * FF_RS + sx * FF_PSB;
     const char* const wb = smem + wbase + par * STB + tap * TAPB;
-    switch (which) {
-      case 0: xh[buf][0] = *reinterpret_cast<const half8*>(pb + xbase[0]); break;
-      case 1: wl[buf][0] = *reinterpret_cast<const half8*>(wb + 1024); break;
-      case 2: wl[buf][1] = *reinterpret_cast<const half8*>(wb + 3072); break;
-      case 3: wl[buf][2] = *reinterpret_cast<const half8*>(wb + 5120); break;
-      case 4: xh[buf][1] = *reinterpret_cast<const half8*>(pb + xbase[1]); break;
-      case 5: xl[buf][0] = *reinterpret_cast<const half8*>(pb + xbase[0] + 32); break;
-      case 6: wh[buf][0] = *reinterpret_cast<const half8*>(wb); break;
-      case 7: wh[buf][1] = *reinterpret_cast<const half8*>(wb + 2048); break;
-      case 8: wh[buf][2] = *reinterpret_cast<const half8*>(wb + 4096); break;
-      case 9: xl[buf][1] = *reinterpret_cast<const half8*>(pb + xbase[1] + 32); break;
-      default: break;
-    }
+    if (which == 0) xh[buf][0] = *reinterpret_cast<const half8*>(pb + xbase[0]);
+    else if (which <= NT) wl[buf][which - 1] = *reinterpret_cast<const half8*>(wb + (which - 1) * 2048 + 1024);
+    else if (which == NT + 1) xh[buf][1] = *reinterpret_cast<const half8*>(pb + xbase[1]);
+    else if (which == NT + 2) xl[buf][0] = *reinterpret_cast<const half8*>(pb + xbase[0] + 32);
+    else if (which <= 2 * NT + 2) wh[buf][which - NT - 3] = *reinterpret_cast<const half8*>(wb + (which - NT - 3) * 2048);
+    else if (which == 2 * NT + 3) xl[buf][1] = *reinterpret_cast<const half8*>(pb + xbase[1] + 32);
   };
 
   // The accumulators live in the accumulator half of the register file for the whole kernel ("+a"); the matrix instructions are asm
@@ -308,7 +306,6 @@ __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __re
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, 0" : "=a"(acc[mt][nt]) : "v"(z));
   };
-  zero_acc();
   // One MFMA per statement, round robin over the six accumulators: product p of a tap (0: hi * lo, 1: lo * hi, 2: hi * hi - small terms
   // first) for all six, then the next product.  Consecutive MFMAs are independent, so the wave is free to issue the gap's fillers while
   // the matrix pipe works (tools/xp_order_probe.hip: ~80 fillers per tap ride for +5 % here; with three dependent MFMAs back to back
@@ -319,6 +316,25 @@ __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __re
     if (p == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(xh[buf][mt]), "v"(wl[buf][nt]));
     else if (p == 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(xl[buf][mt]), "v"(wh[buf][nt]));
     else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(xh[buf][mt]), "v"(wh[buf][nt]));
+  };
+
+  // hipcc does not know that the asm statements are matrix instructions, and the hardware does not interlock a matrix write against a
+  // vector read of the same register (11 wait states for the 8-pass 32x32x16).  Two consequences:
+  //  * the epilogue's reads of the accumulators sit behind tie_acc_done(), a wait tied to every accumulator so that no read can move
+  //    above it;
+  //  * hipcc must never move an accumulator itself.  It did: with the accumulators live across the loop's back edge (and across a
+  //    conditional head of unit 0) the two sides of the join held them in different registers, and the 16 v_accvgpr_mov per
+  //    accumulator landed directly behind / in front of matrix instructions - reading an accumulator before its last update had
+  //    landed (seen as wrong first elements of one accumulator with 64-cout groups) and costing ~200 vector instructions per tile.
+  //    Hence the loop structure below: no accumulator is live across any control-flow edge except the stage-pair loop's, where both
+  //    sides are the same code.  tools/check_xp_isa.py (run by the build) fails if anything but a matrix instruction or a read behind
+  //    tie_acc_done() touches an accumulator register.
+  auto tie_acc_done = [&]() __attribute__((always_inline)) {
+    if constexpr (NT == 3)
+      asm volatile("s_nop 15\n\ts_nop 7"
+                   : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]));
+    else
+      asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));
   };
 
   // ---- epilogue operands of a tile (requested while its last stage is multiplied, used after that stage's last tap) ----
@@ -364,20 +380,17 @@ __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __re
       tv[nt] = a_temb ? a_temb[(size_t)t.b * a_temb_stride + c_lane + nt * 32] : 0.f;
     }
   };
-  auto req_res = [&](int e) __attribute__((always_inline)) {      // e = (mt * 16 + r) * 3 + nt
+  auto req_res = [&](int e) __attribute__((always_inline)) {      // e = (mt * 16 + r) * NT + nt
     if constexpr (RES) {
       if (XP_ABL & 32) return;
-      const int idx = e / 3, nt = e - idx * 3;
+      const int idx = e / NT, nt = e - idx * NT;
       rs[idx / 16][nt][idx % 16] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(res_r, res_voff + nt * 128, res_run, 0));
-      if (nt == 2 && idx < 31) e_advance(res_run, idx, st_res);
+      if (nt == NT - 1 && idx < 31) e_advance(res_run, idx, st_res);
     }
   };
   float* const red = reinterpret_cast<float*>(smem + OFF_RED);      // [4 waves][NT*32 couts][2]: statistics hand-over
   auto epilogue = [&]() __attribute__((always_inline)) {
-    // (hipcc does not know the asm statements are MFMAs: without this their results would be read a few cycles after issue; the
-    // operands tie every accumulator to the statement so that no read can move above it)
-    asm volatile("s_nop 15\n\ts_nop 7"
-                 : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]));
+    tie_acc_done();
     XP_TS(22);
     float vs[NT], vq[NT];
 #pragma unroll
@@ -398,7 +411,6 @@ __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __re
       }
       if (idx < 31) e_advance(out_run, idx, st_out);
     }
-    zero_acc();
     XP_TS(23);
     if (a_stats) {
 #pragma unroll
@@ -447,16 +459,17 @@ __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __re
       req_slot(j, gc);
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int q = 0; q < WH0; ++q) req_w(q);
 #pragma unroll
-      for (int q = 0; q < WH; ++q) req_w(h * WH + q);
+    for (int q = 0; q < WH0; ++q) put_w(q, 0);
 #pragma unroll
-      for (int q = 0; q < WH; ++q) put_w(h * WH + q, 0);
-    }
+    for (int q = WH0; q < WPW; ++q) req_w(q);
+#pragma unroll
+    for (int q = WH0; q < WPW; ++q) put_w(q, 0);
   }
   ff_barrier();
 #pragma unroll
-  for (int wch = 0; wch < 10; ++wch) rd_frag(0, 0, 0, wch);
+  for (int wch = 0; wch < NF; ++wch) rd_frag(0, 0, 0, wch);
 
   // =========================================================================================================================
   // One unit = [barrier | tap 8 of the PREVIOUS stage | (first unit of a tile: the previous tile's epilogue) | taps 0 .. 7 of stage s].
@@ -471,9 +484,10 @@ __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __re
   // fragment register buffer of tap 0 alternates from stage to stage.  FIRST: stage 0 of a tile.
   // =========================================================================================================================
   int par = 0;                                       // buffer parity of the stage whose taps 0 .. 7 run (or ran last)
-  auto unit = [&](auto flip_tag, auto pos_tag, auto first_tag, int s, bool head) __attribute__((always_inline)) {
-    constexpr int FLIP = decltype(flip_tag)::value, POS = decltype(pos_tag)::value;
+  auto unit = [&](auto flip_tag, auto pos_tag, auto first_tag, auto part_tag, int s) __attribute__((always_inline)) {
+    constexpr int FLIP = decltype(flip_tag)::value, POS = decltype(pos_tag)::value, PART = decltype(part_tag)::value;
     constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr bool HEAD = PART == 0 || PART == 2, BODY = PART == 0 || PART == 1;      // (PART 3: the set-up pieces alone)
     const Tile& tx = POS == 2 ? tn : tc;             // tile of stage X
     const Tile& tl = POS >= 1 ? tn : tc;             // tile of stage L
     const Geom& gx = POS == 2 ? gn : gc;
@@ -487,7 +501,11 @@ __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __re
       else if (g == 4) w_begin((tx.ng * (Cin / 16) + sx) * STB);
       else if (g == 5) { if constexpr (POS == 1) epi_setup(tc); }
     };
-    if (!FIRST || head) {
+    if constexpr (PART == 3) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) setup(g);
+    }
+    if constexpr (HEAD) {
       par ^= 1;
       XP_FENCE();
       if (s == 2) XP_TS(20);
@@ -496,47 +514,60 @@ __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __re
       XP_FENCE();
       constexpr int buf = 1 - FLIP;                  // (= (8 + the previous stage's FLIP) & 1)
 #pragma unroll
-      for (int g = 0; g < 18; ++g) {
+      for (int g = 0; g < GP; ++g) {
         XP_FENCE();
-        mm(buf, g / 6, g % 6);
+        mm(buf, g / (2 * NT), g % (2 * NT));
         XP_FENCE();
-        if (g < 10) rd_frag(buf ^ 1, par, 0, g);
-        else setup(g - 10);
+        if (g < NF) rd_frag(buf ^ 1, par, 0, g);
+        else {                                       // the six set-up pieces over the remaining gaps (at most two per gap)
+          constexpr int R = GP - NF;
+          const int q0 = (6 * (g - NF) + R - 1) / R, q1 = (6 * (g - NF + 1) + R - 1) / R;
+          if (q0 < q1) setup(q0);
+          if (q0 + 1 < q1) setup(q0 + 1);
+        }
       }
       XP_FENCE();
       if constexpr (FIRST) epilogue();
-    } else {
-#pragma unroll
-      for (int g = 0; g < 8; ++g) setup(g);
     }
+    if constexpr (!BODY) return;
     XP_TS(0 + s);
     const int npar = par ^ 1;
 #pragma unroll
     for (int tap = 0; tap < 8; ++tap) {
       const int buf = (tap + FLIP) & 1;
 #pragma unroll
-      for (int g = 0; g < 18; ++g) {
+      for (int g = 0; g < GP; ++g) {
         XP_FENCE();
-        mm(buf, g / 6, g % 6);
+        mm(buf, g / (2 * NT), g % (2 * NT));
         XP_FENCE();
         // ---- fillers of gap (tap, g) ----
-        if (g < 10) rd_frag(buf ^ 1, par, tap + 1, g);
-        if (tap >= 1 && tap <= 6) {                  // conversion of slot tap - 1 (stage X), then the request of the same slot for stage L
-          if (g < 16) cvt_step(tap - 1, g, npar, gx.msk[tap - 1]);
-          else if (g == 16) req_slot(tap - 1, gl);
+        if (g < NF) rd_frag(buf ^ 1, par, tap + 1, g);
+        if (tap >= 1 && tap <= 6) {
+          // conversion of slot tap - 1 (stage X) in 16 micro-steps, then the request of the same slot for stage L as step 16.
+          // NT = 3: one step per gap.  NT = 2: step q in gap q * GP / 17 (at most two per gap).  (Two spellings on purpose: with the
+          // general one hipcc leaves the NT = 3 residual registers in scratch memory.)
+          if constexpr (NT == 3) {
+            if (g < 16) cvt_step(tap - 1, g, npar, gx.msk[tap - 1]);
+            else if (g == 16) req_slot(tap - 1, gl);
+          } else {
+            const int q0 = (17 * g + GP - 1) / GP, q1 = (17 * (g + 1) + GP - 1) / GP;
+            if (q0 < q1 && q0 < 16) cvt_step(tap - 1, q0, npar, gx.msk[tap - 1]);
+            if (q0 + 1 < q1 && q0 + 1 < 16) cvt_step(tap - 1, q0 + 1, npar, gx.msk[tap - 1]);
+            if (q0 <= 16 && 16 < q1) req_slot(tap - 1, gl);
+          }
         }
         // stage X's weights: first half requested in tap 0, stored in tap 3; second half requested in tap 4, stored in tap 7
-        if (tap == 0 && g >= 10 && g < 10 + WH) req_w(g - 10);
-        if (tap == 4 && (g & 1) == 0 && g < 2 * WH) req_w(WH + g / 2);
-        if (tap == 3 && (g & 1) == 1 && g < 2 * WH) put_w(g / 2, npar);
-        if (tap == 7 && g < WH) put_w(WH + g, npar);
-        // 96 residual requests over the tile's last two units, in taps 1-2 and 5-6 only (two of every three gaps).  The memory counter
+        if (tap == 0 && g >= GP - 1 - WH0 && g < GP - 1) req_w(g - (GP - 1 - WH0));
+        if (tap == 4 && (g & 1) == 0 && g / 2 < WH1) req_w(WH0 + g / 2);
+        if (tap == 3 && (g & 1) == 1 && g / 2 < WH0) put_w(g / 2, npar);
+        if (tap == 7 && g < WH1) put_w(WH0 + g, npar);
+        // 32 NT residual requests over the tile's last two units, in taps 1-2 and 5-6 only (two of every three gaps).  The memory counter
         // retires in order: a weight piece (an L2 hit, stored to LDS three taps after its request) cannot retire before an OLDER request
         // that went to HBM - so no slow request may be issued in the ~3 taps in front of a weight request (taps 0 and 4).
         if constexpr (POS >= 1) {
           if ((tap == 1 || tap == 2 || tap == 5 || tap == 6) && g % 3 != 0) {
             const int w = (tap == 1 ? 0 : tap == 2 ? 1 : tap == 5 ? 2 : 3);
-            req_res((POS - 1) * 48 + w * 12 + (g / 3) * 2 + (g % 3 - 1));
+            req_res((POS - 1) * 16 * NT + w * 4 * NT + (g / 3) * 2 + (g % 3 - 1));
           }
         }
       }
@@ -548,12 +579,20 @@ __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __re
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
   using P2 = std::integral_constant<int, 2>;
+  using Whole = std::integral_constant<int, 0>;     // parts of a unit: head + taps, the taps alone, the head alone, the set-up alone
+  using Taps = std::integral_constant<int, 1>;
+  using Head = std::integral_constant<int, 2>;
+  using SetUp = std::integral_constant<int, 3>;
   using Yes = std::true_type;
   using No = std::false_type;
 
   // =========================================================================================================================
-  // persistent loop (NS even, >= 4): stage pairs, the first and the last pair of a tile peeled
+  // persistent loop (NS even, >= 4): stage pairs, the first and the last pair of a tile peeled.  Unit 0 of a tile is cut in two: its
+  // taps open the iteration, and the iteration closes with the head of the NEXT tile's unit 0 (= this tile's last tap, under which the
+  // next tile's first fragments are read, and this tile's epilogue).  The back edge therefore sits where no accumulator is live -
+  // they are zeroed at the top - and the last iteration needs no special tail (its "next tile" is the last tile again: harmless reads).
   // =========================================================================================================================
+  unit(F0{}, P0{}, Yes{}, SetUp{}, 0);
   for (int it = 0; it < n_my; ++it) {
 #ifdef CSD_FF_TUNE
     ts_on = it == 1;
@@ -562,51 +601,46 @@ __global__ __launch_bounds__(XP_THREADS, 1) void conv_xp_kernel(const char* __re
     if (it == 1 && a_dbg && tid == 0) a_dbg[blockIdx.x * 32 + 26] = clock64();
     if (it == 2 && a_dbg && tid == 0) a_dbg[blockIdx.x * 32 + 27] = clock64();
 #endif
-    unit(F0{}, P0{}, Yes{}, 0, it > 0);
-    unit(F1{}, P0{}, No{}, 1, true);
+    zero_acc();
+    unit(F0{}, P0{}, Yes{}, Taps{}, 0);
+    unit(F1{}, P0{}, No{}, Whole{}, 1);
     for (int s = 2; s + 2 < NS; s += 2) {
-      unit(F0{}, P0{}, No{}, s, true);
-      unit(F1{}, P0{}, No{}, s + 1, true);
+      unit(F0{}, P0{}, No{}, Whole{}, s);
+      unit(F1{}, P0{}, No{}, Whole{}, s + 1);
     }
     gn = geom_of(tn);
-    unit(F0{}, P1{}, No{}, NS - 2, true);
-    unit(F1{}, P2{}, No{}, NS - 1, true);
+    unit(F0{}, P1{}, No{}, Whole{}, NS - 2);
+    unit(F1{}, P2{}, No{}, Whole{}, NS - 1);
     XP_TS(0 + NS);
     tc = tn;
     gc = gn;
     tn = tile_at(it + 2);
-  }
-  // the last tile's last tap and epilogue
-  {
-#pragma unroll
-    for (int g = 0; g < 18; ++g) {
-      XP_FENCE();
-      mm(1, g / 6, g % 6);                           // (the last stage of a tile has FLIP = 1: its tap 8 sits in fragment buffer (8 + 1) & 1)
-      XP_FENCE();
-    }
-    epilogue();
+    unit(F0{}, P0{}, Yes{}, Head{}, 0);
   }
   XP_WALL(31);
 }
 
-template <bool NORM, bool RES>
+template <int NT, bool NORM, bool RES>
 static int launch_xp(const ConvFFArgs& k, hipStream_t s) {
-  auto kern = conv_xp_kernel<NORM, RES>;
+  auto kern = conv_xp_kernel<NT, NORM, RES>;
   CSD_SET_MAX_LDS_ONCE(kern);
   const int n_cu = device_cu_count8();               // persistent: one workgroup per CU, a multiple of the 8 XCDs
   const int grid = k.nblocks < n_cu ? (k.nblocks + 7) / 8 * 8 : n_cu;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(XP_THREADS), XPCfg::LDS, s, reinterpret_cast<const char*>(k.a.wpack), k);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(XP_THREADS), XPCfg<NT>::LDS, s, reinterpret_cast<const char*>(k.a.wpack), k);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
 
-// the fp16x3 (ns = 2) layers conv_ff covers with 96-cout groups and >= 2 stages; same packed weights, same arguments
-bool convxp_supported(const ConvFFArgs& k, int nt) { return nt == 3 && k.nstage >= 4 && k.nstage % 2 == 0; }
+// the fp16x3 (ns = 2) layers conv_ff covers (96- or 64-cout groups) with an even number >= 4 of stages; same packed weights, same arguments
+bool convxp_supported(const ConvFFArgs& k, int nt) { return (nt == 3 || nt == 2) && k.nstage >= 4 && k.nstage % 2 == 0; }
 
-int convxp_launch(const ConvFFArgs& k, hipStream_t s) {
+template <int NT>
+static int launch_xp_nt(const ConvFFArgs& k, hipStream_t s) {
   const bool norm = k.a.nscale != nullptr, res = k.a.res != nullptr;
-  if (norm) return res ? launch_xp<true, true>(k, s) : launch_xp<true, false>(k, s);
-  return res ? launch_xp<false, true>(k, s) : launch_xp<false, false>(k, s);
+  if (norm) return res ? launch_xp<NT, true, true>(k, s) : launch_xp<NT, true, false>(k, s);
+  return res ? launch_xp<NT, false, true>(k, s) : launch_xp<NT, false, false>(k, s);
 }
+
+int convxp_launch(const ConvFFArgs& k, int nt, hipStream_t s) { return nt == 3 ? launch_xp_nt<3>(k, s) : launch_xp_nt<2>(k, s); }
 
 }  // namespace csd

@@ -15,6 +15,8 @@ SHAPES = [  # B, C0, C1, Cout, H, residual
     (64, 96, 0, 96, 80, True),
     (64, 192, 96, 96, 80, False),
     (64, 192, 0, 192, 80, True),
+    (64, 128, 0, 128, 64, True),       # 6, 7: nf = 128 networks (64-cout groups)
+    (64, 256, 128, 128, 64, False),
 ]
 
 

@@ -44,3 +44,7 @@ run(1, 96, 0, 96, 32, 32, True, False, '4 tiles norm')
 run(2, 96, 96, 96, 16, 48, True, True, 'concat')
 run(1, 64, 32, 192, 32, 16, True, True, '2 groups')
 run(8, 96, 0, 96, 160, 160, True, True, 'big')
+run(1, 64, 0, 64, 16, 16, False, False, 'nt2 1 tile raw')
+run(1, 64, 0, 64, 16, 16, True, False, 'nt2 1 tile norm')
+run(1, 128, 0, 128, 16, 16, True, False, 'nt2 2 groups')
+run(2, 128, 0, 128, 32, 32, True, True, 'nt2 tiles res')
