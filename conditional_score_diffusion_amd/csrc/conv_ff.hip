@@ -512,6 +512,11 @@ bool convff_supported(const ConvPlan& p, int ns) {
          p.IH == p.OH && p.IW == p.OW;
 }
 
+bool convff_pipelined(const ConvPlan& p, int ns) {
+  const int nstage = (p.C0 + p.C1) / 16;
+  return ns == 2 && convff_supported(p, ns) && nstage >= 4 && nstage % 2 == 0 && !CSD_TUNE_ENV("CSD_XP_OPS_OFF");
+}
+
 size_t convff_packed_bytes(const ConvPlan& p, int ns) {
   const int nt = ff_nt(p.Cout);
   return (size_t)(p.Cout / (32 * nt)) * ((p.C0 + p.C1) / 16) * 9 * nt * (ns == 3 ? 2 : ns) * 1024 + 4096;

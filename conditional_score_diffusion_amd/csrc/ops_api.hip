@@ -85,6 +85,14 @@ static size_t api_packed_floats(const ConvPlan& p, int Cin) {
     const size_t m = al64(pw16_packed_bytes(q, 2) / sizeof(float) + 1);
     if (m > n) n = m;
   }
+  {
+    ConvPlan q = p;
+    q.C0 = Cin; q.C1 = 0;
+    if (Cin % 16 == 0 && convff_pipelined(q, 2)) {
+      const size_t m = al64(convff_packed_bytes(q, 2) / sizeof(float) + 1);
+      if (m > n) n = m;
+    }
+  }
   return n;
 }
 
@@ -108,6 +116,7 @@ int csd::conv2d_operand_planes(int B, int Cin, int Cout, int H, int W, int ksize
   if (!ns || Cin % 32 != 0 || CSD_TUNE_ENV("CSD_NO_Q")) return 0;
   ConvPlan q = p;
   q.C0 = Cin; q.C1 = 0;
+  if (convff_pipelined(q, ns)) return 0;             // (conv_xp splits the fp32 source itself)
   return (conv16q_supported(q, ns) && conv16q_plan_tiles(&q, ns) == CSD_OK) ? (ns >= 2 ? 2 : 1) : 0;
 }
 
@@ -127,6 +136,24 @@ int csd::conv2d_impl(const float* x, const float* weight, const float* bias, con
   const size_t bias_fl = al64((size_t)p.CoutPad);
   int ns = precision_ns(precision);
   bool pw = false, quad = false;
+  if (ns == 2 && in_nhwc && out_nhwc && Cin % 16 == 0) {
+    // NHWC fp32 source, fp32-class arithmetic, a layer shape conv_xp.hip covers (the training graph's 3x3 convolutions and their data
+    // gradients on the >= 16^2 levels): the software-pipelined block convolution without its GroupNorm prologue - it splits the fp32
+    // operand into fp16 hi | lo itself, so no operand planes are written or read
+    ConvPlan q = p;
+    q.C0 = Cin; q.C1 = 0;
+    if (convff_pipelined(q, ns)) {
+      CSD_REQUIRE(!planes, "conv2d: pre-split operand planes on a layer that does not take them");
+      if ((rc = convff_plan_tiles(&q, ns))) return rc;
+      float* const wpk = static_cast<float*>(scratch) + al64((size_t)B * H * W * ceil32(Cin));
+      if ((rc = convff_pack_weight(q, ns, weight, (layout & 4) ? 2 : 0, Cin, Cout, 0, wpk, s))) return rc;
+      ConvArgs a;
+      memset(&a, 0, sizeof(a));
+      a.src0 = x; a.wpack = wpk; a.bias = bias; a.res = res; a.temb = temb; a.temb_stride = Cout;
+      a.out = y; a.out_stride = Cout; a.out_nchw = 0; a.out_scale = 1.f;
+      return convff_launch(q, ns, a, s);
+    }
+  }
   if (ns && in_nhwc && Cin % 32 == 0 && !CSD_TUNE_ENV("CSD_NO_Q")) {
     // NHWC source (the training graph): the quad schedule of the sampling path - one split pass writes the fp16 planes into the
     // scratch region an NCHW source would be transposed into, then conv_f16_q_kernel
