@@ -565,7 +565,9 @@ __global__ void convff_zero_kernel(uint32_t* p, size_t n) {
 int convff_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int cin_src, int cout_src, int cout_off,
                        void* wpack, hipStream_t s) {
   const int Cin = p.C0 + p.C1;
-  if (cout_off == 0) {
+  // (the packed layout has no padding in cin or cout: zero it only when this call does not cover all of it - a weight that arrives
+  // in several cout slices or with fewer input channels than the layer)
+  if (cout_off == 0 && !(cin_src == Cin && cout_src == p.Cout)) {
     const size_t n32 = convff_packed_bytes(p, ns) / 4;
     hipLaunchKernelGGL(convff_zero_kernel, dim3((unsigned)cdiv64(n32, 256)), dim3(256), 0, s, (uint32_t*)wpack, n32);
     CSD_LAUNCH_CHECK();

@@ -312,3 +312,26 @@ def test_vs_cmde_variance_schedule():
     assert abs(f(0) - y0) < 1e-9 and abs(f(xk) - yk) < 1e-9
     assert f(1000) > f(2000) > f(100000) > yk
     assert abs(f(150000) - xk * yk * y0 / (150000 * (y0 - yk) + xk * yk)) < 1e-12
+
+
+def test_conv_xp_isa_check_catches_unprotected_accumulator_accesses(tmp_path):
+    """tools/check_xp_isa.py (run by the build on conv_xp.hip's ISA) accepts matrix instructions + reads behind the tied wait, and
+    rejects a register move on an accumulator or a read in the shadow of a matrix instruction"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('check_xp_isa', os.path.join(root, 'tools', 'check_xp_isa.py'))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    name = '_ZN3csd14conv_xp_kernelILi2ELb0ELb0EEEvPKcNS_10ConvFFArgsE'
+    mf = ['\tv_mfma_f32_32x32x16_f16 a[%d:%d], v[2:5], v[6:9], a[%d:%d]' % (16 * i, 16 * i + 15, 16 * i, 16 * i + 15) for i in range(4)]
+    good = [name + ':'] + mf + ['\ts_nop 15', '\tv_accvgpr_read_b32 v1, a0', '\tv_accvgpr_mov_b32 a100, a101', '\ts_endpgm']
+    moved = [name + ':'] + mf + ['\tv_accvgpr_mov_b32 a16, a64', '\ts_nop 15', '\tv_accvgpr_read_b32 v1, a0', '\ts_endpgm']
+    early = [name + ':'] + mf + ['\tv_accvgpr_read_b32 v1, a0', '\ts_endpgm']
+    five = [name + ':'] + mf + ['\tv_mfma_f32_32x32x16_f16 a[64:79], v[2:5], v[6:9], a[64:79]', '\ts_endpgm']
+    for lines, rc in ((good, 0), (moved, 1), (early, 1), (five, 1)):
+        p = tmp_path / 'k.s'
+        p.write_text('\n'.join(lines) + '\n')
+        assert chk.main(str(p)) == rc
+    built = os.path.join(root, 'conditional_score_diffusion_amd', 'csrc', 'conv_xp.s')
+    if os.path.exists(built):                        # the ISA the in-tree library was built from
+        assert chk.main(built) == 0

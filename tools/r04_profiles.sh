@@ -25,4 +25,10 @@ bash tools/pmc_hbm.sh fp16x3 r04_fp16x3
 python tools/hbm_traffic.py r04_fp16x3 $O/hbm_traffic_fp16x3.json > $O/hbm_traffic_fp16x3.txt
 bash tools/timeline_run.sh fp16x3 r04_sampling_fp16x3
 cp gpurun_out/timeline_r04_sampling_fp16x3.txt $O/ 2>/dev/null
-python bench.py --cpu-thread-sweep > $O/cpu_thread_sweep.txt 2>&1
+# the training step and the NCSN++ forwards (kernel stats of the side benches)
+bash tools/train_prof.sh ddpm_paired r04 > $O/train_bench_ddpm_paired.json; cp gpurun_out/train_r04_kernel_stats.csv $O/train_ddpm_paired_kernel_stats.csv
+python tools/bench_train.py --model ncsnpp_paired --precision fp16x3 2>/dev/null | tail -1 > $O/train_bench_ncsnpp_paired.json
+python tools/bench_train.py --model ddpm_paired --precision fp16x3 --batch 7 2>/dev/null | tail -1 > $O/train_bench_ddpm_paired_b7.json
+bash tools/ncsnpp_timeline.sh 160 r04_160 > /dev/null; cp gpurun_out/ncsnpp_r04_160_kernel_stats.csv $O/ncsnpp160_kernel_stats.csv
+bash tools/ncsnpp_timeline.sh 256 r04_256 > /dev/null; cp gpurun_out/ncsnpp_r04_256_kernel_stats.csv $O/ncsnpp256_kernel_stats.csv
+if [ "${1:-}" = "sweep" ]; then python bench.py --cpu-thread-sweep > $O/cpu_thread_sweep.txt 2>&1; fi
