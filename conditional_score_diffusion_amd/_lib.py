@@ -88,6 +88,12 @@ SIGNATURES = {
     'csd_unet_train_forward': (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _i, _f, ctypes.c_uint64, ctypes.c_uint64, _vp]),
     'csd_unet_backward': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _i, ctypes.c_uint64, _vp]),
     'csd_unet_train_release': (_i, [_vp, _vp]),
+    'csd_unet_backward_marks': (_i, [_vp, _vp, _vp, _i]),
+    'csd_unet_backward_marks_epoch': (ctypes.c_uint64, [_vp]),
+    'csd_event_create': (_vp, []),
+    'csd_event_destroy': (_i, [_vp]),
+    'csd_stream_wait_event': (_i, [_vp, _vp]),
+    'csd_event_query': (_i, [_vp]),
     'csd_update_scratch_bytes': (_sz, [_i]),
     'csd_langevin_step': (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _i64, _vp, _vp]),
     'csd_reverse_diffusion_step': (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i64, _vp]),

@@ -46,6 +46,13 @@ struct TrainState {
 // between a training forward and its backward) as long as each has its own workspace - and a backward names the call_index of the
 // forward it belongs to, so a workspace that was re-used in between is an error, never a silently wrong gradient
 static std::map<std::pair<const Net*, const void*>, TrainState> g_train;
+// gradient-ready marks of a handle (csd_unet_backward_marks): event k is recorded on the backward's stream as soon as every gradient
+// of the modules with all_modules index >= first_module[k] is final; `epoch` counts the backward calls that recorded all of them
+struct GradMarks {
+  std::vector<std::pair<int, hipEvent_t>> marks;     // sorted by first_module, descending (the order they become ready)
+  uint64_t epoch = 0;
+};
+static std::map<const Net*, GradMarks> g_marks;
 static std::mutex g_train_mu;                         // (the map only; a handle itself is driven by one thread at a time)
 static TrainState& train_state_of(const Net* n, const void* ws) {
   std::lock_guard<std::mutex> lk(g_train_mu);
@@ -70,6 +77,7 @@ static void train_state_purge_stale(const Net* n, const void* keep) {
 static void train_state_erase(const Net* n) {
   std::lock_guard<std::mutex> lk(g_train_mu);
   for (auto it = g_train.begin(); it != g_train.end();) it = it->first.first == n ? g_train.erase(it) : std::next(it);
+  g_marks.erase(n);
 }
 
 __global__ void concat_c_kernel(const float4* __restrict__ a, int ca4, const float4* __restrict__ b, int cb4,
@@ -119,6 +127,17 @@ struct TG {
   float p_drop = 0.f;
   uint64_t seed = 0, call = 0;
   int drop_count = 0;
+  GradMarks* gm = nullptr;      // backward only
+  size_t gm_next = 0;
+  // every gradient of the modules with index >= `from` has been enqueued: record the marks that this completes
+  int marks_reached(int from) {
+    if (!gm || dry) return CSD_OK;
+    while (gm_next < gm->marks.size() && gm->marks[gm_next].first >= from) {
+      CSD_CHECK_HIP(hipEventRecord(gm->marks[gm_next].second, s));
+      ++gm_next;
+    }
+    return CSD_OK;
+  }
 
   TG(Net& net, TrainState& state, int B_, hipStream_t s_, bool dry_, const float* const* P_, float* const* G_, float* ws)
       : n(net), st(state), B(B_), s(s_), dry(dry_), P(P_), G(G_), base(ws), prec(net.cfg.precision), act(net.cfg.act) {}
@@ -866,8 +885,23 @@ struct TG {
       dtemb_act = alloc((size_t)B * 4 * nf);
       if (!dry) CSD_CHECK_HIP(hipMemsetAsync(dtemb_act, 0, (size_t)B * 4 * nf * sizeof(float), s));
     }
+    // the marks may follow the steps only if the recorded steps walk the modules in ascending order (they do: the forward consumes
+    // all_modules front to back) - otherwise every mark waits for the end of the backward
+    bool ordered = true;
+    {
+      int last = -1;
+      for (const TStep& sp : st.steps) {
+        if (sp.mod < 0) continue;
+        const int idx = n.mods[sp.mod].idx;
+        if (idx < last) ordered = false;
+        last = idx;
+      }
+    }
     for (int i = (int)st.steps.size() - 1; i >= 0; --i) {
       const TStep& sp = st.steps[i];
+      if (i + 1 < (int)st.steps.size() && ordered && st.steps[i + 1].mod >= 0) {      // step i + 1 and everything after it is complete
+        rc = marks_reached(n.mods[st.steps[i + 1].mod].idx); if (rc) return rc;
+      }
       switch (sp.kind) {
         case TS_HEAD: {
           const Module& mg = n.mods[sp.mod];
@@ -1001,7 +1035,7 @@ struct TG {
         CSD_CHECK_HIP(hipMemsetAsync(DW(st.fourier_mod, "W"), 0, (size_t)nf * sizeof(float), s));
       top = mk;
     }
-    return CSD_OK;
+    return marks_reached(-1);                        // (the embedding MLP holds the lowest module indices: everything is final now)
   }
 #undef TG_RUN
 };
@@ -1087,7 +1121,58 @@ extern "C" int csd_unet_backward(csd_unet* net, const float* const* params, floa
     CSD_REQUIRE(params[i] && grads[i], "backward: parameter / gradient pointer %zu (%s) is null", i, net->net.params[i].name.c_str());
   for (auto& t : st.t) t.g = nullptr;
   TG g(net->net, st, B, (hipStream_t)stream, false, params, grads, static_cast<float*>(workspace));
+  {
+    std::lock_guard<std::mutex> lk(g_train_mu);
+    auto it = g_marks.find(&net->net);
+    g.gm = it == g_marks.end() ? nullptr : &it->second;
+  }
   rc = g.backward(d_out);
+  if (!rc && g.gm) ++g.gm->epoch;
   st.valid = false;                                  // the saved activations are consumed (gradient buffers overwrote nothing, but one backward per forward)
   return rc;
+}
+
+// ---- gradient-ready marks + the event / stream helpers a data-parallel caller needs to overlap its all-reduce with the backward ----
+extern "C" int csd_unet_backward_marks(csd_unet* net, const int* first_module, void* const* events, int n) {
+  int rc = csd::train_check(net);
+  if (rc) return rc;
+  CSD_REQUIRE(n >= 0 && (n == 0 || (first_module && events)), "backward_marks: null argument");
+  std::lock_guard<std::mutex> lk(csd::g_train_mu);
+  if (n == 0) { csd::g_marks.erase(&net->net); return CSD_OK; }
+  csd::GradMarks& gm = csd::g_marks[&net->net];
+  gm.marks.clear();
+  for (int k = 0; k < n; ++k) {
+    CSD_REQUIRE(events[k], "backward_marks: event %d is null", k);
+    gm.marks.emplace_back(first_module[k], static_cast<hipEvent_t>(events[k]));
+  }
+  std::stable_sort(gm.marks.begin(), gm.marks.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+  return CSD_OK;
+}
+extern "C" uint64_t csd_unet_backward_marks_epoch(csd_unet* net) {
+  if (!net) return 0;
+  std::lock_guard<std::mutex> lk(csd::g_train_mu);
+  auto it = csd::g_marks.find(&net->net);
+  return it == csd::g_marks.end() ? 0 : it->second.epoch;
+}
+extern "C" void* csd_event_create(void) {
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+  return e;
+}
+extern "C" int csd_event_destroy(void* event) {
+  if (event) CSD_CHECK_HIP(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  return CSD_OK;
+}
+extern "C" int csd_stream_wait_event(void* stream, void* event) {
+  CSD_REQUIRE(event, "stream_wait_event: null event");
+  CSD_CHECK_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(event), 0));
+  return CSD_OK;
+}
+extern "C" int csd_event_query(void* event) {      /* 1: complete, 0: not yet, < 0: error */
+  CSD_REQUIRE(event, "event_query: null event");
+  const hipError_t e = hipEventQuery(static_cast<hipEvent_t>(event));
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) return 0;
+  csd::set_error("event_query: %s", hipGetErrorString(e));
+  return CSD_ERR_HIP;
 }

@@ -97,6 +97,24 @@ def sample_sharded(sampler, model, y_global=None, n_total=None, seed=None, group
 # ------------------------------------------------------------------------------------------------------------------
 # data-parallel training: gradient all-reduce (replaces Lightning-DDP / NCCL, run_lib.py:55-73)
 # ------------------------------------------------------------------------------------------------------------------
+def ctypes_ptr(v):
+    import ctypes
+    return ctypes.c_void_p(int(v))
+
+
+def bucket_first_modules(param_names, bucket_param_indices):
+    """Lowest ``all_modules`` index among the parameters of every bucket (``all_modules.<k>.<leaf>``: the reference's module list,
+    models/ddpm.py:97-147) - the module whose backward completes the bucket, since the backward walks the list back to front.
+    None if a name does not follow the pattern."""
+    mods = []
+    for n in param_names:
+        parts = n.split('.')
+        if len(parts) < 3 or parts[0] != 'all_modules' or not parts[1].isdigit():
+            return None
+        mods.append(int(parts[1]))
+    return [min(mods[i] for i in idxs) for idxs in bucket_param_indices]
+
+
 class GradSync:
     """Bucketed gradient all-reduce over a flat gradient buffer, overlapped with the backward pass.
 
@@ -136,6 +154,40 @@ class GradSync:
             for i, p in enumerate(flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
 
+    def attach_planned(self, model):
+        """Planned training graph (the whole backward is ONE csd_unet_backward call: no autograd hooks fire): register one
+        gradient-ready event per bucket on the network handle - the library records it on the backward's stream as soon as the
+        gradients of that bucket's modules are final (csd_unet_backward_marks) - so that ``finish()`` can launch every bucket's
+        all-reduce on a communication stream that waits for ITS event only: the late layers' gradients are reduced while the
+        backward of the early layers still runs.  Without a process group (or off the GPU) nothing is registered."""
+        self._model, self._events, self._comm, self._epoch = None, None, None, 0
+        if not self.grouped or not self.flat.grad.is_cuda or getattr(model, '_h', None) is None:
+            return False
+        from ._lib import check, lib
+        first = bucket_first_modules([n for n, _ in model.named_parameters()], [b[2] for b in self.buckets])
+        if first is None:
+            return False
+        import ctypes
+        self._events = [lib().csd_event_create() for _ in self.buckets]
+        if not all(self._events):
+            raise RuntimeError('csd_event_create failed')
+        fm = (ctypes.c_int * len(first))(*first)
+        ev = (ctypes.c_void_p * len(first))(*self._events)
+        check(lib().csd_unet_backward_marks(model._h, fm, ev, len(first)), 'unet_backward_marks')
+        self._model = model
+        self._comm = torch.cuda.Stream(device=self.flat.grad.device)
+        self._epoch = int(lib().csd_unet_backward_marks_epoch(model._h))
+        self.overlapped_launches = 0      # buckets launched from their event (statistics for tests / logs)
+        return True
+
+    def detach_planned(self):
+        if getattr(self, '_events', None):
+            from ._lib import lib
+            lib().csd_unet_backward_marks(self._model._h, None, None, 0)
+            for e in self._events:
+                lib().csd_event_destroy(e)
+        self._events = None
+
     def scale_loss(self, loss, local_n=None, global_n=None):
         """The summed gradients must be the GLOBAL-batch mean: equal shards -> loss / world; ragged shards (a global batch that does
         not divide, ``shard_bounds``) -> the rank's mean weighted by its share ``local_n / global_n`` of the images."""
@@ -145,6 +197,8 @@ class GradSync:
 
     def _make_hook(self, i):
         def hook(param):
+            if getattr(self, '_events', None):        # planned graph: nothing was accumulated (the hook fires for an undefined
+                return                                # gradient too); finish() launches every bucket from its gradient-ready event
             b = self._bucket_of[i]
             self._pending[b] -= 1
             if self._pending[b] == 0:
@@ -159,6 +213,17 @@ class GradSync:
     def finish(self):
         """Call after ``backward``: every bucket reduced, the flat gradient holds the global mean."""
         if self.grouped:
+            ev = getattr(self, '_events', None)
+            if ev and not any(self._launched):
+                from ._lib import check, lib
+                epoch = int(lib().csd_unet_backward_marks_epoch(self._model._h))
+                if epoch == self._epoch + 1:          # exactly one planned backward since the last step recorded every event
+                    for b in reversed(range(len(self.buckets))):      # the order the gradients become final
+                        check(lib().csd_stream_wait_event(ctypes_ptr(self._comm.cuda_stream), ev[b]), 'stream_wait_event')
+                        with torch.cuda.stream(self._comm):
+                            self._launch(b)
+                        self.overlapped_launches += 1
+                self._epoch = epoch
             for b in range(len(self.buckets)):
                 if not self._launched[b]:
                     self._launch(b)

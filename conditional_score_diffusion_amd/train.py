@@ -6,10 +6,12 @@ Replaces ``BaseSdeGenerativeModel.training_step`` / ``configure_optimizers`` (li
 
 * forward + backward as ONE planned graph behind csd_unet_train_forward / csd_unet_backward (DDPM family; csrc/train_graph.h) or
   on the differentiable HIP operators of grad_ops (NCSN++; csrc/backward.hip);
-* gradients live in ONE flat buffer, all-reduced in 32 MiB buckets (distributed.GradSync).  On the operator-granular executor
-  (NCSN++) the buckets are launched from autograd hooks while the backward of earlier layers is still running; on the planned graph
-  (DDPM family: the whole backward is ONE csd_unet_backward call that only enqueues kernels) every bucket is reduced after that
-  call - there is no overlap with the backward in that mode, and none is claimed (115 MB of gradients per step at configs[3]);
+* gradients live in ONE flat buffer, all-reduced in 32 MiB buckets (distributed.GradSync).  On the operator-granular executor the
+  buckets are launched from autograd hooks while the backward of earlier layers is still running.  On the planned graph (the whole
+  backward is ONE csd_unet_backward call that only enqueues kernels) the library records one gradient-ready event per bucket on
+  the backward's stream (csd_unet_backward_marks); after the call returns - the GPU is still early in the backward - every bucket
+  is launched on a communication stream that waits for its own event only.  (Measured on ONE GPU only: the event order and the
+  gradients are tested, the overlap itself has never run on more than one device.)
 * ONE fused kernel applies clipping + Adam + EMA (optim.FusedAdam / csd_adam_step).
 """
 import torch
@@ -48,6 +50,7 @@ class Trainer:
         # by zero_grad()) - autograd has nothing to accumulate and GradSync.finish() reduces every bucket after the backward
         if getattr(model, 'train_executor', None) == 'planned':
             model.grad_sink = True
+            self.sync.attach_planned(model)           # per-bucket gradient-ready events: the all-reduce overlaps the backward
         self.step = 0                     # completed optimizer steps (the warm-up factor of step k is k / warmup)
 
     def _build_loss_fns(self):

@@ -406,6 +406,20 @@ int csd_unet_backward(csd_unet* net, const float* const* params, float* const* g
 /* The library keeps one recorded training graph per (handle, workspace).  A caller that frees a workspace (a monitoring forward's
  * private one) tells the library so: the record is dropped (no error if there is none).  csd_unet_destroy drops all of a handle's. */
 int csd_unet_train_release(csd_unet* net, const void* workspace);
+/* Gradient-ready marks - what Lightning-DDP's bucketed all-reduce hooks into autograd for (run_lib.py:55-73), for a backward that is
+ * ONE call: while csd_unet_backward enqueues its kernels on `stream`, it records events[k] on that stream as soon as every gradient
+ * of the modules with all_modules index >= first_module[k] is final (the backward walks all_modules back to front; the embedding
+ * MLP's gradients come last).  A data-parallel caller makes its communication stream wait for events[k] and launches the
+ * all-reduce of that bucket there: the reduction of the late layers' gradients overlaps the backward of the early ones.
+ * The marks stay registered on the handle until replaced or cleared (n = 0); the events are the caller's.
+ * csd_unet_backward_marks_epoch: number of csd_unet_backward calls of this handle that recorded every mark (a caller checks that it
+ * advanced before trusting the events). */
+int csd_unet_backward_marks(csd_unet* net, const int* first_module, void* const* events, int n);
+uint64_t csd_unet_backward_marks_epoch(csd_unet* net);
+void* csd_event_create(void);                         /* hipEventDisableTiming; NULL on failure */
+int csd_event_destroy(void* event);
+int csd_stream_wait_event(void* stream, void* event);
+int csd_event_query(void* event);                     /* 1: complete, 0: not yet, < 0: error */
 
 #ifdef __cplusplus
 }

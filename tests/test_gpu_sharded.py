@@ -205,3 +205,96 @@ def test_rccl_world_one(golden_dir):
     assert np.abs(res['global'] - g['sr3_tiny_global']).max() / smax < 2e-4
     # one rank: d(sum(W x + b))/dW = sum_b x_b = 2 * 1, all-reduced over a world of one
     assert np.allclose(res['grad'][:64 * 64], 2.0)
+
+
+def _planned_overlap_worker(port, q):
+    """one-rank 'nccl' group: Trainer on the planned training graph with per-bucket gradient-ready events"""
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        import ctypes
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path[:0] = [root, os.path.join(root, 'oracle'), os.path.join(root, 'tests')]
+        import cases as cs
+        from test_gpu_network import build as bld, sdes_for as sf
+        from conditional_score_diffusion_amd import train
+        from conditional_score_diffusion_amd._lib import check, lib
+        res = {}
+        for case in ('sr3_tiny', 'cmde_tiny'):
+            try:
+                cfg, B, x, y, u, tape = cs.grad_case(case)
+            except Exception:
+                continue
+            cfg.model.dropout = 0.1
+            cfg.optim.warmup = 1
+            batch = (y.to('cuda:0'), x.to('cuda:0'))
+
+            def run(overlap):
+                torch.manual_seed(3)
+                _, _, _, model = bld(cfg)
+                tr = train.Trainer(cfg, model, sf(cfg), bucket_bytes=256 << 10)
+                assert len(tr.sync.buckets) >= 3
+                if not overlap:
+                    tr.sync.detach_planned()
+                for i in range(3):
+                    torch.manual_seed(10 + i)
+                    tr.train_step(batch)
+                torch.cuda.synchronize()
+                return tr
+
+            a, b = run(True), run(False)
+            same = bool(torch.equal(a.flat.data, b.flat.data)) and bool(torch.equal(a.ema.shadow, b.ema.shadow))
+            # the order in which the library records the marks: timing events of the caller in place of the trainer's
+            tr = a
+            n = len(tr.sync.buckets)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+            for e in evs:
+                e.record()
+            torch.cuda.synchronize()
+            from conditional_score_diffusion_amd.distributed import bucket_first_modules
+            first = bucket_first_modules([k for k, _ in tr.model.named_parameters()], [bk[2] for bk in tr.sync.buckets])
+            fm = (ctypes.c_int * n)(*first)
+            ev = (ctypes.c_void_p * n)(*[e.cuda_event for e in evs])
+            check(lib().csd_unet_backward_marks(tr.model._h, fm, ev, n), 'marks')
+            tr.sync._events = None                   # (this step reduces after the backward; the marks are ours)
+            start = torch.cuda.Event(enable_timing=True)
+            start.record()
+            torch.manual_seed(99)
+            tr.train_step(batch)
+            torch.cuda.synchronize()
+            check(lib().csd_unet_backward_marks(tr.model._h, None, None, 0), 'marks clear')
+            res[case] = dict(buckets=n, overlapped=a.sync.overlapped_launches, plain=getattr(b.sync, 'overlapped_launches', 0),
+                             same=same, first=first,
+                             t_ms=[start.elapsed_time(e) for e in evs])
+        q.put((res, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:      # pragma: no cover
+        import traceback
+        q.put((None, traceback.format_exc()))
+
+
+def test_planned_backward_records_gradient_ready_events_for_the_all_reduce():
+    """csd_unet_backward_marks: with a process group the Trainer launches every gradient bucket's all-reduce from the event the
+    library records when that bucket's gradients are final (3 steps x buckets launches), the result is bit-identical to reducing
+    after the backward, and the events fire in the order the backward walks the modules: the bucket of the LAST modules first, the
+    bucket holding the embedding MLP last, with the backward's kernels in between"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    pr = ctx.Process(target=_planned_overlap_worker, args=(_free_port(), q))
+    pr.start()
+    res, err = q.get(timeout=900)
+    pr.join(timeout=120)
+    assert err is None, err
+    assert 'sr3_tiny' in res
+    for case, r in res.items():
+        assert r['overlapped'] == 3 * r['buckets'] and r['plain'] == 0, (case, r)
+        assert r['same'], case
+        assert r['first'] == sorted(r['first']) and r['first'][0] == 0, (case, r['first'])
+        t = r['t_ms']
+        assert all(t[k] > t[k + 1] for k in range(len(t) - 1)), (case, t)      # later buckets (late modules) are ready earlier
+        assert t[0] - t[-1] > 0.2 * t[0], (case, t)      # ... with most of the backward between the last bucket and the first

@@ -335,3 +335,14 @@ def test_conv_xp_isa_check_catches_unprotected_accumulator_accesses(tmp_path):
     built = os.path.join(root, 'conditional_score_diffusion_amd', 'csrc', 'conv_xp.s')
     if os.path.exists(built):                        # the ISA the in-tree library was built from
         assert chk.main(built) == 0
+
+
+def test_bucket_first_modules_follow_the_module_list():
+    """distributed.bucket_first_modules: the module whose backward completes a gradient bucket = the lowest all_modules index among
+    the bucket's parameters (the planned backward walks the list back to front and records the bucket's event after that module)"""
+    from conditional_score_diffusion_amd.distributed import bucket_first_modules
+    names = ['all_modules.0.weight', 'all_modules.0.bias', 'all_modules.1.weight', 'all_modules.3.Conv_0.weight',
+             'all_modules.3.Conv_0.bias', 'all_modules.10.NIN_0.W', 'all_modules.11.weight']
+    assert bucket_first_modules(names, [[0, 1, 2], [3, 4], [5, 6]]) == [0, 3, 10]
+    assert bucket_first_modules(names, [[0, 1, 2, 3], [4, 5, 6]]) == [0, 3]      # a module split over two buckets completes both
+    assert bucket_first_modules(names + ['head.weight'], [[0], [7]]) is None      # not the reference's naming: no events, no overlap

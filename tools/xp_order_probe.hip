@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, int iters, long long
     // ORDER 3: random fp16 pairs (what real operands look like to the matrix pipe: every bit toggles); otherwise a smooth ramp
     unsigned h = (i + blockIdx.x * 16384) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
     const unsigned lo16 = (h & 0x3ff) | (((h >> 10) % 12 + 9) << 10) | ((h >> 20 & 1) << 15), hi16 = (h >> 21 & 0x3ff) | (((h >> 3) % 12 + 9) << 10) | ((h >> 31) << 15);
-    if (ORDER == 3) reinterpret_cast<unsigned*>(lds)[i] = lo16 | (hi16 << 16);
+    if (ORDER >= 3) reinterpret_cast<unsigned*>(lds)[i] = lo16 | (hi16 << 16);
     else reinterpret_cast<float*>(lds)[i] = i * 1e-6f;
   }
   __syncthreads();
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, int iters, long long
                        : "+a"(acc[i]) : "v"(a[i / 3]), "v"(b[i % 3]), "v"(a[1 - i / 3]), "v"(b[(i + 1) % 3]));
           fill(i, 6);
         }
-      } else if (ORDER == 3) {
+      } else if (ORDER == 3 || ORDER == 4 || ORDER == 5) {
         // operands of this tap come from LDS (10 fragments, a different 10 KB window per tap), read during the previous tap
         half8 fa[2][2], fb[2][3];
 #pragma unroll
@@ -69,9 +69,12 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, int iters, long long
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
-          for (int i = 0; i < 6; ++i) {
+          for (int j = 0; j < 6; ++j) {
+            // ORDER 3: pixel tile major (the A operand repeats three times); 4: cout tile major (B repeats twice, A alternates);
+            // 5: snake (A A A' A' ... with B reversed on the way back: one operand changes per MFMA)
+            const int i = ORDER == 4 ? (j % 2) * 3 + j / 2 : ORDER == 5 ? (j < 3 ? j : 8 - j) : j;
             MFMA(acc[i], fa[p == 1 ? 1 : 0][i / 3], fb[p == 0 ? 1 : 0][i % 3]);
-            fill(p * 6 + i, 18);
+            fill(p * 6 + j, 18);
           }
       } else if (ORDER == 1) {
 #pragma unroll
@@ -133,5 +136,6 @@ int main() {
   run<0, 90, 10>(out, clk); run<1, 90, 10>(out, clk); run<2, 90, 10>(out, clk);
   run<1, 108, 10>(out, clk); run<1, 36, 18>(out, clk);
   run<3, 0, 0>(out, clk); run<3, 36, 0>(out, clk); run<3, 54, 0>(out, clk);
+  for (int rep = 0; rep < 3; ++rep) { run<3, 36, 0>(out, clk); run<4, 36, 0>(out, clk); run<5, 36, 0>(out, clk); }
   return 0;
 }
