@@ -183,7 +183,11 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
   };
 
   // ---- weight stream of this wave: 3 fragments (x NS planes) per K step, ring of BR steps ----
-  constexpr int BR = UP4 ? 2 : 3;
+  // ring depth: the prefetch distance (BR - 1 steps of MQ x NTQ x 3 MFMAs) has to cover an L2 round trip.  With one 16-cout tile per
+  // wave (the 5^2 level) a step is 6 MFMAs = ~100 cycles, so the whole stage's nine steps are kept in flight there (72 registers):
+  // 26 -> 23.5 us per launch for ~7 us of arithmetic - the rest of those launches is the per-stage patch hand-over (a 32-channel
+  // stage is 0.4 us of MFMAs: one stage of prefetch distance does not cover a global load), launch latency and the prologue tables
+  constexpr int BR = UP4 ? 2 : (NTQ == 1 && !F8 ? 9 : 3);
   const int nk32 = Cin / 32;
   const char* wstep = g_wpack + ((size_t)((UP4 ? ph * k.n_groups * 2 : 0) + ng * 2 + ni) * nk32 * TAPS) * WSTEP + lane * 16;
   constexpr int NP = F8 ? 1 : NS;               // fp16 planes read per fragment
@@ -495,7 +499,7 @@ static inline int q_ntq(const ConvPlan& p) { return p.qnt ? p.qnt : (p.Cout % 96
 size_t conv16q_packed_bytes(const ConvPlan& p, int ns) {
   if (ns == 3) ns = 2;
   const int ntq = q_ntq(p);
-  return (size_t)(p.Cout / (32 * ntq)) * 2 * (p.C0 / 32) * 9 * ntq * ns * 1024 + (size_t)4 * ntq * ns * 1024;   // + prefetch slack
+  return (size_t)(p.Cout / (32 * ntq)) * 2 * (p.C0 / 32) * 9 * ntq * ns * 1024 + (size_t)8 * ntq * ns * 1024;   // + prefetch slack (8 K steps: the deepest weight ring)
 }
 
 __global__ void conv16q_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ wpack, int layout, int cin_src,
@@ -505,7 +509,7 @@ __global__ void conv16q_pack_kernel(const float* __restrict__ w, _Float16* __res
   const size_t total = (size_t)cout_src * Cin * 9;
   if (idx >= total) return;
   {                                                    // the prefetch slack behind the last fragment (read, never multiplied) is zeroed here
-    const size_t body32 = (size_t)(Cout / (32 * ntq)) * 2 * (Cin / 32) * 9 * ntq * ns * 256, slack32 = (size_t)ntq * ns * 1024;
+    const size_t body32 = (size_t)(Cout / (32 * ntq)) * 2 * (Cin / 32) * 9 * ntq * ns * 256, slack32 = (size_t)2 * ntq * ns * 1024;
     if (cout_off == 0 && idx < slack32) reinterpret_cast<uint32_t*>(wpack)[body32 + idx] = 0u;
   }
   const int tap = (int)(idx % 9);

@@ -125,7 +125,22 @@ void run(float* out, long long* clk) {
   printf("order %d  fma %3d  ds_read %2d per tap (18 MFMAs): %7.1f us  %6.0f TF/s  %5.1f ns per MFMA  | %.1f cycles per MFMA at %.3f GHz\n", ORDER, F, R, ms * 1e3, tf, ms * 1e6 / mf, h[0] / mf, h[0] / (h[1] * 10.0));
 }
 
-int main() {
+template <int ORDER, int F>
+void run_long(float* out, long long* clk, int launches) {      // a few seconds of one stream: for tools/power_trace.sh
+  for (int i = 0; i < launches; ++i) hipLaunchKernelGGL((probe<ORDER, F, 0>), dim3(256), dim3(256), 0, 0, out, 400, clk);
+  hipDeviceSynchronize();
+  long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+  printf("order %d fma %d: %d launches, last one at %.3f GHz\n", ORDER, F, launches, h[0] / (h[1] * 10.0));
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 'l') {                // "long": random operands, 36 fillers per tap, ~6 s; then constant operands
+    float* out; hipMalloc(&out, 256 * 256 * 4);
+    long long* clk; hipMalloc(&clk, 256 * 16);
+    run_long<3, 36>(out, clk, 3500);
+    run_long<1, 36>(out, clk, 5000);
+    return 0;
+  }
   float* out; hipMalloc(&out, 256 * 256 * 4);
   long long* clk; hipMalloc(&clk, 256 * 16);
   run<0, 0, 0>(out, clk); run<1, 0, 0>(out, clk); run<2, 0, 0>(out, clk);
