@@ -6,16 +6,20 @@
 // overlaps a dense MFMA stream by 15-20 % only, and the per-tile prologue / epilogue is exposed.  What does hide behind a matrix
 // instruction is the SAME wave's next few instructions (MI355X_MICROARCH.md: ~5 single-issue instructions per 32-cycle MFMA gap with
 // one wave per SIMD).  So: one 4-wave workgroup per CU (512 registers per lane), persistent over its tiles, and every wave runs
-//   chain of 3 MFMAs (lo*hi, hi*lo, hi*hi on one accumulator, back to back)  |  a handful of "filler" instructions  |  next chain ...
+//   MFMA  |  2-5 "filler" instructions  |  MFMA  |  ...      (per tap: the products hi*lo, lo*hi, hi*hi, each round robin over the
+//   2 x NT accumulators - consecutive MFMAs are independent, so the wave is free to issue the fillers while the matrix pipe works)
 // where the fillers are, in program order and pinned by scheduling fences:
 //   * the ds_read_b128 of the NEXT tap's fragments (register double buffer);
 //   * this wave's quarter of the NEXT stage's operand patch: GroupNorm affine + exp2-domain SiLU + fp16 hi | lo split of an fp32
 //     float4 that was requested one whole stage (>= 5184 matrix cycles) earlier, then the request for the stage after;
 //   * this wave's quarter of the NEXT stage's weights: global -> registers at the top of the stage, registers -> LDS at its end
 //     (no LDS-DMA: with a DMA in flight hipcc drains vmcnt(0) at the next use of any ordinary load);
-//   * in a tile's last stage: the residual / bias / temb requests of the epilogue.
+//   * in a tile's last two stages: the residual / bias / temb requests of the epilogue.
 // ONE barrier per 16-channel stage (whole-stage double buffers: patch 2 x 21 KB, weights 2 x 54 KB), placed in front of the stage's
-// LAST tap: that tap's fragments are in registers, so the first fragments of the next stage are read under its 18 MFMAs.
+// LAST tap: that tap's fragments are in registers, so the first fragments of the next stage are read under its 6 NT MFMAs.
+// NT = 32-cout tiles per workgroup: 3 (96-cout groups) or 2 (64-cout groups, the nf = 128 networks); NORM = the GroupNorm + SiLU
+// prologue (without it the fp32 source is only split: the training graph's convolutions and data gradients); RES = a residual.
+// Measured (profiles/r04_power_trace.txt): back-to-back launches hold the package at its 1400 W power limit, 70 % MFMA-busy at 1.6 GHz.
 // The pipeline (patch two stages ahead, weights one) runs across tile boundaries; a tile costs its K loop + a short epilogue
 // (the accumulators start at zero; out = acc * k + (residual + bias + temb) * out_scale is one or two fused multiply-adds per
 // element on data that is already in registers).
