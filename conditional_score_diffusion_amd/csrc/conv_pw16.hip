@@ -62,21 +62,9 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
   const int ng = blockIdx.y;
   const int Cin = k.C0 + k.C1;
 
-  // ---- this cout group's weights -> LDS, once per workgroup ----
   const int wbytes = k.ks * PW_NTL * NS * 1024;
-  {
-    const char* wsrc = g_wpack + (size_t)ng * wbytes;
-    for (int i = tid * 16; i < wbytes; i += PW_THREADS * 16)
-      *reinterpret_cast<uint4*>(smem + i) = *reinterpret_cast<const uint4*>(wsrc + i);
-  }
-  // bias of this group's 96 couts behind the weights (zero where the cout does not exist)
-  float* const lds_bias = reinterpret_cast<float*>(smem + wbytes);
-  if (tid < PW_NTL * 16) {
-    const int c = ng * (PW_NTL * 16) + tid;
-    lds_bias[tid] = (k.a.bias && c < k.Cout) ? k.a.bias[c] : 0.f;
-  }
+  float* const lds_bias = reinterpret_cast<float*>(smem + wbytes);      // bias of this group's 96 couts behind the weights
   const int col_base = ng * (PW_NTL * 16) + kq * 4;       // this lane's first cout of tile 0
-  __syncthreads();
 
   const int nt_mine = (k.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = nt_mine * k.ks;
@@ -85,7 +73,12 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
   const bool has_act = k.a.act == CSD_ACT_SWISH;          // (only next to a GroupNorm: the tap-partial form of a tiny-Cout 3x3, below)
   const int ntl = min(PW_NTL, (k.Cout - (int)blockIdx.y * (PW_NTL * 16) + 15) / 16);     // 16-cout tiles of this group that exist
 
-  float4 raw[2][MTP][2];
+  // load-side pipeline depth in K steps: small maps (one or two tiles per workgroup, MTP = 1) have nothing but their own K loop to
+  // cover a global load with - four steps in flight, GroupNorm scale / shift rows included; big ones keep two (registers)
+  constexpr int D = MTP == 1 ? 4 : 2;
+  float4 raw[D][MTP][2];
+  constexpr bool PFN = MTP == 1;          // the scale / shift rows ride with the prefetch (else: loaded at their use, as ever)
+  float4 nsc[PFN ? D : 1][MTP][2], nsh[PFN ? D : 1][MTP][2];
   floatx4 acc[MTP][PW_NTL];
 #pragma unroll
   for (int j = 0; j < MTP; ++j)
@@ -96,7 +89,7 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
   int l_tile = blockIdx.x, l_kk = 0, l_it = 0;
   int c_tile = blockIdx.x, c_kk = 0;
 
-  auto issue = [&](float4 (&dst)[MTP][2]) {
+  auto issue = [&](float4 (&dst)[MTP][2], float4 (&dsc)[MTP][2], float4 (&dsh)[MTP][2]) {
     if (l_it < total) {
       const int kb = l_kk * 32;
       const bool s1 = kb >= k.C0;
@@ -110,18 +103,35 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
         const float* q = src + (size_t)p * C + ch;
         dst[j][0] = pw_gload4(q);
         dst[j][1] = pw_gload4(q + 4);
+        if (PFN && has_norm) {
+          const size_t row = (size_t)(p / k.hw) * Cin + l_kk * 32 + kq * 8;
+          dsc[j][0] = pw_gload4(k.a.nscale + row); dsc[j][1] = pw_gload4(k.a.nscale + row + 4);
+          dsh[j][0] = pw_gload4(k.a.nshift + row); dsh[j][1] = pw_gload4(k.a.nshift + row + 4);
+        }
       }
       ++l_it;
       if (++l_kk == k.ks) { l_kk = 0; l_tile += gridDim.x; }
     }
   };
 
-  issue(raw[0]);
-  issue(raw[1]);
-
-  for (int it = 0; it < total; it += 2) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < D; ++u) issue(raw[u], nsc[PFN ? u : 0], nsh[PFN ? u : 0]);
+
+  // ---- this cout group's weights -> LDS, once per workgroup (behind the first activation requests: their latency overlaps the copy) ----
+  {
+    const char* wsrc = g_wpack + (size_t)ng * wbytes;
+    for (int i = tid * 16; i < wbytes; i += PW_THREADS * 16)
+      *reinterpret_cast<uint4*>(smem + i) = *reinterpret_cast<const uint4*>(wsrc + i);
+  }
+  if (tid < PW_NTL * 16) {                                // (zero where the cout does not exist)
+    const int c = ng * (PW_NTL * 16) + tid;
+    lds_bias[tid] = (k.a.bias && c < k.Cout) ? k.a.bias[c] : 0.f;
+  }
+  __syncthreads();
+
+  for (int it = 0; it < total; it += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
       if (it + u < total) {
         // ---- fp32 rows -> fp16 B fragments (GroupNorm affine applied here when the layer has one) ----
         half8_t bh[MTP], bl[MTP];
@@ -130,11 +140,16 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
           float v[8] = {raw[u][j][0].x, raw[u][j][0].y, raw[u][j][0].z, raw[u][j][0].w,
                         raw[u][j][1].x, raw[u][j][1].y, raw[u][j][1].z, raw[u][j][1].w};
           if (has_norm) {
-            int p = c_tile * TPIX + wave * WPIX + j * 16 + l16;
-            p = p < k.npix ? p : k.npix - 1;
-            const size_t row = (size_t)(p / k.hw) * Cin + c_kk * 32 + kq * 8;
-            const float4 s0 = pw_gload4(k.a.nscale + row), s1 = pw_gload4(k.a.nscale + row + 4);
-            const float4 h0 = pw_gload4(k.a.nshift + row), h1 = pw_gload4(k.a.nshift + row + 4);
+            float4 s0, s1, h0, h1;
+            if constexpr (PFN) {
+              s0 = nsc[u][j][0]; s1 = nsc[u][j][1]; h0 = nsh[u][j][0]; h1 = nsh[u][j][1];
+            } else {
+              int p = c_tile * TPIX + wave * WPIX + j * 16 + l16;
+              p = p < k.npix ? p : k.npix - 1;
+              const size_t row = (size_t)(p / k.hw) * Cin + c_kk * 32 + kq * 8;
+              s0 = pw_gload4(k.a.nscale + row); s1 = pw_gload4(k.a.nscale + row + 4);
+              h0 = pw_gload4(k.a.nshift + row); h1 = pw_gload4(k.a.nshift + row + 4);
+            }
             const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
             const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
@@ -151,7 +166,7 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
             if (NS == 2) bl[j][q] = (_Float16)(v[q] - (float)hi);
           }
         }
-        issue(raw[u]);                       // this slot is free again: request K step it+u+2
+        issue(raw[u], nsc[PFN ? u : 0], nsh[PFN ? u : 0]);       // this slot is free again: request K step it + u + D
         // ---- MFMAs: 6 cout tiles x MTP pixel tiles ----
         const char* wk = smem + (size_t)c_kk * PW_NTL * NS * 1024 + lane * 16;
 #pragma unroll
