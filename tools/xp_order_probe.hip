@@ -2,6 +2,8 @@
 //   order 0: chains of three dependent MFMAs per accumulator (6 chains per tap), fillers after each chain      (6 gaps)
 //   order 1: round robin over the six accumulators (an accumulator recurs every 6 MFMAs), fillers after each MFMA (18 gaps)
 //   order 2: two accumulators interleaved (A B A B A B), fillers after each MFMA                                  (18 gaps)
+//   order 3-5: operands re-read every tap from RANDOM fp16 data in LDS, MFMAs pixel-tile major / cout-tile major / snake
+//   order 6-8: as 3, with 3 / 6 / all significand bits of the two "lo" operand planes cleared (bit activity vs clock at the power limit)
 // fillers per tap: F v_fma_f32 (four independent chains) + R ds_read_b128 (conflict-free) spread evenly over the gaps.
 // hipcc --offload-arch=gfx950 -O3 tools/xp_order_probe.hip -o /tmp/xp_order_probe && /tmp/xp_order_probe
 #include <hip/hip_runtime.h>
@@ -10,6 +12,7 @@
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 #define MFMA(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, int iters, long long
                        : "+a"(acc[i]) : "v"(a[i / 3]), "v"(b[i % 3]), "v"(a[1 - i / 3]), "v"(b[(i + 1) % 3]));
           fill(i, 6);
         }
-      } else if (ORDER == 3 || ORDER == 4 || ORDER == 5) {
+      } else if (ORDER >= 3) {
         // operands of this tap come from LDS (10 fragments, a different 10 KB window per tap), read during the previous tap
         half8 fa[2][2], fb[2][3];
 #pragma unroll
@@ -65,6 +68,22 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, int iters, long long
           for (int m = 0; m < 2; ++m) fa[q][m] = *reinterpret_cast<const half8*>(lds + ((tap * 10 + q * 2 + m) & 63) * 1024 + lane * 16);
 #pragma unroll
           for (int m = 0; m < 3; ++m) fb[q][m] = *reinterpret_cast<const half8*>(lds + ((tap * 10 + 4 + q * 3 + m) & 63) * 1024 + lane * 16);
+        }
+        if (ORDER >= 6) {      // the "lo" fragments with 3 (ORDER 6) / 6 (7) trailing significand bits cleared, or all zero (8): what the
+                               // multipliers' switching activity is worth at the power limit
+          const unsigned msk = ORDER == 6 ? 0xFFF8FFF8u : ORDER == 7 ? 0xFFC0FFC0u : 0u;
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            u4 t = __builtin_bit_cast(u4, fa[1][m]);
+            t = u4{t[0] & msk, t[1] & msk, t[2] & msk, t[3] & msk};
+            fa[1][m] = __builtin_bit_cast(half8, t);
+          }
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            u4 t = __builtin_bit_cast(u4, fb[1][m]);
+            t = u4{t[0] & msk, t[1] & msk, t[2] & msk, t[3] & msk};
+            fb[1][m] = __builtin_bit_cast(half8, t);
+          }
         }
 #pragma unroll
         for (int p = 0; p < 3; ++p)
@@ -152,5 +171,6 @@ int main(int argc, char** argv) {
   run<1, 108, 10>(out, clk); run<1, 36, 18>(out, clk);
   run<3, 0, 0>(out, clk); run<3, 36, 0>(out, clk); run<3, 54, 0>(out, clk);
   for (int rep = 0; rep < 3; ++rep) { run<3, 36, 0>(out, clk); run<4, 36, 0>(out, clk); run<5, 36, 0>(out, clk); }
+  for (int rep = 0; rep < 3; ++rep) { run<3, 36, 0>(out, clk); run<6, 16, 0>(out, clk); run<7, 16, 0>(out, clk); run<8, 16, 0>(out, clk); }
   return 0;
 }
