@@ -321,6 +321,81 @@ def test_up_or_down_sampling_module_vs_oracle():
     assert got.shape == ref.shape and (got.cpu() - ref).abs().max() <= 1e-5 * ref.abs().max()
 
 
+def _block_case(rs, B, C0, C1, Cout, H, W, norm, res, precision):
+    """one csd_conv3x3_block call on random data against fp64 torch: (relative max error, relative error of the tile partials)"""
+    from conditional_score_diffusion_amd import ops
+    Cin = C0 + C1
+    x = torch.from_numpy(rs.standard_normal((B, H, W, Cin)).astype(np.float32)) * 1.5 + 0.2
+    w = torch.from_numpy(rs.standard_normal((Cout, Cin, 3, 3)).astype(np.float32)) / (3.0 * Cin ** 0.5)
+    bias = torch.from_numpy(rs.standard_normal(Cout).astype(np.float32))
+    sc = torch.from_numpy(rs.uniform(0.5, 1.5, (B, Cin)).astype(np.float32)) if norm else None
+    sh = torch.from_numpy((rs.standard_normal((B, Cin)) * 0.5).astype(np.float32)) if norm else None
+    rv = torch.from_numpy(rs.standard_normal((B, H, W, Cout)).astype(np.float32)) * 2.0 if res else None
+    d = dev()
+    opt = lambda t: None if t is None else t.to(d)      # noqa: E731
+    y, stats = ops.conv3x3_block(x[..., :C0].contiguous().to(d), w.to(d), bias.to(d), x1=x[..., C0:].contiguous().to(d) if C1 else None,
+                                 nscale=opt(sc), nshift=opt(sh), res=opt(rv), out_scale=0.75, precision=precision, want_stats=True)
+    xd = x.double()
+    if norm:
+        xd = torch.nn.functional.silu(xd * sc.double()[:, None, None, :] + sh.double()[:, None, None, :])
+    ref = torch.nn.functional.conv2d(xd.permute(0, 3, 1, 2), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+    if rv is not None:
+        ref = ref + rv.double()
+    ref = ref * 0.75
+    yc = y.cpu().double()
+    err = (yc - ref).abs().max().item() / ref.abs().max().item()
+    yt = yc.reshape(B, H // 16, 16, W // 16, 16, Cout).permute(0, 1, 3, 2, 4, 5).reshape(-1, 256, Cout)
+    serr = (stats.cpu()[:, :, 0] - yt.sum(1)).abs().max().item() / yt.abs().sum(1).max().item()
+    return err, serr
+
+
+def test_conv3x3_block_shape_sweep_fp16x3():
+    """conv_xp.hip (the persistent software-pipelined form: every fp16x3 layer with an even number >= 4 of 16-channel stages) over a
+    seeded sweep of shapes: 96- and 64-cout groups, one and two sources, 1 .. 23 tiles per workgroup walk (grids smaller than,
+    equal to and larger than the CU count, tile counts that do not divide by the 8 XCDs), with and without the GroupNorm prologue and
+    the residual; the layers it does not cover (odd stage counts, two stages) ride along on conv_ff"""
+    rs = np.random.RandomState(2024)
+    worst = 0.0
+    shapes = [(1, 16, 16), (1, 16, 32), (3, 16, 16), (1, 48, 16), (2, 32, 48), (5, 16, 32), (1, 80, 80), (7, 32, 32), (2, 64, 96)]
+    chans = [(64, 0, 64), (96, 0, 96), (64, 64, 128), (96, 96, 96), (128, 0, 192), (32, 96, 64), (160, 32, 288), (128, 128, 256),
+             (80, 0, 96), (32, 0, 64), (48, 16, 192)]
+    n = 0
+    for (B, H, W) in shapes:
+        for k in rs.choice(len(chans), size=4, replace=False):
+            C0, C1, Cout = chans[k]
+            norm, res = bool(rs.randint(2)), bool(rs.randint(2))
+            err, serr = _block_case(rs, B, C0, C1, Cout, H, W, norm, res, 'fp16x3')
+            assert err < 3e-6 and serr < 1e-5, (B, H, W, C0, C1, Cout, norm, res, err, serr)
+            worst = max(worst, err)
+            n += 1
+    assert n == 36 and worst > 0
+
+
+def test_conv3x3_block_is_bitwise_repeatable_under_load():
+    """conv_xp.hip issues its matrix instructions as asm statements (no compiler-inserted wait states): 30 launches of a chip-filling
+    layer (8 x 160^2, 96 -> 96 and 64 + 64 -> 128, GroupNorm prologue + residual; several tiles per workgroup, hot chip) must be
+    bit-identical - a timing-dependent read of a matrix result would show up here"""
+    from conditional_score_diffusion_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(5)
+    for (C0, C1, Cout) in ((96, 0, 96), (64, 64, 128)):
+        B, H = 8, 160
+        Cin = C0 + C1
+        x = torch.randn(B, H, H, Cin, generator=g).to(d)
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).to(d)
+        bias = torch.randn(Cout, generator=g).to(d)
+        sc, sh = (torch.rand(B, Cin, generator=g) + 0.5).to(d), torch.randn(B, Cin, generator=g).to(d)
+        rv = torch.randn(B, H, H, Cout, generator=g).to(d)
+        x0, x1 = x[..., :C0].contiguous(), (x[..., C0:].contiguous() if C1 else None)
+        first = None
+        for _ in range(30):
+            y, st = ops.conv3x3_block(x0, w, bias, x1=x1, nscale=sc, nshift=sh, res=rv, precision='fp16x3', want_stats=True)
+            if first is None:
+                first = (y.clone(), st.clone())
+            else:
+                assert torch.equal(y, first[0]) and torch.equal(st, first[1])
+
+
 @pytest.mark.parametrize('precision,tol', [('fp16x3', 3e-6), ('fp16', 2e-3), ('fp16f8', 1e-4)])
 @pytest.mark.parametrize('B,C0,C1,Cout,H,W,norm,temb,res', [
     (2, 96, 0, 96, 32, 32, True, True, False),       # ResnetBlock Conv_0: GroupNorm + SiLU prologue, + Dense(temb)
