@@ -72,5 +72,8 @@ int convfx_launch(const ConvFFArgs& k, int nt, hipStream_t s);
 // conv_xp.hip: the fp16x3 form as one software-pipelined stream per SIMD (one 4-wave workgroup per CU, persistent)
 bool convxp_supported(const ConvFFArgs& k, int nt);
 int convxp_launch(const ConvFFArgs& k, int nt, hipStream_t s);
+// conv_xw.hip: conv_xp's stream in the 1-D Winograd F(2,3) form (4 instead of 6 contractions per output pair; its own packed weights)
+bool convxw_supported(const ConvFFArgs& k, int nt);
+int convxw_launch(const ConvFFArgs& k, int nt, hipStream_t s);
 
 }  // namespace csd

@@ -517,8 +517,17 @@ bool convff_pipelined(const ConvPlan& p, int ns) {
   return ns == 2 && convff_supported(p, ns) && nstage >= 4 && nstage % 2 == 0 && !CSD_TUNE_ENV("CSD_XP_OPS_OFF");
 }
 
+// the pipelined layers that run in the Winograd F(2,3) form (conv_xw.hip: 96-cout groups; transformed weights, 4 components x 3 filter
+// rows instead of 9 taps).  Tuning build: CSD_XW=0 keeps them on conv_xp.
+bool convff_winograd(const ConvPlan& p, int ns) {
+  if (!convff_pipelined(p, ns) || ff_nt(p.Cout) != 3) return false;
+  const char* xw = CSD_TUNE_ENV("CSD_XW");
+  return !(xw && atoi(xw) == 0);
+}
+
 size_t convff_packed_bytes(const ConvPlan& p, int ns) {
   const int nt = ff_nt(p.Cout);
+  if (convff_winograd(p, ns)) return (size_t)(p.Cout / (32 * nt)) * ((p.C0 + p.C1) / 16) * 12 * nt * 2 * 1024 + 4096;
   return (size_t)(p.Cout / (32 * nt)) * ((p.C0 + p.C1) / 16) * 9 * nt * (ns == 3 ? 2 : ns) * 1024 + 4096;
 }
 
@@ -557,6 +566,39 @@ __global__ void convff_pack_kernel(const float* __restrict__ w, _Float16* __rest
   }
 }
 
+// conv_xw.hip's weights: G0 = g0, G1 = (g0 + g1 + g2) / 2, G2 = (g0 - g1 + g2) / 2, G3 = g2 of every filter row (g0, g1, g2), in
+// [cout group][cin / 16][filter row][component][cout tile][hi | lo][lane][8 halves]; transform in double, one rounding to fp32, x 2^8
+__global__ void convxw_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ wpack, int layout, int cin_src, int cout_src,
+                                   int cout_off, int Cin, int Cout, int nt) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)cout_src * Cin * 3;
+  if (idx >= total) return;
+  const int r = (int)(idx % 3);
+  const int cin = (int)((idx / 3) % Cin);
+  const int co = (int)(idx / ((size_t)3 * Cin));
+  const int cout = cout_off + co;
+  if (cin >= cin_src || cout >= Cout) return;
+  double g[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int tap = r * 3 + t;
+    g[t] = (layout == 0) ? (double)w[((size_t)co * cin_src + cin) * 9 + tap] : (double)w[((size_t)cin * cout_src + co) * 9 + (8 - tap)];
+  }
+  const double G[4] = {g[0], 0.5 * (g[0] + g[1] + g[2]), 0.5 * (g[0] - g[1] + g[2]), g[2]};
+  const int gc = 32 * nt;
+  const int ng = cout / gc, t = (cout % gc) / 32, row = cout % 32;
+  const int kb = cin / 16, khalf = (cin % 16) / 8, e = cin % 8;
+  const size_t step = ((size_t)ng * (Cin / 16) + kb) * 3 + r;
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) {
+    const float v = (float)G[kc] * C16_WSCALE;
+    _Float16* dst = wpack + (((step * 4 + kc) * nt + t) * (size_t)2) * 512 + (khalf * 32 + row) * 8 + e;
+    const _Float16 hi = (_Float16)v;
+    dst[0] = hi;
+    dst[512] = (_Float16)(v - (float)hi);
+  }
+}
+
 __global__ void convff_zero_kernel(uint32_t* p, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0u;
@@ -571,6 +613,14 @@ int convff_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, in
     const size_t n32 = convff_packed_bytes(p, ns) / 4;
     hipLaunchKernelGGL(convff_zero_kernel, dim3((unsigned)cdiv64(n32, 256)), dim3(256), 0, s, (uint32_t*)wpack, n32);
     CSD_LAUNCH_CHECK();
+  }
+  if (convff_winograd(p, ns)) {
+    CSD_REQUIRE(layout == 0 || layout == 2, "convff: the Winograd pack takes 3x3 weights");
+    const size_t total3 = (size_t)cout_src * Cin * 3;
+    hipLaunchKernelGGL(convxw_pack_kernel, dim3((unsigned)cdiv64(total3, 256)), dim3(256), 0, s, w, (_Float16*)wpack, layout, cin_src,
+                       cout_src, cout_off, Cin, p.Cout, ff_nt(p.Cout));
+    CSD_LAUNCH_CHECK();
+    return CSD_OK;
   }
   const size_t total = (size_t)cout_src * Cin * 9;
   hipLaunchKernelGGL(convff_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w, (_Float16*)wpack, layout,
@@ -641,6 +691,11 @@ int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
     const char* fx = CSD_TUNE_ENV("CSD_FX");
     const bool use_fx = fx ? atoi(fx) != 0 : k.nstage >= 12;
     if (ns == 3 && use_fx && k.nstage >= 2 * nt) return convfx_launch(k, nt, s);
+  }
+  // conv_xw.hip: conv_xp's stream in the Winograd F(2,3) form (the weights were packed for it: convff_winograd is the one switch)
+  if (convff_winograd(p, ns)) {
+    CSD_REQUIRE(convxw_supported(k, nt), "convff: Winograd layer outside conv_xw's range");
+    return convxw_launch(k, nt, s);
   }
   // conv_xp.hip (fp16x3: one persistent 4-wave workgroup per CU, the conversion / fragment reads / weight staging placed between
   // the MFMA chains of ONE instruction stream per SIMD).  Tuning build: CSD_XP=0 disables it.

@@ -236,7 +236,8 @@ extern "C" size_t csd_conv3x3_block_scratch_bytes(int Cin, int Cout) {
   ConvPlan p;
   memset(&p, 0, sizeof(p));
   p.C0 = Cin; p.Cout = Cout;
-  return convff_packed_bytes(p, 2) + 256;
+  // (the shape is not known here: sized for the Winograd pack of conv_xw.hip - 12 instead of 9 fragment sets per 16 channels)
+  return convff_packed_bytes(p, 2) / 3 * 4 + 4096 + 256;
 }
 
 extern "C" int csd_conv3x3_block(const float* x0, const float* x1, const float* weight, const float* bias, const float* nscale,
