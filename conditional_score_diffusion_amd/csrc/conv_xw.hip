@@ -106,8 +106,16 @@ struct XWSched {
   static constexpr bool rd_wlB(int g) { return g < RW; }                                             // wl[RW + g] of THIS tap (into the register MFMA g just read)
   static constexpr bool rd_wlA(int g) { return g >= GP - RW; }                                       // wl[g - (GP - RW)] of the NEXT tap
   static constexpr bool rd_xh(int g) { return g >= 2 * PB && (g - 2 * PB) % 2 == 0 && (g - 2 * PB) / 2 < 4; }      // xh[(g - 2 PB) / 2] of the next tap
-  static constexpr bool put(int g) { return g >= PB && g < 2 * PB && (g - PB) % 2 == 1 && (g - PB) / 2 < WPT; }    // ring store of piece (g - PB) / 2
-  static constexpr bool req(int g) { return g >= 2 * PB && (g - 2 * PB) % 2 == 1 && (g - 2 * PB) / 2 < WPT; }      // request of piece (g - 2 PB) / 2
+  // the weight ring: a row tap stores the WPT pieces of the tap two ahead in two halves of WH through the same WH registers -
+  // half A (requested at the end of the tap before) in gaps PA + 2 q, half B requested right behind (gaps PA + 1 + 2 q) and stored in
+  // gaps PB2 + 2 q, the next tap's half A requested right behind those (gaps PB2 + 1 + 2 q)
+  static constexpr int WH = WPT / 2, PA = PB - 3, PB2 = 2 * PB + 4;
+  static constexpr bool in_a(int g) { return g >= PA && g < PA + 2 * WH; }
+  static constexpr bool in_b(int g) { return g >= PB2 && g < PB2 + 2 * WH; }
+  static constexpr bool put(int g) { return (in_a(g) && (g - PA) % 2 == 0) || (in_b(g) && (g - PB2) % 2 == 0); }
+  static constexpr bool req(int g) { return (in_a(g) && (g - PA) % 2 == 1) || (in_b(g) && (g - PB2) % 2 == 1); }
+  static constexpr int wq(int g) { return in_a(g) ? (g - PA) / 2 : (g - PB2) / 2; }      // register of the piece
+  static constexpr int wpiece(int g) { return in_a(g) ? (g - PA) / 2 : WH + (g - PB2) / 2; }      // piece stored in gap g
   static constexpr int fixed(int g) { return (rd_wh(g) ? 1 : 0) + (rd_xl(g) ? 1 : 0) + (rd_wlA(g) ? 1 : 0) + (rd_wlB(g) ? 1 : 0) + (rd_xh(g) ? 1 : 0) + (put(g) ? 1 : 0) + (req(g) ? 1 : 0); }
   // the conversion's micro-operations go where the fixed fillers leave room: weight of a gap = 14 - 3 fixed (thirds of an issue slot)
   static constexpr int wgt(int g) { return 14 - 3 * fixed(g) > 2 ? 14 - 3 * fixed(g) : 2; }
@@ -166,6 +174,11 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
     return t;
   };
 
+  // Per-lane values that only the once-per-tile code needs are recomputed there from a FRESH lane id (two instructions): kept in
+  // registers across the stream they would be spilled - and a reload from scratch memory waits for every outstanding request.
+  // (an asm volatile statement on the lane id makes what is derived from it opaque: hipcc can neither hoist it out of the tile loop
+  // nor merge it with the prologue's copy of the same arithmetic)
+  auto fresh_lane = [&]() __attribute__((always_inline)) { int l = lane; asm volatile("" : "+v"(l)); return l; };
   constexpr unsigned OOB = 0x80000000u;
   constexpr int RSRC_FLAGS = 0x00020000;
   constexpr float NLOG2E = -1.4426950408889634f;
@@ -192,9 +205,10 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
   struct Geom { int pa[3], pb[3]; };
   auto geom_of = [&](const Tile& t) __attribute__((always_inline)) {
     Geom g;
+    const int ulf = fresh_lane() >> 2;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int U = 15 * (4 * j + wave) + ul;
+      const int U = 15 * (4 * j + wave) + ulf;
       const int Uc = U < XW_NU ? U : XW_NU - 1;
       const int pr = Uc / 9, u = Uc - pr * 9;
       const int y = t.ty0 - 1 + pr, xa = t.tx0 - 1 + 2 * u;
@@ -256,67 +270,77 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
   // piece i = q * 4 + wave of a row tap.  The scalar offset runs (asm add) and is re-based when the stream moves to the next tile.
   const __amdgpu_buffer_rsrc_t w_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g_wpack), 0, OOB, RSRC_FLAGS);
   const int wvoff = lane * 16 + wave * 1024;
-  xw_u4 wr[WPT];
+  constexpr int WH = S::WH;
+  xw_u4 wr[WH];
   int w_run = 0;
   const int c4096 = 4096;
   auto w_begin = [&](int wso) __attribute__((always_inline)) { w_run = wso; };
-  auto req_w = [&](int q) __attribute__((always_inline)) {      // q: 0 .. WPT - 1, in order, once per row tap
+  auto req_w = [&](int q) __attribute__((always_inline)) {      // the next piece of the stream into register q
     if (XW_ABL & 2) return;
     wr[q] = __builtin_amdgcn_raw_buffer_load_b128(w_r, (unsigned)wvoff, w_run, 0);
     XW_SADD(w_run, c4096);
   };
-  auto put_w = [&](int q, int slot) __attribute__((always_inline)) {
+  auto put_w = [&](int q, int piece, int slot) __attribute__((always_inline)) {
     if (XW_ABL & 2) return;
-    *reinterpret_cast<xw_u4*>(smem + C::slot_off(slot) + q * 4096 + wvoff) = wr[q];
+    *reinterpret_cast<xw_u4*>(smem + C::slot_off(slot) + piece * 4096 + wvoff) = wr[q];
   };
 
   // ---- conversion of a slot, as a sequence of single operations (placed one by one between the MFMAs) ----
-  // The slot's 4 channels are worked in two halves of 2 (a half = 4 values: pixels a, b x 2 channels).  Per half, "pre" = affine (4) |
-  // exp2 (4) | 1 + (4) | rcp (4) | u * (4) | zero padding (4) | neighbour values (4), "post" = the four components (8) | hi pack (4) |
-  // lo (8) | lo pack (4).  Order: pre 0, pre 1, post 0, post 1 - a half's neighbour values (an LDS round trip) are not needed
-  // before the other half's pre is through.  Without the GroupNorm prologue pre = padding + neighbour values only.
-  constexpr int NPRE = NORM ? 28 : 8, NPOST = 24, NMATH = 2 * NPRE + 2 * NPOST;
-  float cv[2][4], ce[2][4], cn[2][4], cd[4][2], cl[4][2];      // [half][a0 a1 b0 b1]; [component][channel of the half]
-  int chp[4][2], clp[4][2];                                    // packed hi | lo of [component][half]
+  // "pre": per value (8 = pixels a, b x 4 channels) the chain affine > exp2 > 1 + > rcp > u * > zero padding > neighbour value; emitted
+  // along the diagonals of the (value, phase) table, so that a dependent operation sits 7 operations behind its producer and the
+  // transcendentals (12.8 cycles of issue each, two per MFMA gap ride free - tools/filler_cost_probe.hip) are spread out.
+  // "post", per half of the channels (2 of the lane's 4): the four components (8) | hi pack (4) | lo (8) | lo pack (4).
+  // Without the GroupNorm prologue pre = padding + neighbour values only.
+  constexpr int NPH = NORM ? 7 : 2, NPRE = 8 * NPH, NPOST = 24, NMATH = NPRE + 2 * NPOST;
+  struct PreOrder {
+    int val[8 * 7], ph[8 * 7];
+    constexpr PreOrder(int nph) : val{}, ph{} {
+      int n = 0;
+      for (int d = 0; d < nph + 7; ++d)
+        for (int i = 0; i < 8; ++i)
+          if (d - i >= 0 && d - i < nph) { val[n] = i; ph[n] = d - i; ++n; }
+    }
+  };
+  constexpr PreOrder PRE(NPH);
+  float cv[8], ce[8], cn[8], cd[4][2], cl[4][2];     // values: a0..a3 b0..b3 (index = 4 * (b) + channel); [component][channel of the half]
+  int chp[4][2], clp[4][2];                          // packed hi | lo of [component][half]
   auto math_op = [&](auto j_tag, auto o_tag, const Geom& g) __attribute__((always_inline)) {
     constexpr int j = decltype(j_tag)::value, ol = decltype(o_tag)::value;
     if (XW_ABL & 1) return;
-    constexpr bool PRE = ol < 2 * NPRE;
-    constexpr int hh = PRE ? ol / NPRE : (ol - 2 * NPRE) / NPOST;                      // the half
-    constexpr int o = PRE ? ol % NPRE + (NORM ? 0 : 20) : (ol - 2 * NPRE) % NPOST;     // the operation inside pre | post
-    if constexpr (PRE) {
-      constexpr int i = o & 3, c = 2 * hh + (i & 1);      // value i of the half: a (i < 2) | b, channel c of the lane's four
-      if constexpr (o < 4) {
-        const float x = __uint_as_float(i < 2 ? pfa[j][c] : pfb[j][c]);
-        cv[hh][i] = fmaf(x, msc[c], msh[c]);
-        XW_PIN(cv[hh][i]);
-      } else if constexpr (o < 8) {
-        ce[hh][i] = __builtin_amdgcn_exp2f(cv[hh][i]);
-        XW_PIN(ce[hh][i]);
-      } else if constexpr (o < 12) {
-        ce[hh][i] = 1.0f + ce[hh][i];
-        XW_PIN(ce[hh][i]);
-      } else if constexpr (o < 16) {
-        ce[hh][i] = __builtin_amdgcn_rcpf(ce[hh][i]);
-        XW_PIN(ce[hh][i]);
-      } else if constexpr (o < 20) {
-        cv[hh][i] = cv[hh][i] * ce[hh][i];
-        XW_PIN(cv[hh][i]);
-      } else if constexpr (o < 24) {                 // padding applies to the ACTIVATED tensor: exactly 0
-        const int m = (i < 2 ? g.pa[j] : g.pb[j]) >> 31;
-        const int raw = NORM ? __float_as_int(cv[hh][i]) : (int)(i < 2 ? pfa[j][c] : pfb[j][c]);
-        cv[hh][i] = __int_as_float(raw & m);
-        XW_PIN(cv[hh][i]);
+    if constexpr (ol < NPRE) {
+      constexpr int i = PRE.val[ol], c = i & 3, o = PRE.ph[ol] + (NORM ? 0 : 5);      // value i (a: i < 4), channel c, phase o
+      if constexpr (o == 0) {
+        const float x = __uint_as_float(i < 4 ? pfa[j][c] : pfb[j][c]);
+        cv[i] = fmaf(x, msc[c], msh[c]);
+        XW_PIN(cv[i]);
+      } else if constexpr (o == 1) {
+        ce[i] = __builtin_amdgcn_exp2f(cv[i]);
+        XW_PIN(ce[i]);
+      } else if constexpr (o == 2) {
+        ce[i] = 1.0f + ce[i];
+        XW_PIN(ce[i]);
+      } else if constexpr (o == 3) {
+        ce[i] = __builtin_amdgcn_rcpf(ce[i]);
+        XW_PIN(ce[i]);
+      } else if constexpr (o == 4) {
+        cv[i] = cv[i] * ce[i];
+        XW_PIN(cv[i]);
+      } else if constexpr (o == 5) {                 // padding applies to the ACTIVATED tensor: exactly 0
+        const int m = (i < 4 ? g.pa[j] : g.pb[j]) >> 31;
+        const int raw = NORM ? __float_as_int(cv[i]) : (int)(i < 4 ? pfa[j][c] : pfb[j][c]);
+        cv[i] = __int_as_float(raw & m);
+        XW_PIN(cv[i]);
       } else {                                       // the neighbour unit's value (not pinned: the wait belongs in front of its use)
-        cn[hh][i] = __int_as_float(__builtin_amdgcn_ds_bpermute(nb_addr, __float_as_int(cv[hh][i])));
+        cn[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(nb_addr, __float_as_int(cv[i])));
       }
     } else {
+      constexpr int hh = (ol - NPRE) / NPOST, o = (ol - NPRE) % NPOST;      // the half: channels 2 hh, 2 hh + 1
       if constexpr (o < 8) {
-        constexpr int kc = o >> 1, c = o & 1;
-        if constexpr (kc == 0) cd[0][c] = cv[hh][c] - cn[hh][c];               // d0 - d2
-        else if constexpr (kc == 1) cd[1][c] = cv[hh][2 + c] + cn[hh][c];      // d1 + d2
-        else if constexpr (kc == 2) cd[2][c] = cn[hh][c] - cv[hh][2 + c];      // d2 - d1
-        else cd[3][c] = cv[hh][2 + c] - cn[hh][2 + c];                         // d1 - d3
+        constexpr int kc = o >> 1, c = o & 1, ca = 2 * hh + c, cb = 4 + ca;
+        if constexpr (kc == 0) cd[0][c] = cv[ca] - cn[ca];               // d0 - d2
+        else if constexpr (kc == 1) cd[1][c] = cv[cb] + cn[ca];          // d1 + d2
+        else if constexpr (kc == 2) cd[2][c] = cn[ca] - cv[cb];          // d2 - d1
+        else cd[3][c] = cv[cb] - cn[cb];                                 // d1 - d3
         XW_PIN(cd[kc][c]);
       } else if constexpr (o < 12) {
         constexpr int kc = o - 8;
@@ -414,20 +438,20 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
   const int res_col = kCout * 4, res_row = (kW - 7) * kCout * 4, out_col = a_out_stride * 4, out_row = (kW - 7) * a_out_stride * 4;
   int res_run = 0;
   const __amdgpu_buffer_rsrc_t bias_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_bias ? a_bias : a_src0), 0, a_bias ? OOB : 0u, RSRC_FLAGS);
-  auto epi_setup = [&](const Tile& t) __attribute__((always_inline)) {
+  auto epi_setup = [&](const Tile& t) __attribute__((always_inline)) {      // scalars only
     const size_t tile_pix = (size_t)t.b * kH * kW + (size_t)t.ty0 * kW + t.tx0;
-    const int c_lane = t.ng * NT * 32 + p32;
     out_r = __builtin_amdgcn_make_buffer_rsrc(a_out + tile_pix * a_out_stride + a_out_coff, 0, OOB, RSRC_FLAGS);
-    out_voff = (unsigned)((4 * wave * kW + 8 * kh) * a_out_stride + c_lane) * 4u;
     e_tile = t.tile; e_ng = t.ng;
     if constexpr (RES) {
       res_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_res + tile_pix * kCout), 0, OOB, RSRC_FLAGS);
-      res_voff = (unsigned)((4 * wave * kW + 8 * kh) * kCout + c_lane) * 4u;
       res_run = 0;
     }
   };
-  auto epi_loads = [&](const Tile& t) __attribute__((always_inline)) {      // under the tile's last tap
-    const int c_lane = t.ng * NT * 32 + p32;
+  auto epi_loads = [&](const Tile& t) __attribute__((always_inline)) {      // under the tile's last tap: the per-lane offsets, bias, temb
+    const int lf = fresh_lane();
+    const int c_lane = t.ng * NT * 32 + (lf & 31);
+    out_voff = (unsigned)((4 * wave * kW + 8 * (lf >> 5)) * a_out_stride + c_lane) * 4u;
+    if constexpr (RES) res_voff = (unsigned)((4 * wave * kW + 8 * (lf >> 5)) * kCout + c_lane) * 4u;
     // (a null bias / temb reads as zeros through an empty descriptor: no branch in the stream)
     const __amdgpu_buffer_rsrc_t tb_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_temb ? a_temb + (size_t)t.b * a_temb_stride : a_src0), 0,
                                                                            a_temb ? OOB : 0u, RSRC_FLAGS);
@@ -455,7 +479,7 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
       for (int e = 8 * NT; e < 32 * NT; ++e) req_res(e);
     }
     tie_acc_done();
-    XW_TS(22);
+    XW_TS(23);
     float vs[NT], vq[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) vs[nt] = vq[nt] = 0.f;
@@ -494,31 +518,32 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
         else if (row != 3) XW_SADD(out_run, out_row);
       }
     }
-    XW_TS(23);
+    XW_TS(24);
     if (a_stats) {
+      const int lf = fresh_lane(), tidf = wave * 64 + lf;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         vs[nt] += __shfl_xor(vs[nt], 32);
         vq[nt] += __shfl_xor(vq[nt], 32);
-        if (kh == 0) {
-          red[(wave * NT * 32 + nt * 32 + p32) * 2 + 0] = vs[nt];
-          red[(wave * NT * 32 + nt * 32 + p32) * 2 + 1] = vq[nt];
+        if (lf < 32) {
+          red[(wave * NT * 32 + nt * 32 + lf) * 2 + 0] = vs[nt];
+          red[(wave * NT * 32 + nt * 32 + lf) * 2 + 1] = vq[nt];
         }
       }
       ff_barrier();
-      if (tid < NT * 32) {
+      if (tidf < NT * 32) {
         double sm = 0.0, sq = 0.0;
 #pragma unroll
         for (int wv = 0; wv < 4; ++wv) {
-          sm += (double)red[(wv * NT * 32 + tid) * 2 + 0];
-          sq += (double)red[(wv * NT * 32 + tid) * 2 + 1];
+          sm += (double)red[(wv * NT * 32 + tidf) * 2 + 0];
+          sq += (double)red[(wv * NT * 32 + tidf) * 2 + 1];
         }
-        double* dst = a_stats + ((size_t)e_tile * kCout + e_ng * NT * 32 + tid) * 2;
+        double* dst = a_stats + ((size_t)e_tile * kCout + e_ng * NT * 32 + tidf) * 2;
         dst[0] = sm;
         dst[1] = sq;
       }
     }
-    XW_TS(24);
+    XW_TS(25);
   };
 
   Tile tc = tile_at(0), tn = tile_at(1);
@@ -548,14 +573,14 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
     cvt_prep_half(0); cvt_prep_half(1);
     xw_static_for<NMATH>([&](auto o) __attribute__((always_inline)) { math_op(J0{}, o, gc); });
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int h = 0; h < 4; ++h) {                    // row taps 0 and 1, half by half
 #pragma unroll
-      for (int q = 0; q < WPT; ++q) req_w(q);
+      for (int q = 0; q < WH; ++q) req_w(q);
 #pragma unroll
-      for (int q = 0; q < WPT; ++q) put_w(q, r);
+      for (int q = 0; q < WH; ++q) put_w(q, (h & 1) * WH + q, h >> 1);
     }
 #pragma unroll
-    for (int q = 0; q < WPT; ++q) req_w(q);
+    for (int q = 0; q < WH; ++q) req_w(q);           // half A of row tap 2
   }
   ff_barrier();
 #pragma unroll
@@ -591,6 +616,7 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
       xw_static_for<GP>([&](auto g_tag) __attribute__((always_inline)) {
         constexpr int g = decltype(g_tag)::value;
         XW_FENCE();
+        if constexpr (g % NA == 0) { if (s == 2) XW_TS(14 + R * 3 + g / NA); }      // (tuning build: the nine products of unit 2)
         if constexpr (FIRST && R == 0 && g < NA) mm_first(g);
         else mm(g / NA, g % NA);
         XW_FENCE();
@@ -600,14 +626,14 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
         if constexpr (S::rd_wlB(g)) rd_w(wl[g], R, RW + g, 1);
         if constexpr (S::rd_wlA(g)) rd_w(wl[g - (GP - RW)], (R + 1) % 3, g - (GP - RW), 1);
         if constexpr (S::rd_xh(g)) rd_x(xh[(g - 2 * PB) / 2], R == 2 ? xb_nxt : xb_cur, (R + 1) % 3, (g - 2 * PB) / 2, 0);
-        if constexpr (S::put(g)) put_w((g - PB) / 2, (R + 2) % 3);
-        if constexpr (S::req(g)) req_w((g - 2 * PB) / 2);
+        if constexpr (S::put(g)) put_w(S::wq(g), S::wpiece(g), (R + 2) % 3);
+        if constexpr (S::req(g)) req_w(S::wq(g));
         // ---- scalar set-up of the stage, in the first gaps of tap 0 ----
         if constexpr (R == 0) {
           if constexpr (g == 0) src_of(tl, sl);
-          if constexpr (g == 1) req_norm(tl, sl);
           if constexpr (g == 2 && POS == 1) epi_setup(tc);
         }
+        if constexpr (R == 1 && g == PB + PB / 2) req_norm(tl, sl);                     // (used by tap 2's first operations)
         if constexpr (R == 2 && POS == 2 && g == PB) epi_loads(tc);
         if constexpr (R == 0 && POS == 2 && g == 2 * PB) w_begin(tn.ng * NSTB);      // (this unit's requests are the next tile's stage 0)
         // ---- the conversion's operations of this gap ----
@@ -654,6 +680,8 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
     ts_on = it == 1;
     if (it == 1) XW_WALL(28);
     if (it == 2) XW_WALL(29);
+    if (it == 1 && a_dbg && tid == 0) a_dbg[blockIdx.x * 32 + 26] = clock64();
+    if (it == 2 && a_dbg && tid == 0) a_dbg[blockIdx.x * 32 + 27] = clock64();
 #endif
     unit(P0{}, Yes{}, 0);
     for (int s = 1; s + 2 < NS; ++s) unit(P0{}, No{}, s);
