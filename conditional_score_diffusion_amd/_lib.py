@@ -187,9 +187,19 @@ def profile_stop():
     return {PROF_CLASSES[i]: {'ms': ms[i], 'launches': la[i], 'flops': fl[i], 'bytes': by[i]} for i in range(n)}
 
 
+ERR_NONFINITE = -6            # include/csd.h CSD_ERR_NONFINITE
+
+
+class NonFiniteError(FloatingPointError, RuntimeError):
+    """the fused sampler's state (or a Langevin norm) left the finite range: an fp16-operand arithmetic mode met an operand beyond
+    65504 - run the network with ``config.model.csd_precision = 'fp32'`` (include/csd.h, csd_pc_sample's finiteness contract)"""
+
+
 def check(rc, what=''):
     if rc != 0:
         msg = lib().csd_last_error().decode('utf-8', 'replace')
+        if rc == ERR_NONFINITE:
+            raise NonFiniteError('libcsd_hip %s: %s' % (what, msg))
         raise RuntimeError('libcsd_hip %s failed (status %d): %s' % (what, rc, msg))
 
 

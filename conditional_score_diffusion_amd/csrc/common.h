@@ -289,11 +289,12 @@ int sumsq_rows_launch(const float* net, int64_t net_stride, const float* z, doub
                       int64_t per, int nchunk, hipStream_t s);
 int langevin_update_launch(float* x, float* x_mean, const float* net, int64_t net_stride, const float* z,
                            const double* partial, int nchunk, float std, float snr, float alpha, int B,
-                           int64_t per, hipStream_t s);
+                           int64_t per, hipStream_t s, int* nonfinite = nullptr);
+int finite_check_launch(const float* x, size_t total, int* nonfinite, hipStream_t s);
 int norm_sums_launch(const double* partial, int nchunk, float std, int B, float* sums, hipStream_t s);
 int langevin_update_global_launch(float* x, float* x_mean, const float* net, int64_t net_stride, const float* z,
                                   const float* sums, int Bg, float std, float snr, float alpha, int B, int64_t per,
-                                  hipStream_t s);
+                                  hipStream_t s, int* nonfinite = nullptr);
 int affine_net_update_launch(float* x, float* x_mean, const float* net, int64_t net_stride, const float* z, float std, float p,
                              float a, float c, int B, int64_t per, hipStream_t s);
 int reverse_diffusion_update_launch(float* x, float* x_mean, const float* net, int64_t net_stride,

@@ -83,7 +83,8 @@ __device__ __forceinline__ float xw_lo(int hp, float v) {      // v - (float)hal
 #define XW_SADD(x, y) asm volatile("s_add_u32 %0, %0, %1" : "+s"(x) : "s"(y) : "scc")
 #define XW_PIN(a) asm volatile("" : "+v"(a))
 // tuning aids (never in the product library): XW_ABL bits remove parts of the stream at compile time (results are then garbage):
-// 1 conversion, 2 weight staging, 4 fragment reads, 8 epilogue stores, 16 patch requests, 32 residual requests, 64 barriers
+// 1 conversion, 2 weight staging, 4 fragment reads, 8 epilogue stores, 16 patch requests, 32 residual requests, 64 barriers,
+// 4096 patch requests confined to the first 256 pixels of the sample (cache hits), 256 patch stores, 512 neighbour exchange (own value instead), 1024 transcendentals (plain multiplies instead), 2048 hi | lo split
 #ifndef XW_ABL
 #define XW_ABL 0
 #endif
@@ -242,10 +243,10 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
     soffL = (s1 ? cb - kC0 : cb) * 4;
   };
   auto req_a = [&](int j, const Geom& g) __attribute__((always_inline)) {
-    if (!(XW_ABL & 16)) pfa[j] = __builtin_amdgcn_raw_buffer_load_b128(srcL, __umul24(g.pa[j], strideL) + lg * 16, soffL, 0);
+    if (!(XW_ABL & 16)) pfa[j] = __builtin_amdgcn_raw_buffer_load_b128(srcL, __umul24((XW_ABL & 4096) ? (g.pa[j] & 255) : g.pa[j], strideL) + lg * 16, soffL, 0);
   };
   auto req_b = [&](int j, const Geom& g) __attribute__((always_inline)) {
-    if (!(XW_ABL & 16)) pfb[j] = __builtin_amdgcn_raw_buffer_load_b128(srcL, __umul24(g.pb[j], strideL) + lg * 16, soffL, 0);
+    if (!(XW_ABL & 16)) pfb[j] = __builtin_amdgcn_raw_buffer_load_b128(srcL, __umul24((XW_ABL & 4096) ? (g.pb[j] & 255) : g.pb[j], strideL) + lg * 16, soffL, 0);
   };
   const __amdgpu_buffer_rsrc_t nsc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(NORM ? k.a.nscale : a_src0), 0, OOB, RSRC_FLAGS);
   const __amdgpu_buffer_rsrc_t nsh_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(NORM ? k.a.nshift : a_src0), 0, OOB, RSRC_FLAGS);
@@ -314,13 +315,13 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
         cv[i] = fmaf(x, msc[c], msh[c]);
         XW_PIN(cv[i]);
       } else if constexpr (o == 1) {
-        ce[i] = __builtin_amdgcn_exp2f(cv[i]);
+        ce[i] = (XW_ABL & 1024) ? cv[i] * 1.5f : __builtin_amdgcn_exp2f(cv[i]);
         XW_PIN(ce[i]);
       } else if constexpr (o == 2) {
         ce[i] = 1.0f + ce[i];
         XW_PIN(ce[i]);
       } else if constexpr (o == 3) {
-        ce[i] = __builtin_amdgcn_rcpf(ce[i]);
+        ce[i] = (XW_ABL & 1024) ? ce[i] * 0.7f : __builtin_amdgcn_rcpf(ce[i]);
         XW_PIN(ce[i]);
       } else if constexpr (o == 4) {
         cv[i] = cv[i] * ce[i];
@@ -331,7 +332,8 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
         cv[i] = __int_as_float(raw & m);
         XW_PIN(cv[i]);
       } else {                                       // the neighbour unit's value (not pinned: the wait belongs in front of its use)
-        cn[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(nb_addr, __float_as_int(cv[i])));
+        if (XW_ABL & 512) { cn[i] = cv[i] * 0.5f; XW_PIN(cn[i]); }
+        else cn[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(nb_addr, __float_as_int(cv[i])));
       }
     } else {
       constexpr int hh = (ol - NPRE) / NPOST, o = (ol - NPRE) % NPOST;      // the half: channels 2 hh, 2 hh + 1
@@ -344,14 +346,17 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
         XW_PIN(cd[kc][c]);
       } else if constexpr (o < 12) {
         constexpr int kc = o - 8;
+        if (XW_ABL & 2048) { chp[kc][hh] = __float_as_int(cd[kc][0]); clp[kc][hh] = __float_as_int(cd[kc][1]); return; }
         chp[kc][hh] = xw_pack_f16(cd[kc][0], cd[kc][1]);
         XW_PIN(chp[kc][hh]);
       } else if constexpr (o < 20) {
+        if (XW_ABL & 2048) return;
         constexpr int kc = (o - 12) >> 1, c = (o - 12) & 1;
         if constexpr (c == 0) cl[kc][0] = xw_lo<false>(chp[kc][hh], cd[kc][0]);
         else cl[kc][1] = xw_lo<true>(chp[kc][hh], cd[kc][1]);
         XW_PIN(cl[kc][c]);
       } else {
+        if (XW_ABL & 2048) return;
         constexpr int kc = o - 20;
         clp[kc][hh] = xw_pack_f16(cl[kc][0], cl[kc][1]);
         XW_PIN(clp[kc][hh]);
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
   // the eight stores of a slot: component kc hi (o = kc), lo (o = 4 + kc), into the patch buffer `par1` (0 | 1)
   auto write_op = [&](auto j_tag, auto o_tag) __attribute__((always_inline)) {
     constexpr int j = decltype(j_tag)::value, o = decltype(o_tag)::value;
-    if (XW_ABL & 1) return;
+    if (XW_ABL & (1 | 256)) return;
     constexpr int kc = o & 3, pl = o >> 2;
     char* const rec = smem + s_dst[j] + kc * 512 + pl * 32;
     if constexpr (pl == 0) *reinterpret_cast<int2*>(rec) = make_int2(chp[kc][0], chp[kc][1]);

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(float* __restrict_
                                                               int64_t net_stride, const float* __restrict__ z,
                                                               const double* __restrict__ partial, int nchunk,
                                                               float std, float snr, float alpha, int B, int64_t per,
-                                                              size_t total) {
+                                                              size_t total, int* __restrict__ nonfinite) {
   __shared__ float s_step;
   if (threadIdx.x < 64) {
     // fold partials: lanes stride over samples; each lane folds its samples' chunks in order
@@ -89,6 +89,9 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(float* __restrict_
       const float gbar = (float)(g / B), nbar = (float)(n / B);
       const float r = snr * nbar / gbar;
       s_step = r * r * 2.f * alpha;  // (snr*nbar/gbar)**2 * 2 * alpha; alpha = 1 for the VE SDEs, sde.alphas[timestep] for VP / subVP
+      // the finiteness contract of the fused loop: the norms see every element of the score and of the noise, so a NaN / Inf
+      // anywhere (an fp16-operand mode past its range) shows here at no cost; csd_pc_sample reports the flag at its final sync
+      if (blockIdx.x == 0 && nonfinite && !(fabsf(s_step) <= 3.0e38f)) *nonfinite = 1;
     }
   }
   __syncthreads();
@@ -131,10 +134,12 @@ __global__ __launch_bounds__(256) void langevin_update_global_kernel(float* __re
                                                                      const float* __restrict__ net, int64_t net_stride,
                                                                      const float* __restrict__ z,
                                                                      const float* __restrict__ sums, int Bg, float std,
-                                                                     float snr, float alpha, int64_t per, size_t total) {
+                                                                     float snr, float alpha, int64_t per, size_t total,
+                                                                     int* __restrict__ nonfinite) {
   const float gbar = sums[0] / (float)Bg, nbar = sums[1] / (float)Bg;
   const float r = snr * nbar / gbar;
   const float step = r * r * 2.f * alpha;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nonfinite && !(fabsf(step) <= 3.0e38f)) *nonfinite = 1;
   const float nz = sqrtf(step * 2.f);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t b = i / (size_t)per;
@@ -244,7 +249,20 @@ __global__ void scale_rows_kernel(float* __restrict__ out, const float* __restri
   }
 }
 
+// the finiteness contract for loops without a Langevin corrector, and for the state the loop returns: one pass over x at the END
+__global__ __launch_bounds__(256) void finite_check_kernel(const float* __restrict__ x, size_t total, int* __restrict__ nonfinite) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) bad |= !(fabsf(x[i]) <= 3.0e38f);
+  if (bad) *nonfinite = 1;
+}
+
 static int ew_grid(size_t total) { return (int)std::min<size_t>(cdiv64(total, 256), 4096); }
+
+int finite_check_launch(const float* x, size_t total, int* nonfinite, hipStream_t s) {
+  hipLaunchKernelGGL(finite_check_kernel, dim3(ew_grid(total)), dim3(256), 0, s, x, total, nonfinite);
+  CSD_LAUNCH_CHECK();
+  return CSD_OK;
+}
 
 int sumsq_rows_launch(const float* net, int64_t net_stride, const float* z, double* partial, int B, int64_t per,
                       int nchunk, hipStream_t s) {
@@ -256,10 +274,10 @@ int sumsq_rows_launch(const float* net, int64_t net_stride, const float* z, doub
 
 int langevin_update_launch(float* x, float* x_mean, const float* net, int64_t net_stride, const float* z,
                            const double* partial, int nchunk, float std, float snr, float alpha, int B, int64_t per,
-                           hipStream_t s) {
+                           hipStream_t s, int* nonfinite) {
   const size_t total = (size_t)B * per;
   hipLaunchKernelGGL(langevin_update_kernel, dim3(ew_grid(total)), dim3(256), 0, s, x, x_mean, net, net_stride, z,
-                     partial, nchunk, std, snr, alpha, B, per, total);
+                     partial, nchunk, std, snr, alpha, B, per, total, nonfinite);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
@@ -272,10 +290,10 @@ int norm_sums_launch(const double* partial, int nchunk, float std, int B, float*
 
 int langevin_update_global_launch(float* x, float* x_mean, const float* net, int64_t net_stride, const float* z,
                                   const float* sums, int Bg, float std, float snr, float alpha, int B, int64_t per,
-                                  hipStream_t s) {
+                                  hipStream_t s, int* nonfinite) {
   const size_t total = (size_t)B * per;
   hipLaunchKernelGGL(langevin_update_global_kernel, dim3(ew_grid(total)), dim3(256), 0, s, x, x_mean, net, net_stride, z,
-                     sums, Bg, std, snr, alpha, per, total);
+                     sums, Bg, std, snr, alpha, per, total, nonfinite);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }

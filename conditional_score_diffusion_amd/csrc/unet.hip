@@ -1945,6 +1945,7 @@ struct PCCtx {
   Net* n; Plan* pl; const float* pk; float* ws;
   float *net_out, *x_mean, *z, *zy, *labels, *ystate;
   double* partial;
+  int* nonfinite;                                    // device flag of the finiteness contract (behind the norm partials)
   bool path = false;                                 // use_path: y_t follows the bridge (csd_pc_params.path_coef)
   const csd_pc_params* p;
   float* x; const float* y;
@@ -2018,6 +2019,7 @@ static int pc_setup(PCCtx* c, csd_unet* net, const void* packed, void* workspace
   c->labels = f; f += align_up((size_t)B, 64);
   c->ystate = f; f += align_up(std::max(c->ny, (size_t)B * hw), 64);
   c->partial = reinterpret_cast<double*>(f);
+  c->nonfinite = reinterpret_cast<int*>(c->partial + (size_t)B * 64 * 2);      // (csd_pc_scratch_bytes keeps 256 bytes behind the partials)
   c->path = p->path_coef != nullptr;
   CSD_REQUIRE(!c->path || (cf.y_channels > 0 && !p->std_y), "pc_sample: use_path needs a conditioning image and no marginal std_y");
   c->per = (int64_t)cf.x_channels * hw;
@@ -2068,9 +2070,9 @@ static int pc_phase(const PCCtx& c, int i, int phase, int part, float* sums_out,
     } else if (phase == 0) {
       const float alpha = p->corr_alpha ? p->corr_alpha[i] : 1.0f;      // sde.alphas[timestep] (VP / subVP); 1 for the VE SDEs
       rc = sums_in ? langevin_update_global_launch(c.x, c.x_mean, c.net_out, c.net_stride, zp, sums_in, Bg, p->std_x[i], p->snr,
-                                                   alpha, c.B, c.per, c.s)
+                                                   alpha, c.B, c.per, c.s, c.nonfinite)
                    : langevin_update_launch(c.x, c.x_mean, c.net_out, c.net_stride, zp, c.partial, c.nchunk, p->std_x[i],
-                                            p->snr, alpha, c.B, c.per, c.s);
+                                            p->snr, alpha, c.B, c.per, c.s, c.nonfinite);
     } else {
       rc = reverse_diffusion_update_launch(c.x, c.x_mean, c.net_out, c.net_stride, zp, p->std_x[i], p->G[i], c.B, c.per, c.s);
     }
@@ -2088,12 +2090,30 @@ static int pc_step_tail(const PCCtx& c, int i) {
   return CSD_OK;
 }
 
+// The finiteness contract of the fused loop (BASELINE.json north_star: outputs within 1e-3 of the reference - a NaN image is not):
+// every Langevin step's norms and one pass over the returned state set a device flag; the loop's LAST call reads it back behind the
+// stream (the only synchronisation of the sampler) and fails with CSD_ERR_NONFINITE instead of returning NaN images silently.
+static int pc_finish(const PCCtx& c) {
+  int rc = finite_check_launch(c.x, c.nx, c.nonfinite, c.s);
+  if (rc) return rc;
+  int flag = 0;
+  CSD_CHECK_HIP(hipMemcpyAsync(&flag, c.nonfinite, sizeof(int), hipMemcpyDeviceToHost, c.s));
+  CSD_CHECK_HIP(hipStreamSynchronize(c.s));
+  if (flag) {
+    set_error("pc_sample: the sampler's state or a corrector norm is not finite - an operand of an fp16-operand mode (fp16x3 / fp16f8 / fp16) "
+              "left the fp16 range (65504); run this network with csd_precision = 'fp32'");
+    return CSD_ERR_NONFINITE;
+  }
+  return CSD_OK;
+}
+
 extern "C" int csd_pc_sample(csd_unet* net, const void* packed, void* workspace, size_t workspace_bytes,
                              void* scratch, size_t scratch_bytes, float* x, const float* y, int B,
                              const csd_pc_params* p, void* stream) {
   PCCtx c;
   int rc = pc_setup(&c, net, packed, workspace, workspace_bytes, scratch, scratch_bytes, x, y, B, p, stream);
   if (rc) return rc;
+  CSD_CHECK_HIP(hipMemsetAsync(c.nonfinite, 0, sizeof(int), c.s));
   if (c.path) {                                 // y_{T+tau} = y + sigma_y(T+tau) z (sampling/conditional.py:146-149)
     const float* z0 = c.noise_path(-1, 0, c.zy, c.ny);
     if (!z0) return CSD_ERR_HIP;
@@ -2115,7 +2135,7 @@ extern "C" int csd_pc_sample(csd_unet* net, const void* packed, void* workspace,
     if ((rc = pc_step_tail(c, i))) return rc;
   }
   g_prof.step_on = true;
-  return CSD_OK;
+  return pc_finish(c);
 }
 
 extern "C" int csd_pc_step_begin(csd_unet* net, const void* packed, void* workspace, size_t workspace_bytes, void* scratch,
@@ -2126,6 +2146,7 @@ extern "C" int csd_pc_step_begin(csd_unet* net, const void* packed, void* worksp
   if (rc) return rc;
   CSD_REQUIRE(norm_sums && step >= 0 && step < p->n_steps, "pc_step_begin: bad step %d / null norm_sums", step);
   CSD_REQUIRE(!c.path, "pc_step_begin: use_path runs through csd_pc_sample only");
+  if (step == 0) CSD_CHECK_HIP(hipMemsetAsync(c.nonfinite, 0, sizeof(int), c.s));
   return pc_phase(c, step, 0, 1, norm_sums, nullptr, 0);
 }
 
@@ -2138,5 +2159,6 @@ extern "C" int csd_pc_step_end(csd_unet* net, const void* packed, void* workspac
   CSD_REQUIRE(norm_sums && global_batch >= B && step >= 0 && step < p->n_steps, "pc_step_end: bad arguments");
   if ((rc = pc_phase(c, step, 0, 2, nullptr, norm_sums, global_batch))) return rc;
   if ((rc = pc_phase(c, step, 1, 3, nullptr, nullptr, 0))) return rc;
-  return pc_step_tail(c, step);
+  if ((rc = pc_step_tail(c, step))) return rc;
+  return step == p->n_steps - 1 ? pc_finish(c) : CSD_OK;
 }

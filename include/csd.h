@@ -32,7 +32,9 @@ typedef enum csd_status {
   CSD_ERR_HIP = -2,          /* a HIP runtime call or kernel launch failed           */
   CSD_ERR_STATE = -3,        /* call sequence violated (e.g. forward before pack)    */
   CSD_ERR_NOT_FOUND = -4,    /* unknown parameter name                               */
-  CSD_ERR_WORKSPACE = -5     /* caller-supplied buffer too small                     */
+  CSD_ERR_WORKSPACE = -5,    /* caller-supplied buffer too small                     */
+  CSD_ERR_NONFINITE = -6     /* the sampler's state left the finite range (csd_pc_sample / csd_pc_step_end of the last step:
+                                an fp16-operand mode met an operand beyond 65504 - run the network in CSD_PREC_F32)          */
 } csd_status;
 
 /* activation ids (models/layers.py:29-41 get_act) */
@@ -178,7 +180,10 @@ typedef struct csd_pc_params {
 } csd_pc_params;
 
 /* x: [B, x_channels, S, S] in: prior sample (already scaled by sigma_max); out: result.
- * y: [B, y_channels, S, S] or NULL.  scratch: csd_pc_scratch_bytes() device bytes. */
+ * y: [B, y_channels, S, S] or NULL.  scratch: csd_pc_scratch_bytes() device bytes.
+ * Finiteness contract: the Langevin corrector's norms (which see every element of the score and of the noise) and one pass over the
+ * returned state set a device flag; csd_pc_sample reads it back behind the stream before it returns - its ONE synchronisation - and
+ * fails with CSD_ERR_NONFINITE rather than hand back NaN images (csd_pc_step_end does the same after the last step). */
 size_t csd_pc_scratch_bytes(const csd_unet* net, int B);
 int csd_pc_sample(csd_unet* net, const void* packed, void* workspace, size_t workspace_bytes,
                   void* scratch, size_t scratch_bytes, float* x, const float* y, int B,

@@ -281,12 +281,43 @@ def test_operand_range_limit_of_the_fp16_operand_modes():
     largest fp16: the hi part of a split operand overflows.  Documented limit of fp16x3 / fp16f8 / fp16: such a
     network runs in csd_precision = 'fp32' (same kernels' fp32-MFMA forms, no range limit) - which must hold the tolerance here - and
     the fp16-operand modes must not return finite-but-wrong numbers silently in the default mode: fp16x3 is either accurate or
-    non-finite (what the samplers' finiteness checks catch).  fp16f8's e4m3 operands saturate at +-448 instead: finite and WRONG
+    non-finite - and the fused sampler turns non-finite into CSD_ERR_NONFINITE (test_sampler_reports_a_non_finite_state below; a
+    bare network evaluation has no such check).  fp16f8's e4m3 operands saturate at +-448 instead: finite and WRONG
     (measured 1.3 norm-wise) - the reason it is not the default for unchanged reference configs."""
     nw, ew = _adversarial_run('outlier_channels_x50', 'fp32')
     assert nw < 1e-4 and ew < 1e-3
     nw3, ew3 = _adversarial_run('outlier_channels_x50', 'fp16x3')
     assert nw3 == float('inf') or (nw3 < 1e-4 and ew3 < 1e-3)
+
+
+def test_sampler_reports_a_non_finite_state():
+    """the finiteness contract of csd_pc_sample (include/csd.h): the x50-outlier weights overflow a raw fp16x3 operand; the fused loop
+    must FAIL (CSD_ERR_NONFINITE -> NonFiniteError naming csd_precision = 'fp32') instead of returning NaN images, through the Langevin
+    norms (free) as well as through the final pass over the state (a loop without a Langevin corrector); the same weights in fp32 and
+    ordinary weights in fp16x3 sample normally; the step-wise global-norm form reports after its last step"""
+    from conditional_score_diffusion_amd._lib import NonFiniteError
+    from conditional_score_diffusion_amd.sampling import correctors as C_, fused, predictors as P_
+    S, B = 80, 2
+    kw = dict(cases.SR3_160)
+    kw.update(image_size=S, ch_mult=(1, 2, 3), attn_resolutions=(20,))
+    y = torch.from_numpy(np.random.RandomState(5).uniform(0, 1, (B, 3, S, S)).astype(np.float32)).to(dev())
+    xs = (B, 3, S, S)
+
+    def run(precision, outliers, **kwargs):
+        cfg, nc, p, model = build(cases.make_config(**kw), precision)
+        if outliers:
+            model.load_state_dict(_adversarial_params(p, 'outlier_channels_x50'))
+        sde = sdes_for(cfg)
+        return fused.run(model, sde, xs, y, 2, cfg.sampling.snr, 1e-5, True, seed=11, **kwargs)[0]
+
+    with pytest.raises(NonFiniteError, match="csd_precision = 'fp32'"):
+        run('fp16x3', True)
+    with pytest.raises(NonFiniteError):                 # no Langevin corrector: the final pass over the state
+        run('fp16x3', True, predictor=P_.get_predictor('conditional_reverse_diffusion'), corrector=C_.get_corrector('conditional_none'))
+    with pytest.raises(NonFiniteError):                 # the step-wise (global-norm) form: after its last step
+        run('fp16x3', True, global_norm=(lambda sums: None, B))
+    assert torch.isfinite(run('fp32', True)).all()
+    assert torch.isfinite(run('fp16x3', False)).all()
 
 
 def test_generic_per_step_path_matches_fused():

@@ -1,12 +1,16 @@
-"""Build-time check of conv_xp.hip's generated code (csrc/Makefile target check-xp, run by __graft_entry__.build()).
+"""Build-time check of the generated code of conv_xp.hip and conv_xw.hip (csrc/Makefile, run by __graft_entry__.build()).
 
-The kernel issues its matrix instructions as asm statements, so hipcc inserts none of the wait states an accumulator access needs
-(MI355X: no hardware interlock between a matrix write and a vector read of the same register).  The source is structured so that
-hipcc never has a reason to touch an accumulator; this script proves it on the ISA of every conv_xp_kernel instantiation:
-  * the matrix instructions use exactly 2 NT accumulator tuples, the same registers throughout the kernel;
+Both kernels issue their matrix instructions as asm statements, so hipcc inserts none of the wait states an accumulator access needs
+(MI355X: no hardware interlock between a matrix write and a vector read of the same register).  The sources are structured so that
+hipcc never has a reason to touch an accumulator; this script proves it on the ISA of every instantiation:
+  * the matrix instructions use exactly the expected accumulator tuples (conv_xp: 2 NT, conv_xw: 4 NT), the same registers throughout;
   * no v_accvgpr_mov / v_accvgpr_write (or any other non-matrix instruction) writes an accumulator register;
-  * every read of an accumulator register sits behind the epilogue's tied wait (s_nop 15) with no matrix instruction in between.
-usage: check_xp_isa.py conv_xp.s"""
+  * every read of an accumulator register sits behind the epilogue's tied wait (s_nop 15) IN THE SAME BASIC BLOCK with no matrix
+    instruction in between: the "behind the wait" state is dropped at every label and after every branch, so a read reached through a
+    back edge or a branch target from a block that ends in a matrix instruction cannot pass (round-4 advisor finding).
+conv_xw keeps two operand fragment sets (64 registers) in the accumulator half of the register file as well: those are written by LDS
+reads and read by matrix instructions only, and are not accumulators.
+usage: check_xp_isa.py conv_xp.s | conv_xw.s"""
 import re
 import sys
 
@@ -26,12 +30,17 @@ def check(name, lines):
             dst = ln.split()[1].rstrip(',')
             tuples.add(dst)
             acc |= regs(dst)
-    nt = int(re.search(r'conv_xp_kernelILi(\d)E', name).group(1))
+    m = re.search(r'conv_x([pw])_kernelILi(\d)E', name)
+    per_nt = 2 if m.group(1) == 'p' else 4
+    nt = int(m.group(2))
     errs = []
-    if len(tuples) != 2 * nt or len(acc) != 32 * nt:
-        errs.append('%d accumulator tuples (%d registers), expected %d (%d)' % (len(tuples), len(acc), 2 * nt, 32 * nt))
+    if len(tuples) != per_nt * nt or len(acc) != 16 * per_nt * nt:
+        errs.append('%d accumulator tuples (%d registers), expected %d (%d)' % (len(tuples), len(acc), per_nt * nt, 16 * per_nt * nt))
     behind_tie = False
     for i, ln in enumerate(lines):
+        if ln.endswith(':') or ln.startswith(('s_cbranch', 's_branch', 's_setpc', 's_endpgm')):
+            behind_tie = False                       # a basic-block boundary: whatever protected the reads above does not reach across
+            continue
         if ln.startswith('v_mfma'):
             behind_tie = False
             continue
@@ -54,7 +63,7 @@ def main(path):
     text = open(path).read().split('\n')
     kernels, cur, name = {}, None, None
     for ln in text:
-        m = re.match(r'^(_ZN3csd14conv_xp_kernel\w+):', ln)
+        m = re.match(r'^(_ZN3csd14conv_x[pw]_kernel\w+):', ln)
         if m:
             name, cur = m.group(1), []
             continue
@@ -64,9 +73,9 @@ def main(path):
                 kernels[name] = cur
                 cur = None
             elif t and not t.startswith((';', '.')):
-                cur.append(t)
+                cur.append(t.split(';')[0].strip())
     if not kernels:
-        print('check_xp_isa: no conv_xp_kernel in', path)
+        print('check_xp_isa: no conv_xp / conv_xw kernel in', path)
         return 1
     bad = 0
     for name, lines in sorted(kernels.items()):

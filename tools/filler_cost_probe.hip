@@ -10,7 +10,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 template <int KIND, int N>
-__global__ __launch_bounds__(256, 1) void probe(float* out, const u4* gsrc, int iters, long long* clk) {
+__global__ __launch_bounds__(256, 1) void probe(float* out, const u4* gsrc, int iters, long long* clk, const u4* big) {
   __shared__ __attribute__((aligned(16))) char lds[65536];
   const int lane = threadIdx.x & 63;
   for (int i = threadIdx.x; i < 16384; i += 256) reinterpret_cast<float*>(lds)[i] = i * 1e-6f;
@@ -53,6 +53,16 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, const u4* gsrc, int 
         else if (KIND == 10) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[0]) : "v"(v[4]));
         else if (KIND == 11) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ld[q]) : "v"(gsrc + threadIdx.x + ((g * N + f) & 63) * 256));
         else if (KIND == 12) asm volatile("s_nop 0");
+        else if (KIND >= 13) {
+          // the patch request of conv_xp / conv_xw: 4 lanes share a pixel's 64 bytes, pixels 384 bytes apart; 13: a 6 MB footprint (L2), 14: 600 MB (HBM),
+          // 15: the same bytes as whole 1 KiB pieces (HBM footprint)
+          const size_t pix = (size_t)blockIdx.x * 9973 + (size_t)(it * 36 + g) * N + f;
+          const size_t span = KIND == 13 ? (1u << 14) : (1u << 21);      // pixels
+          const size_t p0 = (pix * 64) % span;
+          const char* base = reinterpret_cast<const char*>(big);
+          const char* ad = KIND == 15 ? base + p0 * 288 + threadIdx.x * 16 : base + (p0 + (threadIdx.x >> 2)) * 384 + (threadIdx.x & 3) * 16 + ((g & 3) * 64);
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ld[q]) : "v"(ad));
+        }
       }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -70,13 +80,15 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, const u4* gsrc, int 
   if (threadIdx.x == 0) { clk[blockIdx.x * 2] = c1 - c0; clk[blockIdx.x * 2 + 1] = w1 - w0; }
 }
 
+static const u4* g_big = nullptr;
 template <int KIND, int N>
-void run(float* out, const u4* gsrc, long long* clk, const char* what) {
+void run(float* out, const u4* gsrc, long long* clk, const char* what, const u4* big = nullptr) {
+  if (big) g_big = big; big = g_big;
   const int iters = 300;
   auto kern = probe<KIND, N>;
-  hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, out, gsrc, 10, clk);
+  hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, out, gsrc, 10, clk, big);
   (void)hipDeviceSynchronize();
-  hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, out, gsrc, iters, clk);
+  hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, out, gsrc, iters, clk, big);
   (void)hipDeviceSynchronize();
   long long h[2];
   (void)hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
@@ -90,7 +102,12 @@ int main() {
   float* out; (void)hipMalloc(&out, 256 * 256 * 4);
   long long* clk; (void)hipMalloc(&clk, 256 * 16);
   u4* gsrc; (void)hipMalloc(&gsrc, 256 * 256 * 16); (void)hipMemset(gsrc, 0x3c, 256 * 256 * 16);
-  run<0, 0>(out, gsrc, clk, "none");
+  u4* big; (void)hipMalloc(&big, (size_t)900 << 20); (void)hipMemset(big, 0x3c, (size_t)900 << 20);
+  run<0, 0>(out, gsrc, clk, "none", big);
+  run<13, 1>(out, gsrc, clk, "patch-like load, L2"); run<13, 2>(out, gsrc, clk, "patch-like load, L2");
+  run<14, 1>(out, gsrc, clk, "patch-like load, HBM"); run<14, 2>(out, gsrc, clk, "patch-like load, HBM");
+  run<15, 1>(out, gsrc, clk, "1 KiB pieces, HBM"); run<15, 2>(out, gsrc, clk, "1 KiB pieces, HBM");
+  run<11, 1>(out, gsrc, clk, "1 KiB pieces, L2 small");
   RUNK(0, "v_fma_f32") RUNK(1, "v_exp_f32") RUNK(2, "v_rcp_f32") RUNK(3, "v_cvt_pk_f16_f32") RUNK(4, "v_fma_mix_f32") RUNK(5, "v_cndmask_b32 sgpr")
   RUNK(6, "ds_bpermute_b32") RUNK(7, "ds_read_b128") RUNK(8, "ds_write_b64") RUNK(9, "ds_write_b128") RUNK(10, "v_add_f32 dependent")
   RUNK(11, "global_load_dwordx4") RUNK(12, "s_nop 0")
