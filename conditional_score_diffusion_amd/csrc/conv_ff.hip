@@ -613,6 +613,12 @@ int convff_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, in
     const size_t n32 = convff_packed_bytes(p, ns) / 4;
     hipLaunchKernelGGL(convff_zero_kernel, dim3((unsigned)cdiv64(n32, 256)), dim3(256), 0, s, (uint32_t*)wpack, n32);
     CSD_LAUNCH_CHECK();
+  } else if (cout_off == 0) {
+    // full coverage: only the 4096-byte slack behind the fragments (the weight streams prefetch past the last step; nothing
+    // multiplies it today, but it must never hold NaN patterns a future schedule could consume) - round-4 advisor finding
+    const size_t total_b = convff_packed_bytes(p, ns);
+    hipLaunchKernelGGL(convff_zero_kernel, dim3(4), dim3(256), 0, s, (uint32_t*)((char*)wpack + total_b - 4096), (size_t)1024);
+    CSD_LAUNCH_CHECK();
   }
   if (convff_winograd(p, ns)) {
     CSD_REQUIRE(layout == 0 || layout == 2, "convff: the Winograd pack takes 3x3 weights");

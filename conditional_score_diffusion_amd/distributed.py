@@ -164,7 +164,12 @@ class GradSync:
         if not self.grouped or not self.flat.grad.is_cuda or getattr(model, '_h', None) is None:
             return False
         from ._lib import check, lib
-        first = bucket_first_modules([n for n, _ in model.named_parameters()], [b[2] for b in self.buckets])
+        # names of the FLAT buffer's parameters, in its order (a frozen parameter is not in it: indices into the model's full
+        # parameter list would be shifted - round-4 advisor finding)
+        name_of = {id(p): n for n, p in model.named_parameters()}
+        if any(id(p) not in name_of for p in self.flat.params):
+            return False
+        first = bucket_first_modules([name_of[id(p)] for p in self.flat.params], [b[2] for b in self.buckets])
         if first is None:
             return False
         import ctypes
@@ -179,6 +184,12 @@ class GradSync:
         self._epoch = int(lib().csd_unet_backward_marks_epoch(model._h))
         self.overlapped_launches = 0      # buckets launched from their event (statistics for tests / logs)
         return True
+
+    def __del__(self):
+        try:
+            self.detach_planned()
+        except Exception:
+            pass
 
     def detach_planned(self):
         if getattr(self, '_events', None):
@@ -217,7 +228,11 @@ class GradSync:
             if ev and not any(self._launched):
                 from ._lib import check, lib
                 epoch = int(lib().csd_unet_backward_marks_epoch(self._model._h))
-                if epoch == self._epoch + 1:          # exactly one planned backward since the last step recorded every event
+                # exactly one planned backward since the last step recorded every event - AND it wrote the .grad views itself: when
+                # it did not (a gradient buffer the library cannot write directly), autograd accumulates into .grad on the main stream
+                # AFTER the events, and a communication stream that waits for the events alone would reduce stale gradients.  Then
+                # the buckets are launched below, from the current stream (behind the accumulation).
+                if epoch == self._epoch + 1 and getattr(self._model, '_last_backward_direct', False):
                     for b in reversed(range(len(self.buckets))):      # the order the gradients become final
                         check(lib().csd_stream_wait_event(ctypes_ptr(self._comm.cuda_stream), ev[b]), 'stream_wait_event')
                         with torch.cuda.stream(self._comm):

@@ -415,16 +415,23 @@ class _PlannedNet(torch.autograd.Function):
             import weakref
             weakref.finalize(ctx, _release_private_ws, weakref.ref(model), model._h, ws.data_ptr())
         ctx.shapes = [(p.shape, p.numel()) for p in params]
-        ctx.sink = [p.grad for p in params] if getattr(model, 'grad_sink', False) else None
+        # direct mode: the backward writes straight into the parameters' .grad views (the flat gradient buffer).  A parameter that
+        # takes no gradient (the fixed Gaussian-Fourier W of NCSN++) has none: the library still writes one - into a throw-away buffer
+        ctx.sink = [p.grad if p.requires_grad else False for p in params] if getattr(model, 'grad_sink', False) else None
         return out
 
     @staticmethod
     def backward(ctx, dout):
         model, B = ctx.model, ctx.B
         dout = dout.contiguous()
-        direct = ctx.sink is not None and all(g is not None and g.is_contiguous() and g.data_ptr() % 16 == 0 for g in ctx.sink)
+        direct = ctx.sink is not None and all(g is False or (g is not None and g.is_contiguous() and g.data_ptr() % 16 == 0)
+                                              for g in ctx.sink)
+        # (distributed.GradSync reads this: the gradient-ready events of the planned backward describe the FINAL gradients only
+        # when the kernels wrote .grad themselves; otherwise autograd's accumulation runs after them)
+        model._last_backward_direct = direct
         if direct:
-            grads = ctx.sink
+            grads = [torch.empty(shape, dtype=torch.float32, device=dout.device) if g is False else g
+                     for g, (shape, _) in zip(ctx.sink, ctx.shapes)]
         else:
             offs = [0]
             for _, n in ctx.shapes:
@@ -439,7 +446,7 @@ class _PlannedNet(torch.autograd.Function):
             _release_shared_ws(lambda: model, ctx.call)
         if direct:
             return (None, None, None, None) + (None,) * len(grads)
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[4:]))
 
 
 @utils.register_model(name='ddpm')

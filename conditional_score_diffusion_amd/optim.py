@@ -66,9 +66,16 @@ class FlatParams:
         dev = self.params[0].device
         if any(p.dtype != torch.float32 or p.device != dev for p in self.params):
             raise RuntimeError('FlatParams: parameters must be float32 on one device')
-        self.offsets = np.cumsum([0] + [p.numel() for p in self.params])
-        self.numel = int(self.offsets[-1])
-        self.data = torch.empty(self.numel, dtype=torch.float32, device=dev)
+        # every parameter starts on a 16-byte boundary (4 floats): the planned backward writes the gradient views directly and the
+        # library's vector stores need the alignment - a 6-float bias (the output pyramids of NCSN++ on 6 channels) would otherwise
+        # misalign everything behind it; the padding holds zeros for ever (zero gradient -> zero Adam update)
+        starts, o = [], 0
+        for p in self.params:
+            starts.append(o)
+            o += (p.numel() + 3) // 4 * 4
+        self.offsets = np.asarray(starts + [o], dtype=np.int64)
+        self.numel = int(o)
+        self.data = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         for p, o in zip(self.params, self.offsets[:-1]):
             o = int(o)

@@ -53,6 +53,16 @@ class Trainer:
             self.sync.attach_planned(model)           # per-bucket gradient-ready events: the all-reduce overlaps the backward
         self.step = 0                     # completed optimizer steps (the warm-up factor of step k is k / warmup)
 
+    def close(self):
+        """drop the gradient-ready events registered on the network handle (a Trainer rebuilt on the same model registers its own)"""
+        self.sync.detach_planned()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _build_loss_fns(self):
         config, model, sde = self.config, self.model, self.sde
         t = config.training

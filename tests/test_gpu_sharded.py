@@ -223,19 +223,33 @@ def _planned_overlap_worker(port, q):
         from conditional_score_diffusion_amd import train
         from conditional_score_diffusion_amd._lib import check, lib
         res = {}
-        for case in ('sr3_tiny', 'cmde_tiny'):
-            try:
-                cfg, B, x, y, u, tape = cs.grad_case(case)
-            except Exception:
-                continue
+        for case in ('sr3_tiny', 'cmde_tiny', 'ncsnpp_paired_skip'):
+            sde_of = sf
+            if case.startswith('ncsnpp'):
+                # NCSN++ with a Fourier embedding (a FROZEN parameter: no .grad) and 6-channel output pyramids (6-float biases): the
+                # round-4 advisor's case - the planned backward could not write .grad directly, autograd accumulated AFTER the
+                # gradient-ready events, and the communication stream reduced stale gradients
+                from test_gpu_training import _ncsnpp_train_case
+                from conditional_score_diffusion_amd import sde_lib
+                from conditional_score_diffusion_amd.models import utils as mutils
+                cfg, xx = _ncsnpp_train_case()
+                batch = (xx[:, 3:].contiguous().to('cuda:0'), xx[:, :3].contiguous().to('cuda:0'))
+                sde_of = lambda c: {'x': sde_lib.cVESDE(0.01, 50., 1000), 'y': sde_lib.VESDE(0.01, 1.0, 1000)}      # noqa: E731
+                bld_case = lambda c: (None, None, None, mutils.create_model(c).to('cuda:0'))      # noqa: E731
+            else:
+                try:
+                    cfg, B, x, y, u, tape = cs.grad_case(case)
+                except Exception:
+                    continue
+                batch = (y.to('cuda:0'), x.to('cuda:0'))
+                bld_case = bld
             cfg.model.dropout = 0.1
             cfg.optim.warmup = 1
-            batch = (y.to('cuda:0'), x.to('cuda:0'))
 
             def run(overlap):
                 torch.manual_seed(3)
-                _, _, _, model = bld(cfg)
-                tr = train.Trainer(cfg, model, sf(cfg), bucket_bytes=256 << 10)
+                _, _, _, model = bld_case(cfg)
+                tr = train.Trainer(cfg, model, sde_of(cfg), bucket_bytes=256 << 10)
                 assert len(tr.sync.buckets) >= 3
                 if not overlap:
                     tr.sync.detach_planned()
@@ -247,6 +261,11 @@ def _planned_overlap_worker(port, q):
 
             a, b = run(True), run(False)
             same = bool(torch.equal(a.flat.data, b.flat.data)) and bool(torch.equal(a.ema.shadow, b.ema.shadow))
+            if case.startswith('ncsnpp'):
+                res[case] = dict(buckets=len(a.sync.buckets), overlapped=a.sync.overlapped_launches, same=same,
+                                 direct=bool(getattr(a.model, '_last_backward_direct', False)),
+                                 frozen=sum(1 for p_ in a.model.parameters() if not p_.requires_grad))
+                continue
             # the order in which the library records the marks: timing events of the caller in place of the trainer's
             tr = a
             n = len(tr.sync.buckets)
@@ -255,7 +274,8 @@ def _planned_overlap_worker(port, q):
                 e.record()
             torch.cuda.synchronize()
             from conditional_score_diffusion_amd.distributed import bucket_first_modules
-            first = bucket_first_modules([k for k, _ in tr.model.named_parameters()], [bk[2] for bk in tr.sync.buckets])
+            name_of = {id(p_): k for k, p_ in tr.model.named_parameters()}
+            first = bucket_first_modules([name_of[id(p_)] for p_ in tr.flat.params], [bk[2] for bk in tr.sync.buckets])
             fm = (ctypes.c_int * n)(*first)
             ev = (ctypes.c_void_p * n)(*[e.cuda_event for e in evs])
             check(lib().csd_unet_backward_marks(tr.model._h, fm, ev, n), 'marks')
@@ -290,7 +310,12 @@ def test_planned_backward_records_gradient_ready_events_for_the_all_reduce():
     res, err = q.get(timeout=900)
     pr.join(timeout=120)
     assert err is None, err
-    assert 'sr3_tiny' in res
+    assert 'sr3_tiny' in res and 'ncsnpp_paired_skip' in res
+    nc = res.pop('ncsnpp_paired_skip')
+    # the planned NCSN++ graph: identical parameters with and without the event-driven launches - whether the backward could write the
+    # gradient views itself (then every bucket is launched from its event) or not (then none may be)
+    assert nc['same'], nc
+    assert nc['overlapped'] == (3 * nc['buckets'] if nc['direct'] else 0), nc
     for case, r in res.items():
         assert r['overlapped'] == 3 * r['buckets'] and r['plain'] == 0, (case, r)
         assert r['same'], case
