@@ -262,9 +262,15 @@ def main():
         _lib.profile_start()
     t0 = time.perf_counter()
     run_steps(W, K, 2000 + rank)
+    if not stub:
+        torch.cuda.synchronize()      # (this rank's steps are done: the per-rank figure below; csd_pc_sample has synchronised already)
+    t_steps = time.perf_counter() - t0
     if grouped:     # the one collective of the sampling path: gather the finished samples
         out = torch.empty((world * B,) + tuple(x.shape[1:]), dtype=torch.float32, device=dev)
         torch.distributed.all_gather_into_tensor(out, x)
+        if not stub:
+            torch.cuda.synchronize()
+    t_gather = time.perf_counter() - t0 - t_steps
     barrier()
     dt = time.perf_counter() - t0
     prof = _lib.profile_stop()
@@ -282,17 +288,24 @@ def main():
         prof_all = _lib.profile_stop()
         prof_all = {k: dict(v, ms=v['ms'] * K / n2, launches=v['launches'] * K // n2, flops=v['flops'] * K / n2,
                             bytes=v['bytes'] * K / n2) for k, v in prof_all.items()}
+    # diagnostic for the first multi-GPU run (never part of `value`): every rank's own step time and what the all-gather cost it
+    per_rank = {'ms_per_step': [t_steps / K * 1e3], 'all_gather_ms': [t_gather * 1e3]}
     if grouped:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
+        mine = torch.tensor([t_steps / K * 1e3, t_gather * 1e3], dtype=torch.float64, device=dev)
+        every = torch.empty(world * 2, dtype=torch.float64, device=dev)
+        torch.distributed.all_gather_into_tensor(every, mine)
+        every = every.reshape(world, 2).cpu()
+        per_rank = {'ms_per_step': [float(v) for v in every[:, 0]], 'all_gather_ms': [float(v) for v in every[:, 1]]}
     if stub:
         if rank == 0:
             gathered = out[:, 0, 0, 0].reshape(world, B)[:, 0].tolist() if grouped else [float(x[0, 0, 0, 0])]
             print(json.dumps({'metric': 'stub', 'value': B * world / (1000.0 * dt / args.steps), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
                               'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
                               'config': {'workload': 'stub sampler (CPU, gloo)', 'images_per_gpu': B, 'global_batch': B * world},
-                              'gathered_first_element_per_rank': gathered}))
+                              'per_rank': per_rank, 'gathered_first_element_per_rank': gathered}))
         if grouped:
             torch.distributed.barrier()
             torch.distributed.destroy_process_group()
@@ -371,6 +384,7 @@ def main():
                                    'batch %d per GPU, random-init weights, synthetic LR inputs' % B,
                        'images_per_gpu': B, 'global_batch': total_images, 'pc_steps_timed': K,
                        'nfe_per_step': 2, 'noise': 'on-device Philox4x32-10', 'precision_mode': args.precision},
+            'per_rank': per_rank,
             'roofline': roof,
             'hbm_roofline': {'images_per_sec_per_gpu': hbm_roof, 'frac': value / world / hbm_roof,
                              'achieved_GBs': value / world * bytes_per_img / 1e9, 'peak_GBs': HBM_PEAK_GBS},

@@ -252,6 +252,71 @@ def test_two_rank_bucketed_gradient_allreduce_gloo():
         assert torch.equal(res[0][1][it], res[1][1][it])   # every rank holds the same reduced gradient
 
 
+def _skewed_grad_worker(rank, world, port, q):
+    """as _grad_worker, with UNEQUAL backward durations: rank r sleeps r * 30 ms inside the backward of every layer, so that rank 0 has
+    launched all its buckets (and sits in finish()) long before rank 1 launches its first; one parameter gets no gradient at all in
+    the second step (its bucket is launched by finish(), not by a hook)"""
+    import time
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from conditional_score_diffusion_amd import distributed as D, optim
+    net = _tiny_net()
+    flat = optim.FlatParams(net.parameters())
+    sync = D.GradSync(flat, bucket_bytes=4 * 60)
+    order = []
+    launch = sync._launch
+    sync._launch = lambda b: (order.append(b), launch(b))[1]
+    for m in net:
+        if isinstance(m, torch.nn.Linear):
+            m.register_full_backward_hook(lambda mod, gi, go: time.sleep(0.03 * rank))
+    data = torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10.0
+    lo, hi = D.shard_bounds(8, rank, world)
+    out, orders = [], []
+    for it in range(2):
+        flat.zero_grad()
+        h = net[:4](data[lo:hi] + it)
+        loss = (net[4](h) ** 2).mean() if it == 0 else (h ** 2).mean()      # step 1: the last layer takes no gradient
+        sync.scale_loss(loss).backward()
+        sync.finish()
+        out.append(flat.grad.clone())
+        orders.append(list(order))
+        del order[:]
+    q.put((rank, out, orders))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_with_unequal_backward_durations_gloo():
+    """GradSync with ranks whose backward passes take different times: the buckets are launched in the SAME order
+    on both ranks - the order the gradients become final, the collective's matching rule - whatever the skew, a bucket whose hooks
+    never fire is launched by finish(), and both ranks end with the same global-batch mean"""
+    from conditional_score_diffusion_amd import optim
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_skewed_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert res[0][2] == res[1][2]                               # same launch order on both ranks, both steps
+    assert res[0][2][0] == sorted(res[0][2][0], reverse=True) and len(res[0][2][0]) >= 3      # last layers' bucket first
+    assert sorted(res[0][2][1]) == sorted(res[0][2][0])         # every bucket reduced in the step without a last-layer gradient too
+    data = torch.arange(8 * 6, dtype=torch.float32).reshape(8, 6) / 10.0
+    for it in range(2):
+        net = _tiny_net()
+        flat = optim.FlatParams(net.parameters())
+        h = net[:4](data + it)
+        ((net[4](h) ** 2).mean() if it == 0 else (h ** 2).mean()).backward()
+        for r in range(world):
+            assert torch.allclose(res[r][1][it], flat.grad, rtol=1e-5, atol=1e-7)
+        assert torch.equal(res[0][1][it], res[1][1][it])
+
+
 def test_bench_grouped_branch_two_ranks_gloo():
     """bench.py's N > 1 protocol exactly as the driver launches it (torch.distributed.run, one process per rank): process group,
     W untimed + K timed steps between barriers, the ONE all_gather of the finished samples, MAX of the ranks' times, rank 0's line -
@@ -272,5 +337,9 @@ def test_bench_grouped_branch_two_ranks_gloo():
     # the timed region is the slowest rank's (rank 1: 4 ms per step), not rank 0's 2 ms
     assert 3.9 <= j['ms_per_step'] < 40.0
     assert abs(j['value'] - 2 * B / (1000.0 * j['ms_per_step'] * 1e-3)) < 1e-9 * max(1.0, j['value'])
+    # per-rank diagnostics (never part of `value`): rank r's own 2 (r + 1) ms per step; rank 0 waits in the all-gather for rank 1
+    pr = j['per_rank']
+    assert len(pr['ms_per_step']) == 2 and 1.9 <= pr['ms_per_step'][0] < pr['ms_per_step'][1] and pr['ms_per_step'][1] >= 3.9
+    assert pr['all_gather_ms'][0] > pr['all_gather_ms'][1] and pr['all_gather_ms'][0] >= 0.5 * K * 2.0
     # the gather placed rank r's samples in block r: x started at r and every step added 1
     assert j['gathered_first_element_per_rank'] == [0.0 + K + W, 1.0 + K + W]
