@@ -103,21 +103,20 @@ struct XWSched {
   static constexpr int PB = 4 * NT, GP = 3 * PB, WPT = 2 * NT;
   static constexpr bool rd_wh(int g) { return g < PB; }                                              // wh[g] of THIS tap
   static constexpr bool rd_xl(int g) { return g < PB && g % NT == (NT > 1 ? 1 : 0); }                // xl[g / NT] of this tap
-  static constexpr int RW = PB / 2;                                                                  // the wl ring: half a product's fragments
-  static constexpr bool rd_wlB(int g) { return g < RW; }                                             // wl[RW + g] of THIS tap (into the register MFMA g just read)
+  static constexpr int RW = 4;                                                                       // the wl ring (registers)
+  static constexpr bool rd_wlB(int g) { return g < PB - RW; }                                        // wl[RW + g] of THIS tap (into the register MFMA g just read)
   static constexpr bool rd_wlA(int g) { return g >= GP - RW; }                                       // wl[g - (GP - RW)] of the NEXT tap
   static constexpr bool rd_xh(int g) { return g >= 2 * PB && (g - 2 * PB) % 2 == 0 && (g - 2 * PB) / 2 < 4; }      // xh[(g - 2 PB) / 2] of the next tap
-  // the weight ring: a row tap stores the WPT pieces of the tap two ahead in two halves of WH through the same WH registers -
-  // half A (requested at the end of the tap before) in gaps PA + 2 q, half B requested right behind (gaps PA + 1 + 2 q) and stored in
-  // gaps PB2 + 2 q, the next tap's half A requested right behind those (gaps PB2 + 1 + 2 q)
-  static constexpr int WH = WPT / 2, PA = PB - 3, PB2 = 2 * PB + 4;
-  static constexpr bool in_a(int g) { return g >= PA && g < PA + 2 * WH; }
-  static constexpr bool in_b(int g) { return g >= PB2 && g < PB2 + 2 * WH; }
-  static constexpr bool put(int g) { return (in_a(g) && (g - PA) % 2 == 0) || (in_b(g) && (g - PB2) % 2 == 0); }
-  static constexpr bool req(int g) { return (in_a(g) && (g - PA) % 2 == 1) || (in_b(g) && (g - PB2) % 2 == 1); }
-  static constexpr int wq(int g) { return in_a(g) ? (g - PA) / 2 : (g - PB2) / 2; }      // register of the piece
-  static constexpr int wpiece(int g) { return in_a(g) ? (g - PA) / 2 : WH + (g - PB2) / 2; }      // piece stored in gap g
-  static constexpr int fixed(int g) { return (rd_wh(g) ? 1 : 0) + (rd_xl(g) ? 1 : 0) + (rd_wlA(g) ? 1 : 0) + (rd_wlB(g) ? 1 : 0) + (rd_xh(g) ? 1 : 0) + (put(g) ? 1 : 0) + (req(g) ? 1 : 0); }
+  // Vector memory: requests retire IN ORDER (one counter for loads and stores), so a wait for an L2-hit weight piece also waits for
+  // every OLDER request - and the patch requests go to HBM.  Per row tap therefore, in this order: gap 0 the tap's two patch
+  // requests (slot = tap index: its registers were consumed under the tap before), gaps 1 .. WPT the ring stores of the WPT pieces
+  // requested under the tap before (they are OLDER than this tap's patch requests, and the patch requests of the tap before are a
+  // whole tap old), gaps WPT + 1 .. 2 WPT the requests of the next pieces into the same registers.
+  static constexpr bool slot_req(int g) { return g == 0; }
+  static constexpr bool put(int g) { return g >= 1 && g <= WPT; }                                    // ring store of piece g - 1
+  static constexpr bool req(int g) { return g > WPT && g <= 2 * WPT; }                               // request of piece g - WPT - 1
+  static constexpr int wq(int g) { return put(g) ? g - 1 : g - WPT - 1; }
+  static constexpr int fixed(int g) { return (rd_wh(g) ? 1 : 0) + (rd_xl(g) ? 1 : 0) + (rd_wlA(g) ? 1 : 0) + (rd_wlB(g) ? 1 : 0) + (rd_xh(g) ? 1 : 0) + (put(g) ? 1 : 0) + (req(g) ? 1 : 0) + (slot_req(g) ? 3 : 0); }
   // the conversion's micro-operations go where the fixed fillers leave room: weight of a gap = 14 - 3 fixed (thirds of an issue slot)
   static constexpr int wgt(int g) { return 14 - 3 * fixed(g) > 2 ? 14 - 3 * fixed(g) : 2; }
   static constexpr int cum(int g) { int s = 0; for (int h = 0; h < g; ++h) s += wgt(h); return s; }
@@ -201,9 +200,10 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
     const int dummy = OFF_DUMMY + ul * 64 + lg * 8;  // (non-writers store their garbage to a scratch area: no exec juggling in the stream)
     s_dst[j] = writer ? rec : dummy;                 // (the prologue writes buffer 0; ^= XTOG at the end of every unit)
   }
-  // a pixel of a unit: its index inside the sample in the low 24 bits (what the 24-bit multiply of the request reads) and 0xFF on top if
-  // it exists (mask = arithmetic shift by 31) - 0 outside the sample (pixel 0 is read and masked away): zero padding
-  struct Geom { int pa[3], pb[3]; };
+  // the two pixels (a, b = a + 1 in the row) of a unit in ONE register: bits 0-23 the index inside the sample of a (of b when only b
+  // exists, 0 when neither does - what is read there is masked away: zero padding), bit 31: a exists, bit 30: b exists, bit 29: both
+  // (then b's index is a's + 1).  The 24-bit multiply of the request ignores the flags.
+  struct Geom { int p[3]; };
   auto geom_of = [&](const Tile& t) __attribute__((always_inline)) {
     Geom g;
     const int ulf = fresh_lane() >> 2;
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
       const int y = t.ty0 - 1 + pr, xa = t.tx0 - 1 + 2 * u;
       const bool iny = (unsigned)y < (unsigned)kH && U < XW_NU;
       const bool ina = iny && (unsigned)xa < (unsigned)kW, inb = iny && (unsigned)(xa + 1) < (unsigned)kW;      // zero padding outside THIS sample
-      g.pa[j] = ina ? (y * kW + xa) | (int)0xFF000000 : 0;
-      g.pb[j] = inb ? (y * kW + xa + 1) | (int)0xFF000000 : 0;
+      g.p[j] = (ina ? y * kW + xa : inb ? y * kW + xa + 1 : 0) | (ina ? (int)0x80000000 : 0) | (inb ? 0x40000000 : 0) |
+               (ina && inb ? 0x20000000 : 0);
     }
     return g;
   };
@@ -243,10 +243,10 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
     soffL = (s1 ? cb - kC0 : cb) * 4;
   };
   auto req_a = [&](int j, const Geom& g) __attribute__((always_inline)) {
-    if (!(XW_ABL & 16)) pfa[j] = __builtin_amdgcn_raw_buffer_load_b128(srcL, __umul24((XW_ABL & 4096) ? (g.pa[j] & 255) : g.pa[j], strideL) + lg * 16, soffL, 0);
+    if (!(XW_ABL & 16)) pfa[j] = __builtin_amdgcn_raw_buffer_load_b128(srcL, (XW_ABL & 8192) ? (unsigned)(tid * 16 + j * 8192) : __umul24((XW_ABL & 4096) ? (g.p[j] & 255) : g.p[j], strideL) + lg * 16, soffL, 0);
   };
   auto req_b = [&](int j, const Geom& g) __attribute__((always_inline)) {
-    if (!(XW_ABL & 16)) pfb[j] = __builtin_amdgcn_raw_buffer_load_b128(srcL, __umul24((XW_ABL & 4096) ? (g.pb[j] & 255) : g.pb[j], strideL) + lg * 16, soffL, 0);
+    if (!(XW_ABL & 16)) pfb[j] = __builtin_amdgcn_raw_buffer_load_b128(srcL, (XW_ABL & 8192) ? (unsigned)(tid * 16 + j * 8192 + 4096) : __umul24(((XW_ABL & 4096) ? (g.p[j] & 255) : g.p[j]) + ((g.p[j] >> 29) & 1), strideL) + lg * 16, soffL, 0);
   };
   const __amdgpu_buffer_rsrc_t nsc_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(NORM ? k.a.nscale : a_src0), 0, OOB, RSRC_FLAGS);
   const __amdgpu_buffer_rsrc_t nsh_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(NORM ? k.a.nshift : a_src0), 0, OOB, RSRC_FLAGS);
@@ -271,8 +271,7 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
   // piece i = q * 4 + wave of a row tap.  The scalar offset runs (asm add) and is re-based when the stream moves to the next tile.
   const __amdgpu_buffer_rsrc_t w_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g_wpack), 0, OOB, RSRC_FLAGS);
   const int wvoff = lane * 16 + wave * 1024;
-  constexpr int WH = S::WH;
-  xw_u4 wr[WH];
+  xw_u4 wr[WPT];
   int w_run = 0;
   const int c4096 = 4096;
   auto w_begin = [&](int wso) __attribute__((always_inline)) { w_run = wso; };
@@ -281,9 +280,9 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
     wr[q] = __builtin_amdgcn_raw_buffer_load_b128(w_r, (unsigned)wvoff, w_run, 0);
     XW_SADD(w_run, c4096);
   };
-  auto put_w = [&](int q, int piece, int slot) __attribute__((always_inline)) {
+  auto put_w = [&](int q, int slot) __attribute__((always_inline)) {
     if (XW_ABL & 2) return;
-    *reinterpret_cast<xw_u4*>(smem + C::slot_off(slot) + piece * 4096 + wvoff) = wr[q];
+    *reinterpret_cast<xw_u4*>(smem + C::slot_off(slot) + q * 4096 + wvoff) = wr[q];
   };
 
   // ---- conversion of a slot, as a sequence of single operations (placed one by one between the MFMAs) ----
@@ -327,7 +326,7 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
         cv[i] = cv[i] * ce[i];
         XW_PIN(cv[i]);
       } else if constexpr (o == 5) {                 // padding applies to the ACTIVATED tensor: exactly 0
-        const int m = (i < 4 ? g.pa[j] : g.pb[j]) >> 31;
+        const int m = (i < 4 ? g.p[j] : g.p[j] << 1) >> 31;
         const int raw = NORM ? __float_as_int(cv[i]) : (int)(i < 4 ? pfa[j][c] : pfb[j][c]);
         cv[i] = __int_as_float(raw & m);
         XW_PIN(cv[i]);
@@ -381,12 +380,11 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
   using J1 = std::integral_constant<int, 1>;
   using J2 = std::integral_constant<int, 2>;
   // a whole slot: math, stores, the requests of the same slot for the stage after
-  constexpr int NFULL = NMATH + 8 + 2;
+  constexpr int NFULL = NMATH + 8;
   auto full_op = [&](auto j_tag, auto o_tag, const Geom& gm, const Geom& gr) __attribute__((always_inline)) {
     constexpr int o = decltype(o_tag)::value;
     if constexpr (o < NMATH) math_op(j_tag, o_tag, gm);
-    else if constexpr (o < NMATH + 8) write_op(j_tag, std::integral_constant<int, o - NMATH>{});
-    else reqs_op(j_tag, std::integral_constant<int, o - NMATH - 8>{}, gr);
+    else write_op(j_tag, std::integral_constant<int, o - NMATH>{});
   };
 
   // ---- fragments (single-buffered, re-loaded in rotation) ----
@@ -570,22 +568,25 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
     src_of(tc, 1);
     // stage 0, all three slots, into buffer 0; each slot re-requested for stage 1
     xw_static_for<NFULL>([&](auto o) __attribute__((always_inline)) { full_op(J0{}, o, gc, gc); });
+    req_a(0, gc); req_b(0, gc);
     xw_static_for<NFULL>([&](auto o) __attribute__((always_inline)) { full_op(J1{}, o, gc, gc); });
+    req_a(1, gc); req_b(1, gc);
     xw_static_for<NFULL>([&](auto o) __attribute__((always_inline)) { full_op(J2{}, o, gc, gc); });
+    req_a(2, gc); req_b(2, gc);
 #pragma unroll
     for (int j = 0; j < 3; ++j) s_dst[j] ^= XTOG;          // from here on the stream writes buffer 1 (stage 1)
     // stage 1, slot 0: computed and held (stored by the first row tap)
     cvt_prep_half(0); cvt_prep_half(1);
     xw_static_for<NMATH>([&](auto o) __attribute__((always_inline)) { math_op(J0{}, o, gc); });
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {                    // row taps 0 and 1, half by half
+    for (int r = 0; r < 2; ++r) {                    // row taps 0 and 1
 #pragma unroll
-      for (int q = 0; q < WH; ++q) req_w(q);
+      for (int q = 0; q < WPT; ++q) req_w(q);
 #pragma unroll
-      for (int q = 0; q < WH; ++q) put_w(q, (h & 1) * WH + q, h >> 1);
+      for (int q = 0; q < WPT; ++q) put_w(q, r);
     }
 #pragma unroll
-    for (int q = 0; q < WH; ++q) req_w(q);           // half A of row tap 2
+    for (int q = 0; q < WPT; ++q) req_w(q);          // row tap 2 (stored under row tap 0)
   }
   ff_barrier();
 #pragma unroll
@@ -617,7 +618,8 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
       if (!(XW_ABL & 64)) ff_barrier();
       XW_FENCE();
       if (R == 0) XW_TS(0 + (s < 12 ? s : 12));
-      constexpr int NOPS = R == 0 ? 8 + 2 + NFULL : R == 1 ? NFULL : 2 + NMATH;
+      if constexpr (R == 0) src_of(tl, sl);          // (scalar: the descriptor of stage L's requests, used from this tap's gap 0 on)
+      constexpr int NOPS = R == 0 ? 8 + NFULL : R == 1 ? NFULL : 2 + NMATH;
       xw_static_for<GP>([&](auto g_tag) __attribute__((always_inline)) {
         constexpr int g = decltype(g_tag)::value;
         XW_FENCE();
@@ -628,27 +630,24 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
         // ---- fixed fillers of gap (R, g) ----
         if constexpr (S::rd_wh(g)) rd_w(wh[g], R, g, 0);
         if constexpr (S::rd_xl(g)) rd_x(xl[g / NT], xb_cur, R, g / NT, 1);
-        if constexpr (S::rd_wlB(g)) rd_w(wl[g], R, RW + g, 1);
+        if constexpr (S::rd_wlB(g)) rd_w(wl[g % RW], R, RW + g, 1);
         if constexpr (S::rd_wlA(g)) rd_w(wl[g - (GP - RW)], (R + 1) % 3, g - (GP - RW), 1);
         if constexpr (S::rd_xh(g)) rd_x(xh[(g - 2 * PB) / 2], R == 2 ? xb_nxt : xb_cur, (R + 1) % 3, (g - 2 * PB) / 2, 0);
-        if constexpr (S::put(g)) put_w(S::wq(g), S::wpiece(g), (R + 2) % 3);
+        if constexpr (S::slot_req(g)) { req_a(R, gl); req_b(R, gl); }      // slot R for stage L (consumed two taps from now)
+        if constexpr (S::put(g)) put_w(S::wq(g), (R + 2) % 3);
         if constexpr (S::req(g)) req_w(S::wq(g));
         // ---- scalar set-up of the stage, in the first gaps of tap 0 ----
-        if constexpr (R == 0) {
-          if constexpr (g == 0) src_of(tl, sl);
-          if constexpr (g == 2 && POS == 1) epi_setup(tc);
-        }
+        if constexpr (R == 0 && g == 2 && POS == 1) epi_setup(tc);
         if constexpr (R == 1 && g == PB + PB / 2) req_norm(tl, sl);                     // (used by tap 2's first operations)
         if constexpr (R == 2 && POS == 2 && g == PB) epi_loads(tc);
-        if constexpr (R == 0 && POS == 2 && g == 2 * PB) w_begin(tn.ng * NSTB);      // (this unit's requests are the next tile's stage 0)
+        if constexpr (R == 0 && POS == 2 && g == 1) w_begin(tn.ng * NSTB);           // (this unit's requests are the next tile's stage 0)
         // ---- the conversion's operations of this gap ----
         constexpr int o0 = S::first_op(NOPS, g), o1 = S::first_op(NOPS, g + 1);
         xw_static_for<o1 - o0>([&](auto d_tag) __attribute__((always_inline)) {
           constexpr int o = o0 + decltype(d_tag)::value;
           if constexpr (R == 0) {
             if constexpr (o < 8) write_op(J0{}, std::integral_constant<int, o>{});
-            else if constexpr (o < 10) reqs_op(J0{}, std::integral_constant<int, o - 8>{}, gl);
-            else full_op(J1{}, std::integral_constant<int, o - 10>{}, gx, gl);
+            else full_op(J1{}, std::integral_constant<int, o - 8>{}, gx, gl);
           } else if constexpr (R == 1) {
             full_op(J2{}, std::integral_constant<int, o>{}, gx, gl);
           } else {
