@@ -454,6 +454,7 @@ def main():
                 r = subprocess.run([sys.executable, tool, args.precision, 'bench'], capture_output=True, text=True, timeout=600)
                 js = [json.loads(l) for l in r.stdout.strip().splitlines() if l.startswith('{')]
                 cm, nc, n256 = js[0], js[1], js[2]
+                n256f = js[3] if len(js) > 3 else None      # the same network with the chip filled (B = 32): per-GPU batch 8 leaves the 256 CUs short of tiles
                 n256_bytes = 3645.7e6 + 4.0 * n256['params'] / n256['batch']      # fp32 layer-granular bytes per image-evaluation
                 cm_roof = HBM_PEAK_GBS * 1e9 / (2000 * (591.3e6 + ALG_WEIGHT_BYTES_PER_NFE / 64))
                 nc_bytes = 1085.7e6 + 4.0 * nc['params'] / 64
@@ -472,6 +473,11 @@ def main():
                                             'images_per_sec_2000_step_pc_equiv': n256['images_per_sec_per_nfe'] / 4000.0,
                                             'params': n256['params'], 'algorithmic_bytes_per_image_nfe': n256_bytes,
                                             'hbm_roofline_frac': n256['images_per_sec_per_nfe'] * n256_bytes / (HBM_PEAK_GBS * 1e9)}}
+                if n256f:
+                    fb = 3645.7e6 + 4.0 * n256f['params'] / n256f['batch']
+                    res['side_benches']['configs4_ncsnpp_256']['filled'] = {
+                        'image_evaluations_per_sec': n256f['images_per_sec_per_nfe'], 'batch': n256f['batch'],
+                        'hbm_roofline_frac': n256f['images_per_sec_per_nfe'] * fb / (HBM_PEAK_GBS * 1e9)}
             except Exception as e:
                 res['side_benches'] = {'error': str(e)[:200]}
         print(json.dumps(res))

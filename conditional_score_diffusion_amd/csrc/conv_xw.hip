@@ -88,11 +88,12 @@ __device__ __forceinline__ float xw_lo(int hp, float v) {      // v - (float)hal
 #ifndef XW_ABL
 #define XW_ABL 0
 #endif
+// Tuning-build stamps sit at TILE boundaries only (the loop top: no accumulator is live there).  A stamp is a branch; between a tile's
+// first MFMA and its epilogue's last accumulator read a control-flow edge lets hipcc move accumulators - unprotected reads of matrix
+// results: per-unit stamps made the tuning build return NaN, and tools/check_xp_isa.py now checks the tuning build as well.
 #ifdef CSD_FF_TUNE
-#define XW_TS(i) do { if (a_dbg && ts_on && tid == 0) a_dbg[blockIdx.x * 32 + (i)] = clock64(); } while (0)
 #define XW_WALL(i) do { if (a_dbg && tid == 0) a_dbg[blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
 #else
-#define XW_TS(i) do { } while (0)
 #define XW_WALL(i) do { } while (0)
 #endif
 
@@ -150,7 +151,6 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
   const int kh = lane >> 5, p32 = lane & 31, lg = lane & 3, ul = lane >> 2;
 #ifdef CSD_FF_TUNE
   long long* const a_dbg = k.a.dbg;
-  bool ts_on = false;
 #endif
   XW_WALL(30);
 
@@ -482,7 +482,6 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
       for (int e = 8 * NT; e < 32 * NT; ++e) req_res(e);
     }
     tie_acc_done();
-    XW_TS(23);
     float vs[NT], vq[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) vs[nt] = vq[nt] = 0.f;
@@ -521,7 +520,6 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
         else if (row != 3) XW_SADD(out_run, out_row);
       }
     }
-    XW_TS(24);
     if (a_stats) {
       const int lf = fresh_lane(), tidf = wave * 64 + lf;
 #pragma unroll
@@ -546,7 +544,6 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
         dst[1] = sq;
       }
     }
-    XW_TS(25);
   };
 
   Tile tc = tile_at(0), tn = tile_at(1);
@@ -617,13 +614,11 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
       XW_FENCE();
       if (!(XW_ABL & 64)) ff_barrier();
       XW_FENCE();
-      if (R == 0) XW_TS(0 + (s < 12 ? s : 12));
       if constexpr (R == 0) src_of(tl, sl);          // (scalar: the descriptor of stage L's requests, used from this tap's gap 0 on)
       constexpr int NOPS = R == 0 ? 8 + NFULL : R == 1 ? NFULL : 2 + NMATH;
       xw_static_for<GP>([&](auto g_tag) __attribute__((always_inline)) {
         constexpr int g = decltype(g_tag)::value;
         XW_FENCE();
-        if constexpr (g % NA == 0) { if (s == 2) XW_TS(14 + R * 3 + g / NA); }      // (tuning build: the nine products of unit 2)
         if constexpr (FIRST && R == 0 && g < NA) mm_first(g);
         else mm(g / NA, g % NA);
         XW_FENCE();
@@ -681,7 +676,6 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
   // =========================================================================================================================
   for (int it = 0; it < n_my; ++it) {
 #ifdef CSD_FF_TUNE
-    ts_on = it == 1;
     if (it == 1) XW_WALL(28);
     if (it == 2) XW_WALL(29);
     if (it == 1 && a_dbg && tid == 0) a_dbg[blockIdx.x * 32 + 26] = clock64();
@@ -692,7 +686,6 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
     gn = geom_of(tn);
     unit(P1{}, No{}, NS - 2);
     unit(P2{}, No{}, NS - 1);
-    XW_TS(13);
     epilogue();
     tc = tn;
     gc = gn;

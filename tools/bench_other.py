@@ -115,6 +115,7 @@ if __name__ == '__main__':
         cmde128()
         ncsnpp('ncsnpp_paired', 64)
         ncsnpp256(8)
+        ncsnpp256(32)
     else:
         cmde128()
         ncsnpp('ncsnpp_paired', 8)
