@@ -534,8 +534,9 @@ size_t convff_packed_bytes(const ConvPlan& p, int ns) {
 // weights in A-fragment order of v_mfma_f32_32x32x16_f16: [cout group][cin / 16][tap][cout tile][plane][lane][8 halves],
 // lane = (k half << 5) | cout row, scaled by 2^8 (exact) so the lo plane stays out of the fp16 subnormals
 __global__ void convff_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ wpack, int layout, int cin_src,
-                                   int cout_src, int cout_off, int Cin, int Cout, int ns, int nt) {
+                                   int cout_src, int cout_off, int Cin, int Cout, int ns, int nt, uint32_t* __restrict__ slack) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slack && idx < 1024) slack[idx] = 0u;          // the 4096-byte prefetch slack behind the fragments (see convff_pack_weight)
   const size_t total = (size_t)cout_src * Cin * 9;
   if (idx >= total) return;
   const int tap = (int)(idx % 9);
@@ -569,8 +570,9 @@ __global__ void convff_pack_kernel(const float* __restrict__ w, _Float16* __rest
 // conv_xw.hip's weights: G0 = g0, G1 = (g0 + g1 + g2) / 2, G2 = (g0 - g1 + g2) / 2, G3 = g2 of every filter row (g0, g1, g2), in
 // [cout group][cin / 16][filter row][component][cout tile][hi | lo][lane][8 halves]; transform in double, one rounding to fp32, x 2^8
 __global__ void convxw_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ wpack, int layout, int cin_src, int cout_src,
-                                   int cout_off, int Cin, int Cout, int nt) {
+                                   int cout_off, int Cin, int Cout, int nt, uint32_t* __restrict__ slack) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slack && idx < 1024) slack[idx] = 0u;
   const size_t total = (size_t)cout_src * Cin * 3;
   if (idx >= total) return;
   const int r = (int)(idx % 3);
@@ -613,24 +615,22 @@ int convff_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, in
     const size_t n32 = convff_packed_bytes(p, ns) / 4;
     hipLaunchKernelGGL(convff_zero_kernel, dim3((unsigned)cdiv64(n32, 256)), dim3(256), 0, s, (uint32_t*)wpack, n32);
     CSD_LAUNCH_CHECK();
-  } else if (cout_off == 0) {
-    // full coverage: only the 4096-byte slack behind the fragments (the weight streams prefetch past the last step; nothing
-    // multiplies it today, but it must never hold NaN patterns a future schedule could consume) - round-4 advisor finding
-    const size_t total_b = convff_packed_bytes(p, ns);
-    hipLaunchKernelGGL(convff_zero_kernel, dim3(4), dim3(256), 0, s, (uint32_t*)((char*)wpack + total_b - 4096), (size_t)1024);
-    CSD_LAUNCH_CHECK();
   }
+  // full coverage: only the 4096-byte slack behind the fragments is zeroed, by the pack kernel's first 1024 threads (the weight
+  // streams prefetch past the last step; nothing multiplies it today, but it must never hold NaN patterns a future schedule could
+  // consume - round-4 advisor finding; no extra launch: the training graph repacks every weight every step)
+  uint32_t* const slack = cout_off == 0 ? (uint32_t*)((char*)wpack + convff_packed_bytes(p, ns) - 4096) : nullptr;
   if (convff_winograd(p, ns)) {
     CSD_REQUIRE(layout == 0 || layout == 2, "convff: the Winograd pack takes 3x3 weights");
     const size_t total3 = (size_t)cout_src * Cin * 3;
     hipLaunchKernelGGL(convxw_pack_kernel, dim3((unsigned)cdiv64(total3, 256)), dim3(256), 0, s, w, (_Float16*)wpack, layout, cin_src,
-                       cout_src, cout_off, Cin, p.Cout, ff_nt(p.Cout));
+                       cout_src, cout_off, Cin, p.Cout, ff_nt(p.Cout), slack);
     CSD_LAUNCH_CHECK();
     return CSD_OK;
   }
   const size_t total = (size_t)cout_src * Cin * 9;
   hipLaunchKernelGGL(convff_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w, (_Float16*)wpack, layout,
-                     cin_src, cout_src, cout_off, Cin, p.Cout, ns, ff_nt(p.Cout));
+                     cin_src, cout_src, cout_off, Cin, p.Cout, ns, ff_nt(p.Cout), slack);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
