@@ -88,6 +88,7 @@ SIGNATURES = {
     'csd_unet_train_forward': (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _i, _f, ctypes.c_uint64, ctypes.c_uint64, _vp]),
     'csd_unet_backward': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _i, ctypes.c_uint64, _vp]),
     'csd_unet_train_release': (_i, [_vp, _vp]),
+    'csd_unet_train_release_call': (_i, [_vp, _vp, ctypes.c_uint64]),
     'csd_unet_backward_marks': (_i, [_vp, _vp, _vp, _i]),
     'csd_unet_backward_marks_epoch': (ctypes.c_uint64, [_vp]),
     'csd_event_create': (_vp, []),

@@ -63,9 +63,12 @@ static TrainState* train_state_find(const Net* n, const void* ws) {
   auto it = g_train.find(std::make_pair(n, ws));
   return it == g_train.end() ? nullptr : &it->second;
 }
-static void train_state_erase_one(const Net* n, const void* ws) {
+static void train_state_erase_one(const Net* n, const void* ws, const uint64_t* call = nullptr) {
   std::lock_guard<std::mutex> lk(g_train_mu);
-  g_train.erase(std::make_pair(n, ws));
+  auto it = g_train.find(std::make_pair(n, ws));
+  // (a release that names its forward's call index drops the record of THAT forward only: a finalizer that runs late - its context sat
+  // in a reference cycle - may find the allocator has handed the same address to a newer forward whose backward is still pending)
+  if (it != g_train.end() && (!call || it->second.call == *call)) g_train.erase(it);
 }
 // records whose forward has been consumed (or failed) and whose workspace is not `keep`: a long run with monitoring forwards in
 // private workspaces must not grow the map without bound (each record holds pointers into a workspace that may be gone)
@@ -1093,6 +1096,13 @@ extern "C" int csd_unet_train_release(csd_unet* net, const void* workspace) {
   int rc = train_check(net);
   if (rc) return rc;
   train_state_erase_one(&net->net, workspace);
+  return CSD_OK;
+}
+
+extern "C" int csd_unet_train_release_call(csd_unet* net, const void* workspace, uint64_t call_index) {
+  int rc = train_check(net);
+  if (rc) return rc;
+  train_state_erase_one(&net->net, workspace, &call_index);
   return CSD_OK;
 }
 

@@ -378,11 +378,12 @@ def _release_shared_ws(model_ref, owner):
         model._train_ws_owner = None
 
 
-def _release_private_ws(model_ref, handle, ws_ptr):
-    """a monitoring forward's private workspace is about to be freed: drop the library's record of it (csd_unet_train_release)"""
+def _release_private_ws(model_ref, handle, ws_ptr, call):
+    """a monitoring forward's private workspace is about to be freed: drop the library's record of THAT forward (by call index: a late
+    finalizer must not erase the record of a newer forward that was handed the same address - csd_unet_train_release_call)"""
     model = model_ref()
     if model is not None and getattr(model, '_h', None) is handle and handle is not None:
-        lib().csd_unet_train_release(handle, ctypes.c_void_p(ws_ptr))
+        lib().csd_unet_train_release_call(handle, ctypes.c_void_p(ws_ptr), ctypes.c_uint64(call))
 
 
 class _PlannedNet(torch.autograd.Function):
@@ -413,7 +414,7 @@ class _PlannedNet(torch.autograd.Function):
             ctx.fin = weakref.finalize(ctx, _release_shared_ws, weakref.ref(model), ctx.call)
         else:
             import weakref
-            weakref.finalize(ctx, _release_private_ws, weakref.ref(model), model._h, ws.data_ptr())
+            weakref.finalize(ctx, _release_private_ws, weakref.ref(model), model._h, ws.data_ptr(), ctx.call)
         ctx.shapes = [(p.shape, p.numel()) for p in params]
         # direct mode: the backward writes straight into the parameters' .grad views (the flat gradient buffer).  A parameter that
         # takes no gradient (the fixed Gaussian-Fourier W of NCSN++) has none: the library still writes one - into a throw-away buffer

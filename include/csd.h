@@ -411,6 +411,9 @@ int csd_unet_backward(csd_unet* net, const float* const* params, float* const* g
 /* The library keeps one recorded training graph per (handle, workspace).  A caller that frees a workspace (a monitoring forward's
  * private one) tells the library so: the record is dropped (no error if there is none).  csd_unet_destroy drops all of a handle's. */
 int csd_unet_train_release(csd_unet* net, const void* workspace);
+/* The same for the record of ONE forward: dropped only if it still is the record of csd_unet_train_forward call `call_index` (a late
+ * release must not erase the record of a newer forward that was given the same workspace address). */
+int csd_unet_train_release_call(csd_unet* net, const void* workspace, uint64_t call_index);
 /* Gradient-ready marks - what Lightning-DDP's bucketed all-reduce hooks into autograd for (run_lib.py:55-73), for a backward that is
  * ONE call: while csd_unet_backward enqueues its kernels on `stream`, it records events[k] on that stream as soon as every gradient
  * of the modules with all_modules index >= first_module[k] is final (the backward walks all_modules back to front; the embedding
