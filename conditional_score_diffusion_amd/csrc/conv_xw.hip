@@ -84,7 +84,7 @@ __device__ __forceinline__ float xw_lo(int hp, float v) {      // v - (float)hal
 #define XW_PIN(a) asm volatile("" : "+v"(a))
 // tuning aids (never in the product library): XW_ABL bits remove parts of the stream at compile time (results are then garbage):
 // 1 conversion, 2 weight staging, 4 fragment reads, 8 epilogue stores, 16 patch requests, 32 residual requests, 64 barriers,
-// 4096 patch requests confined to the first 256 pixels of the sample (cache hits), 256 patch stores, 512 neighbour exchange (own value instead), 1024 transcendentals (plain multiplies instead), 2048 hi | lo split
+// 16384 row-tap barriers without the LDS wait, 4096 patch requests confined to the first 256 pixels of the sample (cache hits), 256 patch stores, 512 neighbour exchange (own value instead), 1024 transcendentals (plain multiplies instead), 2048 hi | lo split
 #ifndef XW_ABL
 #define XW_ABL 0
 #endif
