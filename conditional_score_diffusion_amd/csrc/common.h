@@ -157,7 +157,8 @@ int conv16q_plan_tiles(ConvPlan* p, int ns);
 bool conv16q_up4_supported(const ConvPlan& p, int ns);
 size_t conv16q_up4_packed_bytes(const ConvPlan& p, int ns);
 int conv16q_pack_weight_up4(const ConvPlan& p, int ns, const float* w, void* wpack, hipStream_t s);
-int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s);
+// raw: src0 is the fp32 NHWC source itself (ns = 2, a layer without a GroupNorm in front: the kernel's staging does the hi | lo split)
+int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s, bool raw = false);
 // fused-prologue schedule (conv_ff.hip): 3x3 stride-1 layers on 16 x 16 tiles that lie inside one sample, fp32 NHWC sources
 // (two-source virtual concat), GroupNorm affine + activation + fp16 split applied while staging (no gn_apply16 pass)
 bool convff_supported(const ConvPlan& p, int ns);

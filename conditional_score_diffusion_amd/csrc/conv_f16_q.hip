@@ -58,18 +58,24 @@ typedef int int8q __attribute__((ext_vector_type(8)));
 // one per output phase (a, b) = (row, column parity): output (2y+a, 2x+b) reads source rows {y-1, y} (a = 0) or {y, y+1} (a = 1) -
 // taps that land on the same source pixel are summed when the weights are packed (conv16q_pack_up4_kernel).  4 taps instead of 9 per
 // output pixel (2.25x fewer MACs); a workgroup = (source tile, phase, cout group), its outputs are written with stride 2.
-template <int MQ, int NS, bool MASK, int PWC, int S, int NTQ, bool F8, bool UP4 = false>
+// RAW (NS = 2, resampling convs and other layers without a GroupNorm in front): g_hi is the fp32 NHWC SOURCE tensor itself and the staging
+// burst splits it into the hi | lo planes of the LDS patch on the way (two float4 in, two 16-byte pieces out per (pixel, 8 channels):
+// the same registers as the two plane pieces) - the gn_apply16 pass that wrote the planes (fp32 read + 2 x fp16 written + read again)
+// is gone; the arithmetic is that pass's: hi = fp16(x), lo = fp16(x - hi).
+template <int MQ, int NS, bool MASK, int PWC, int S, int NTQ, bool F8, bool UP4 = false, bool RAW = false>
 __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void* __restrict__ g_hi,
                                                                     const void* __restrict__ g_lo,
                                                                     const char* __restrict__ g_wpack,
                                                                     const Conv16KArgs k) {
   static_assert(!UP4 || (S == 1 && !F8), "the phase form is the stride-1 Upsample conv (a resampling conv: full split)");
+  static_assert(!RAW || (NS == 2 && !F8), "the fp32-source form splits into two fp16 planes");
   constexpr int TAPS = UP4 ? 4 : 9, KS = UP4 ? 2 : 3, KCS = 2;
   constexpr int LO = 32 * KCS;               // byte offset of the lo plane inside a staged pixel
   constexpr int PSB = 32 * KCS * NS + 16;    // bytes per staged pixel
   constexpr int NPIX = 2 * MQ * 16;          // pixels per workgroup tile
   constexpr int SPP = 2 * NS * KCS;          // 16-byte slots per patch pixel per stage
-  constexpr int NU = (S == 2) ? ((NS == 2) ? 10 : 5) : ((NS == 2) ? 7 : 4);      // staging slots per thread (host: patch * SPP <= NU * 256)
+  constexpr int NU0 = (S == 2) ? ((NS == 2) ? 10 : 5) : ((NS == 2) ? 7 : 4);     // staging slots per thread (host: patch * SPP <= NU0 * 256)
+  constexpr int NU = RAW ? 2 * ((NU0 + 1) / 2) : NU0;                            // RAW: slot PAIRS (pixel, 8 channels), two registers quads each
   constexpr int rstride = PWC * PSB;
   constexpr int WSTEP = NTQ * NS * 1024;     // weight bytes per K step per wave
   constexpr int GC = 32 * NTQ, HC = 16 * NTQ; // couts per workgroup / per N half
@@ -161,7 +167,30 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
   }
 
   // ---- staging: slot e = pixel * SPP + plane * 2*KCS + 16-byte piece ----
-  const int total4 = npatch * SPP;
+  const int total4 = RAW ? npatch * 2 * KCS : npatch * SPP;
+  // RAW: pair e = pixel * 2 KCS + 8-channel group; half = 0 | 1: the group's first | second float4
+  auto raw_load = [&](int e, int cb, int half) -> float4 {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < total4) {
+      const int pix = e / (2 * KCS), grp = e - pix * (2 * KCS);
+      const int sp = stab[pix];
+      if (sp >= 0) v = gload4f(static_cast<const float*>(g_hi) + (size_t)sp * Cin + cb + grp * 8 + half * 4);
+    }
+    return v;
+  };
+  auto raw_store = [&](int e, const float4& a, const float4& b) {
+    if (e >= total4) return;
+    const int pix = e / (2 * KCS), grp = e - pix * (2 * KCS);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    half8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      h[j] = (_Float16)v[j];
+      l[j] = (_Float16)(v[j] - (float)h[j]);
+    }
+    *reinterpret_cast<half8*>(smem16 + dtab[pix] + grp * 16) = h;
+    *reinterpret_cast<half8*>(smem16 + dtab[pix] + LO + grp * 16) = l;
+  };
   auto slot_load = [&](int e, int cb) -> float4 {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < total4) {
@@ -224,10 +253,17 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
   // first stage: one burst
   {
     float4 v0[NU];
+    if constexpr (RAW) {
 #pragma unroll
-    for (int j = 0; j < NU; ++j) v0[j] = slot_load(j * C16Q_THREADS + tid, 0);
+      for (int j = 0; j < NU; ++j) v0[j] = raw_load((j >> 1) * C16Q_THREADS + tid, 0, j & 1);
 #pragma unroll
-    for (int j = 0; j < NU; ++j) slot_store(j * C16Q_THREADS + tid, v0[j]);
+      for (int j = 0; j < NU; j += 2) raw_store((j >> 1) * C16Q_THREADS + tid, v0[j], v0[j + 1]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NU; ++j) v0[j] = slot_load(j * C16Q_THREADS + tid, 0);
+#pragma unroll
+      for (int j = 0; j < NU; ++j) slot_store(j * C16Q_THREADS + tid, v0[j]);
+    }
   }
   __syncthreads();
   Q_TSTAMP();
@@ -238,7 +274,8 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
     float4 sv[NU];
     if (more) {                                 // next stage's burst: in flight under this stage's MFMAs
 #pragma unroll
-      for (int j = 0; j < NU; ++j) sv[j] = slot_load(j * C16Q_THREADS + tid, (stg + 1) * 32);
+      for (int j = 0; j < NU; ++j)
+        sv[j] = RAW ? raw_load((j >> 1) * C16Q_THREADS + tid, (stg + 1) * 32, j & 1) : slot_load(j * C16Q_THREADS + tid, (stg + 1) * 32);
     }
 #ifdef CSD_Q_RING
     constexpr int RING = CSD_Q_RING;
@@ -331,8 +368,13 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
     Q_TSTAMP();
     if (more) {
       __syncthreads();                          // everyone is done reading this stage's patch
+      if constexpr (RAW) {
 #pragma unroll
-      for (int j = 0; j < NU; ++j) slot_store(j * C16Q_THREADS + tid, sv[j]);
+        for (int j = 0; j < NU; j += 2) raw_store((j >> 1) * C16Q_THREADS + tid, sv[j], sv[j + 1]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) slot_store(j * C16Q_THREADS + tid, sv[j]);
+      }
       __syncthreads();
     }
   }
@@ -624,9 +666,9 @@ int conv16q_plan_tiles(ConvPlan* p, int ns) {
   return CSD_OK;
 }
 
-template <int MQ, int NS, bool MASK, int PWC, int S, int NTQ, bool F8 = false, bool UP4 = false>
+template <int MQ, int NS, bool MASK, int PWC, int S, int NTQ, bool F8 = false, bool UP4 = false, bool RAW = false>
 static int launch_q(const Conv16KArgs& k, size_t lds, hipStream_t s) {
-  auto kern = conv_f16_q_kernel<MQ, NS, MASK, PWC, S, NTQ, F8, UP4>;
+  auto kern = conv_f16_q_kernel<MQ, NS, MASK, PWC, S, NTQ, F8, UP4, RAW>;
   static bool attr_set = false;
   if (!attr_set) {
     CSD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -638,7 +680,20 @@ static int launch_q(const Conv16KArgs& k, size_t lds, hipStream_t s) {
   return CSD_OK;
 }
 
-int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
+// the fp32-source (RAW) forms exist for the full split with three or four cout tiles per N half
+template <int MQ, int NS, bool MASK, int PWC, int S, int NTQ, bool UP4>
+static int launch_q_src(bool raw, const Conv16KArgs& k, size_t lds, hipStream_t s) {
+  if constexpr (NS == 2 && NTQ >= 3) {
+    if (raw) return launch_q<MQ, NS, MASK, PWC, S, NTQ, false, UP4, true>(k, lds, s);
+  }
+  if (raw) {
+    set_error("conv16q: no fp32-source kernel for ns=%d NT=%d", NS, NTQ);
+    return CSD_ERR_INVALID;
+  }
+  return launch_q<MQ, NS, MASK, PWC, S, NTQ, false, UP4, false>(k, lds, s);
+}
+
+int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s, bool raw) {
   const bool up4 = p.up == 2;
   CSD_REQUIRE(up4 ? conv16q_up4_supported(p, ns) : conv16q_supported(p, ns), "conv16q: unsupported layer");
   CSD_REQUIRE(!a.out_nchw && a.nscale == nullptr && a.out_stride % 4 == 0 && a.out_coff % 4 == 0,
@@ -673,11 +728,11 @@ int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) 
 #define CSD_QU_CASE(MQ_, NS_, NTQ_)                                                              \
   if (up4 && p.MT == MQ_ && ns == NS_ && p.NT == NTQ_) {                                        \
     if (p.PW <= 24) {                                                                            \
-      if (mask) return launch_q<MQ_, NS_, true, 24, 1, NTQ_, false, true>(k, p.lds_bytes, s);    \
-      return launch_q<MQ_, NS_, false, 24, 1, NTQ_, false, true>(k, p.lds_bytes, s);             \
+      if (mask) return launch_q_src<MQ_, NS_, true, 24, 1, NTQ_, true>(raw, k, p.lds_bytes, s);    \
+      return launch_q_src<MQ_, NS_, false, 24, 1, NTQ_, true>(raw, k, p.lds_bytes, s);             \
     }                                                                                            \
-    if (mask) return launch_q<MQ_, NS_, true, 34, 1, NTQ_, false, true>(k, p.lds_bytes, s);      \
-    return launch_q<MQ_, NS_, false, 34, 1, NTQ_, false, true>(k, p.lds_bytes, s);               \
+    if (mask) return launch_q_src<MQ_, NS_, true, 34, 1, NTQ_, true>(raw, k, p.lds_bytes, s);      \
+    return launch_q_src<MQ_, NS_, false, 34, 1, NTQ_, true>(raw, k, p.lds_bytes, s);               \
   }
   CSD_QU_CASE(4, 2, 3) CSD_QU_CASE(2, 2, 3) CSD_QU_CASE(4, 1, 3) CSD_QU_CASE(2, 1, 3)
   CSD_QU_CASE(4, 2, 4) CSD_QU_CASE(2, 2, 4) CSD_QU_CASE(4, 1, 4) CSD_QU_CASE(2, 1, 4)
@@ -686,19 +741,19 @@ int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) 
 #define CSD_Q_CASE(MQ_, NS_, NTQ_)                                                  \
   if (p.MT == MQ_ && ns == NS_ && p.NT == NTQ_ && p.stride == 1) {                  \
     if (p.PW <= 24) {                                                               \
-      if (mask) return launch_q<MQ_, NS_, true, 24, 1, NTQ_>(k, p.lds_bytes, s);    \
-      return launch_q<MQ_, NS_, false, 24, 1, NTQ_>(k, p.lds_bytes, s);             \
+      if (mask) return launch_q_src<MQ_, NS_, true, 24, 1, NTQ_, false>(raw, k, p.lds_bytes, s);    \
+      return launch_q_src<MQ_, NS_, false, 24, 1, NTQ_, false>(raw, k, p.lds_bytes, s);             \
     }                                                                               \
-    if (mask) return launch_q<MQ_, NS_, true, 34, 1, NTQ_>(k, p.lds_bytes, s);      \
-    return launch_q<MQ_, NS_, false, 34, 1, NTQ_>(k, p.lds_bytes, s);               \
+    if (mask) return launch_q_src<MQ_, NS_, true, 34, 1, NTQ_, false>(raw, k, p.lds_bytes, s);      \
+    return launch_q_src<MQ_, NS_, false, 34, 1, NTQ_, false>(raw, k, p.lds_bytes, s);               \
   }                                                                                 \
   if (p.MT == MQ_ && ns == NS_ && p.NT == NTQ_ && p.stride == 2) {                  \
     if (p.PW <= 24) {                                                               \
-      if (mask) return launch_q<MQ_, NS_, true, 24, 2, NTQ_>(k, p.lds_bytes, s);    \
-      return launch_q<MQ_, NS_, false, 24, 2, NTQ_>(k, p.lds_bytes, s);             \
+      if (mask) return launch_q_src<MQ_, NS_, true, 24, 2, NTQ_, false>(raw, k, p.lds_bytes, s);    \
+      return launch_q_src<MQ_, NS_, false, 24, 2, NTQ_, false>(raw, k, p.lds_bytes, s);             \
     }                                                                               \
-    if (mask) return launch_q<MQ_, NS_, true, 34, 2, NTQ_>(k, p.lds_bytes, s);      \
-    return launch_q<MQ_, NS_, false, 34, 2, NTQ_>(k, p.lds_bytes, s);               \
+    if (mask) return launch_q_src<MQ_, NS_, true, 34, 2, NTQ_, false>(raw, k, p.lds_bytes, s);      \
+    return launch_q_src<MQ_, NS_, false, 34, 2, NTQ_, false>(raw, k, p.lds_bytes, s);               \
   }
 #define CSD_Q8_CASE(MQ_, NTQ_)                                                         \
   if (p.MT == MQ_ && ns == 3 && p.NT == NTQ_ && p.stride == 1) {                     \
@@ -717,6 +772,7 @@ int conv16q_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) 
     if (mask) return launch_q<MQ_, 2, true, 34, 2, NTQ_, true>(k, p.lds_bytes, s);    \
     return launch_q<MQ_, 2, false, 34, 2, NTQ_, true>(k, p.lds_bytes, s);             \
   }
+  CSD_REQUIRE(!(raw && ns == 3), "conv16q: the fp8-correction form reads pre-split planes");
   CSD_Q8_CASE(4, 3) CSD_Q8_CASE(2, 3) CSD_Q8_CASE(2, 1)      // (Cout % 96 == 0 only: with four cout tiles the 128-pixel form spills; those nets run the full split)
 #undef CSD_Q8_CASE
   CSD_Q_CASE(4, 2, 3) CSD_Q_CASE(2, 2, 3) CSD_Q_CASE(4, 1, 3) CSD_Q_CASE(2, 1, 3) CSD_Q_CASE(2, 2, 1)

@@ -988,7 +988,12 @@ struct Builder {
     o.d = norm ? nscale : NONE;
     o.e = norm ? nshift : NONE;
     size_t hi16 = NONE, lo16 = NONE;
-    if (pc.ns && !pc.pw && !pc.ff && (norm || pc.q) && !fused) {
+    // a quad-schedule conv WITHOUT a GroupNorm in front (Downsample / Upsample, the FIR-resampled Conv_0 of NCSN++) in the full split reads
+    // its fp32 source directly: the split happens in the kernel's staging burst (no plane write / read)
+    const bool q_raw = pc.q && !norm && pc.ns == 2 && o.cp.C1 == 0 && (o.cp.NT == 3 || o.cp.NT == 4) && !CSD_TUNE_ENV("CSD_NO_Q_RAW");
+    if (q_raw) {
+      o.i3 = 2;
+    } else if (pc.ns && !pc.pw && !pc.ff && (norm || pc.q) && !fused) {
       // fp16 kernel: normalise + activate + split ONCE per element into fp16 planes, conv copies them
       // (a quad-schedule conv without a GroupNorm - Upsample, the FIR-resampled Conv_0 of NCSN++ - gets a plain split)
       const size_t nh = ((size_t)B * ih * iw * (o.cp.C0 + o.cp.C1) + 1) / 2;      // halves -> floats
@@ -1674,7 +1679,7 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         a.dbg = nullptr;
         a.stats = reinterpret_cast<double*>(W(o.stats));
         rc = o.i2 == 3 ? convff_launch(o.cp, o.i4, a, so)
-           : o.i2 == 2 ? conv16q_launch(o.cp, o.i4, a, so)
+           : o.i2 == 2 ? conv16q_launch(o.cp, o.i4, a, so, o.i3 == 2)
            : o.i2 ? pw16_launch(o.cp, o.i4, a, so) : (o.i4 ? conv16_launch(o.cp, o.i4, a, so, o.i3 != 0) : conv_launch(o.cp, a, so));
         if (so != s && rc == CSD_OK) {
           CSD_CHECK_HIP(hipEventRecord(n.ev_join, n.side));
