@@ -84,7 +84,7 @@ __device__ __forceinline__ float xw_lo(int hp, float v) {      // v - (float)hal
 #define XW_PIN(a) asm volatile("" : "+v"(a))
 // tuning aids (never in the product library): XW_ABL bits remove parts of the stream at compile time (results are then garbage):
 // 1 conversion, 2 weight staging, 4 fragment reads, 8 epilogue stores, 16 patch requests, 32 residual requests, 64 barriers,
-// 16384 row-tap barriers without the LDS wait, 4096 patch requests confined to the first 256 pixels of the sample (cache hits), 256 patch stores, 512 neighbour exchange (own value instead), 1024 transcendentals (plain multiplies instead), 2048 hi | lo split
+// 16384 row-tap barriers without the LDS wait, 32768 the weight ring's LDS stores (the requests stay), 4096 patch requests confined to the first 256 pixels of the sample (cache hits), 256 patch stores, 512 neighbour exchange (own value instead), 1024 transcendentals (plain multiplies instead), 2048 hi | lo split
 #ifndef XW_ABL
 #define XW_ABL 0
 #endif
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xw_kernel(const char* __re
     XW_SADD(w_run, c4096);
   };
   auto put_w = [&](int q, int slot) __attribute__((always_inline)) {
-    if (XW_ABL & 2) return;
+    if (XW_ABL & (2 | 32768)) return;
     *reinterpret_cast<xw_u4*>(smem + C::slot_off(slot) + q * 4096 + wvoff) = wr[q];
   };
 

@@ -85,18 +85,32 @@ __global__ __launch_bounds__(TN_THREADS) void gn_bwd_stats_nhwc_kernel(
 
 // pass 2: fold the chunks; dgamma / dbeta rows; per-(sample, channel) coefficients of pass 3:
 //   dx = du*ca - cb - xhat*cc,  ca = rstd*gamma, cb = rstd*mean_g(du*gamma), cc = rstd*mean_g(du*gamma*xhat)
+// (the chunk fold runs on L lanes per channel, lane l taking chunks l, l + L, ... and the lanes folded in lane order: one thread per
+// channel walking 128 chunks of a small-batch step was 17 us of pure latency per GroupNorm)
 __global__ void gn_bwd_final_nhwc_kernel(const double* __restrict__ partial, const float* __restrict__ gamma,
                                          const float* __restrict__ rs, float* __restrict__ dgamma_rows,
                                          float* __restrict__ dbeta_rows, float* __restrict__ coef, int HW, int C, int G,
-                                         int nchunk, int row_stride) {
-  extern __shared__ __attribute__((aligned(16))) double sh[];   // [C][2]
+                                         int nchunk, int row_stride, int L) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];   // [C][2], then [L][C][2]
+  double* const lane_sums = sh + (size_t)C * 2;
   const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  for (int i = threadIdx.x; i < L * C; i += blockDim.x) {
+    const int l = i / C, c = i - l * C;
     double a1 = 0, a2 = 0;
-    for (int k = 0; k < nchunk; ++k) {
+    for (int k = l; k < nchunk; k += L) {
       const double* p = partial + (((size_t)b * nchunk + k) * C + c) * 2;
       a1 += p[0];
       a2 += p[1];
+    }
+    lane_sums[(size_t)i * 2] = a1;
+    lane_sums[(size_t)i * 2 + 1] = a2;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double a1 = 0, a2 = 0;
+    for (int l = 0; l < L; ++l) {
+      a1 += lane_sums[((size_t)l * C + c) * 2];
+      a2 += lane_sums[((size_t)l * C + c) * 2 + 1];
     }
     sh[c * 2] = a1;
     sh[c * 2 + 1] = a2;
@@ -204,13 +218,23 @@ __global__ __launch_bounds__(TN_THREADS) void sum_pixels_nhwc_kernel(const float
     partial[((size_t)b * nchunk + chunk) * C + i] = a;
   }
 }
-__global__ void sum_pixels_final_kernel(const double* __restrict__ partial, float* __restrict__ out, int C, int nchunk) {
+// 32 channels x 8 chunk lanes per workgroup (lane l: chunks l, l + 8, ...; lanes folded in lane order)
+__global__ __launch_bounds__(256) void sum_pixels_final_kernel(const double* __restrict__ partial, float* __restrict__ out, int C, int nchunk) {
+  __shared__ double sh[8][32];
   const int b = blockIdx.y;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int tx = threadIdx.x & 31, l = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
   double a = 0;
-  for (int k = 0; k < nchunk; ++k) a += partial[((size_t)b * nchunk + k) * C + c];
-  out[(size_t)b * C + c] = (float)a;
+  if (c < C)
+    for (int k = l; k < nchunk; k += 8) a += partial[((size_t)b * nchunk + k) * C + c];
+  sh[l][tx] = a;
+  __syncthreads();
+  if (l == 0 && c < C) {
+    double t = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += sh[j][tx];
+    out[(size_t)b * C + c] = (float)t;
+  }
 }
 
 // z[b][2y+1][2x+1][c] = dy[b][y][x][c], zeros elsewhere (data gradient of the pad-(0,1,0,1) stride-2 Downsample conv)
@@ -302,8 +326,9 @@ int csd::groupnorm_act_backward_nhwc_add(const float* x, const float* gamma, con
   hipLaunchKernelGGL(gn_bwd_stats_nhwc_kernel, dim3(nchunk, B), dim3(TN_THREADS), (size_t)rows * C * 2 * sizeof(double), s, x, dy,
                      gamma, beta, rs, ms, partial, HW, C, act, nchunk);
   CSD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_final_nhwc_kernel, dim3(B), dim3(256), (size_t)C * 2 * sizeof(double), s, partial, gamma, rs,
-                     dgamma_rows, dbeta_rows, coef, HW, C, groups, nchunk, row_stride);
+  const int fl = std::max(1, std::min(std::min(16, nchunk), 1024 / C));      // chunk lanes per channel of the fold
+  hipLaunchKernelGGL(gn_bwd_final_nhwc_kernel, dim3(B), dim3(std::min(1024, std::max(256, fl * C))), (size_t)C * 2 * (1 + fl) * sizeof(double), s,
+                     partial, gamma, rs, dgamma_rows, dbeta_rows, coef, HW, C, groups, nchunk, row_stride, fl);
   CSD_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_bwd_apply_nhwc_kernel, dim3(nchunk, B), dim3(TN_THREADS), 0, s, x, dy, gamma, beta, rs, ms, coef, add, dx,
                      HW, C, act, nchunk);
@@ -342,7 +367,7 @@ extern "C" int csd_sum_pixels_nhwc(const float* x, float* out, int B, int HW, in
   hipLaunchKernelGGL(sum_pixels_nhwc_kernel, dim3(nchunk, B), dim3(TN_THREADS), (size_t)rows * C * sizeof(double), s, x, partial, HW,
                      C, nchunk);
   CSD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sum_pixels_final_kernel, dim3(cdiv(C, 64), B), dim3(64), 0, s, partial, out, C, nchunk);
+  hipLaunchKernelGGL(sum_pixels_final_kernel, dim3(cdiv(C, 32), B), dim3(256), 0, s, partial, out, C, nchunk);
   CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
