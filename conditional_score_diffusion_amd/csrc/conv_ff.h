@@ -75,5 +75,8 @@ int convxp_launch(const ConvFFArgs& k, int nt, hipStream_t s);
 // conv_xw.hip: conv_xp's stream in the 1-D Winograd F(2,3) form (4 instead of 6 contractions per output pair; its own packed weights)
 bool convxw_supported(const ConvFFArgs& k, int nt);
 int convxw_launch(const ConvFFArgs& k, int nt, hipStream_t s);
+// conv_xk.hip: conv_xw's operator with one transform component per wave (weights from L2 straight into registers, no LDS ring)
+bool convxk_supported(const ConvFFArgs& k, int nt);
+int convxk_launch(const ConvFFArgs& k, int nt, hipStream_t s);
 
 }  // namespace csd

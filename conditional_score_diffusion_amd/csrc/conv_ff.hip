@@ -701,6 +701,9 @@ int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
   // conv_xw.hip: conv_xp's stream in the Winograd F(2,3) form (the weights were packed for it: convff_winograd is the one switch)
   if (convff_winograd(p, ns)) {
     CSD_REQUIRE(convxw_supported(k, nt), "convff: Winograd layer outside conv_xw's range");
+    // (conv_xk.hip: the same operator and packed weights, one transform component per wave.  Tuning build: CSD_XK=0 keeps conv_xw)
+    const char* xk = CSD_TUNE_ENV("CSD_XK");
+    if (convxk_supported(k, nt) && !(xk && atoi(xk) == 0)) return convxk_launch(k, nt, s);
     return convxw_launch(k, nt, s);
   }
   // conv_xp.hip (fp16x3: one persistent 4-wave workgroup per CU, the conversion / fragment reads / weight staging placed between

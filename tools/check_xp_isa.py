@@ -30,7 +30,7 @@ def check(name, lines):
             dst = ln.split()[1].rstrip(',')
             tuples.add(dst)
             acc |= regs(dst)
-    m = re.search(r'conv_x([pw])_kernelILi(\d)E', name)
+    m = re.search(r'conv_x([pwk])_kernelILi(\d)E', name)
     per_nt = 2 if m.group(1) == 'p' else 4
     nt = int(m.group(2))
     errs = []
@@ -63,7 +63,7 @@ def main(path):
     text = open(path).read().split('\n')
     kernels, cur, name = {}, None, None
     for ln in text:
-        m = re.match(r'^(_ZN3csd14conv_x[pw]_kernel\w+):', ln)
+        m = re.match(r'^(_ZN3csd14conv_x[pwk]_kernel\w+):', ln)
         if m:
             name, cur = m.group(1), []
             continue
