@@ -504,12 +504,26 @@ long long* g_ff_dbg = nullptr;      // tuning aid: per-workgroup phase stamps (c
 // cout tiles per workgroup: 3 (96 couts: the nf = 96 nets) or 2 (64 couts: the nf = 128 nets - four tiles need 256 VGPRs + spills)
 static inline int ff_nt(int cout) { return cout % 96 == 0 ? 3 : 2; }
 
+// Maps that 16 does not divide (the 40^2 level of the 160^2 nets) run on RAGGED tiles - in conv_xk.hip alone: its epilogue masks the lanes
+// whose 4 x 8-pixel block lies outside the image (8 | H, W), the patch geometry pads with zeros as at any image border.  Worth it while
+// the tiles are at least 65 % full (40^2: 9 tiles of which 6.25 are work; the alternative is the quad kernel behind a gn_apply16 pass).
+static bool ff_ragged_ok(const ConvPlan& p, int ns) {
+  const int nstage = (p.C0 + p.C1) / 16;
+  const char* xk = CSD_TUNE_ENV("CSD_XK");
+  const char* xw = CSD_TUNE_ENV("CSD_XW");
+  if ((xk && atoi(xk) == 0) || (xw && atoi(xw) == 0) || CSD_TUNE_ENV("CSD_XP_OPS_OFF") || CSD_TUNE_ENV("CSD_NO_RAGGED")) return false;
+  const int th = (p.OH + FF_TILE - 1) / FF_TILE * FF_TILE, tw = (p.OW + FF_TILE - 1) / FF_TILE * FF_TILE;
+  return ns == 2 && p.Cout % 96 == 0 && nstage >= 4 && nstage % 2 == 0 && p.OH % 8 == 0 && p.OW % 8 == 0 && p.OH > FF_TILE && p.OW > FF_TILE &&
+         (double)p.OH * p.OW >= 0.65 * th * tw;
+}
+static bool ff_ragged(const ConvPlan& p) { return p.OH % FF_TILE != 0 || p.OW % FF_TILE != 0; }
+
 bool convff_supported(const ConvPlan& p, int ns) {
   if (CSD_TUNE_ENV("CSD_NO_FF")) return false;
   const int kc = ns == 1 ? 32 : 16;
   return (ns >= 1 && ns <= 3) && p.taps == 9 && p.stride == 1 && p.up == 0 && p.pad == 1 && p.C0 > 0 && p.C0 % kc == 0 &&
-         p.C1 % kc == 0 && (p.Cout % 96 == 0 || (p.Cout % 64 == 0 && !CSD_TUNE_ENV("CSD_FF_NO_NT2"))) && p.OH % FF_TILE == 0 && p.OW % FF_TILE == 0 &&
-         p.IH == p.OH && p.IW == p.OW;
+         p.C1 % kc == 0 && (p.Cout % 96 == 0 || (p.Cout % 64 == 0 && !CSD_TUNE_ENV("CSD_FF_NO_NT2"))) &&
+         (!ff_ragged(p) || ff_ragged_ok(p, ns)) && p.IH == p.OH && p.IW == p.OW;
 }
 
 bool convff_pipelined(const ConvPlan& p, int ns) {
@@ -646,8 +660,8 @@ int convff_plan_tiles(ConvPlan* p, int ns) {
   p->MT = 0;
   p->TH = p->TW = FF_TILE;
   p->PH = p->PW = FF_PW;
-  p->tiles_x = p->OW / FF_TILE;
-  p->tiles_y = p->B * p->OH / FF_TILE;
+  p->tiles_x = cdiv(p->OW, FF_TILE);
+  p->tiles_y = p->B * cdiv(p->OH, FF_TILE);
   p->lds_bytes = 0;
   return CSD_OK;
 }
@@ -681,8 +695,8 @@ int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
   ConvFFArgs k;
   k.a = a;
   k.B = p.B; k.H = p.OH; k.W = p.OW; k.C0 = p.C0; k.C1 = p.C1; k.Cout = p.Cout;
-  k.tiles_x = p.OW / FF_TILE;
-  k.tpi = (p.OH / FF_TILE) * k.tiles_x;
+  k.tiles_x = cdiv(p.OW, FF_TILE);
+  k.tpi = cdiv(p.OH, FF_TILE) * k.tiles_x;
   k.n_groups = p.Cout / (32 * ff_nt(p.Cout));
   k.nblocks = p.B * k.tpi * k.n_groups;
   k.nstage = (p.C0 + p.C1) / (ns == 1 ? 32 : 16);
@@ -704,6 +718,7 @@ int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
     // (conv_xk.hip: the same operator and packed weights, one transform component per wave.  Tuning build: CSD_XK=0 keeps conv_xw)
     const char* xk = CSD_TUNE_ENV("CSD_XK");
     if (convxk_supported(k, nt) && !(xk && atoi(xk) == 0)) return convxk_launch(k, nt, s);
+    CSD_REQUIRE(!ff_ragged(p), "convff: ragged tiles run on conv_xk only");
     return convxw_launch(k, nt, s);
   }
   // conv_xp.hip (fp16x3: one persistent 4-wave workgroup per CU, the conversion / fragment reads / weight staging placed between

@@ -76,7 +76,7 @@ __device__ __forceinline__ float xk_lo(int hp, float v) {      // v - (float)hal
 #define XW_PIN(a) asm volatile("" : "+v"(a))
 // tuning aids (never in the product library): XK_ABL bits remove parts of the stream at compile time (results are then garbage):
 // 1 conversion, 2 weight staging, 4 fragment reads, 8 epilogue stores, 16 patch requests, 32 residual requests, 64 barriers,
-// 16384 row-tap barriers without the LDS wait, 32768 the weight ring's LDS stores (the requests stay), 4096 patch requests confined to the first 256 pixels of the sample (cache hits), 256 patch stores, 512 neighbour exchange (own value instead), 1024 transcendentals (plain multiplies instead), 2048 hi | lo split
+// 16384 row-tap barriers without the LDS wait, 128 the epilogue's exchange stores, 65536 its barriers, 131072 its reads (own accumulators instead), 32768 the weight ring's LDS stores (the requests stay), 4096 patch requests confined to the first 256 pixels of the sample (cache hits), 256 patch stores, 512 neighbour exchange (own value instead), 1024 transcendentals (plain multiplies instead), 2048 hi | lo split
 #ifndef XK_ABL
 #define XK_ABL 0
 #endif
@@ -411,6 +411,7 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xk_kernel(const char* __re
   float bv[NT], tv[NT];
   __amdgpu_buffer_rsrc_t res_r, out_r;
   unsigned res_voff = 0, out_voff = 0;
+  bool e_valid = true;
   int e_tile = 0, e_ng = 0;
   const int res_col = kCout * 4, res_row = (kW - 7) * kCout * 4, out_col = a_out_stride * 4, out_row = (kW - 7) * a_out_stride * 4;
   int res_run = 0;
@@ -427,8 +428,11 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xk_kernel(const char* __re
   auto epi_loads = [&](const Tile& t) __attribute__((always_inline)) {      // under the tile's last tap: the per-lane offsets, bias, temb
     const int lf = fresh_lane();
     const int c_lane = t.ng * NT * 32 + (lf & 31);
-    out_voff = (unsigned)((4 * wave * kW + 8 * (lf >> 5)) * a_out_stride + c_lane) * 4u;
-    if constexpr (RES) res_voff = (unsigned)((4 * wave * kW + 8 * (lf >> 5)) * kCout + c_lane) * 4u;
+    // (ragged tiles - maps of 8 k x 8 k pixels that 16 does not divide: a lane's 4 rows x 8 columns lie inside the image together or not
+    // at all; outside, its stores and residual loads go out of the descriptor's range and its statistics are dropped)
+    e_valid = (t.ty0 + 4 * wave < kH) && (t.tx0 + 8 * (lf >> 5) < kW);
+    out_voff = e_valid ? (unsigned)((4 * wave * kW + 8 * (lf >> 5)) * a_out_stride + c_lane) * 4u : OOB;
+    if constexpr (RES) res_voff = e_valid ? (unsigned)((4 * wave * kW + 8 * (lf >> 5)) * kCout + c_lane) * 4u : OOB;
     // (a null bias / temb reads as zeros through an empty descriptor: no branch in the stream)
     const __amdgpu_buffer_rsrc_t tb_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_temb ? a_temb + (size_t)t.b * a_temb_stride : a_src0), 0,
                                                                            a_temb ? OOB : 0u, RSRC_FLAGS);
@@ -484,12 +488,15 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xk_kernel(const char* __re
             *reinterpret_cast<xk_f4*>(smem + tx + nt * 1024) =
                 xk_f4{acc[d][nt][4 * row], acc[d][nt][4 * row + 1], acc[d][nt][4 * row + 2], acc[d][nt][4 * row + 3]};
       }
-      ff_barrier();
+      if (!(XK_ABL & 65536)) ff_barrier();
       xk_f4 mv[4][NT];                               // [component][cout tile]: the four pairs of this row
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) mv[c][nt] = *reinterpret_cast<const xk_f4*>(smem + ((row & 1) ? rxY : rxX) + c * SLOTB + nt * 1024);
+        for (int nt = 0; nt < NT; ++nt) {
+          if (XK_ABL & 131072) mv[c][nt] = xk_f4{acc[c][nt][4 * row], acc[c][nt][4 * row + 1], acc[c][nt][4 * row + 2], acc[c][nt][4 * row + 3]};
+          else mv[c][nt] = *reinterpret_cast<const xk_f4*>(smem + ((row & 1) ? rxY : rxX) + c * SLOTB + nt * 1024);
+        }
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         float y1[NT];
@@ -525,6 +532,8 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xk_kernel(const char* __re
       const int tidf = wave * 64 + lf;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
+        vs[nt] = e_valid ? vs[nt] : 0.f;
+        vq[nt] = e_valid ? vq[nt] : 0.f;
         vs[nt] += __shfl_xor(vs[nt], 32);
         vq[nt] += __shfl_xor(vq[nt], 32);
         if (lf < 32) {

@@ -551,8 +551,9 @@ static int build_packed_layout(Net& n) {
     // (NCSN++ up / down blocks: Conv_0 reads FIR(act(GroupNorm(x))) - an fp32 tensor that is already normalised and activated, so the same
     // kernel takes it with its NORM = false prologue (plain split; the values stay far inside e4m3): no split pass, no fp16 planes)
     const bool fir_act_input = resample && !upsample && normed && n.cfg.arch == 1;
-    if (net_ns && normed && stride1 && (!resample || fir_act_input) && n.cfg.act == CSD_ACT_SWISH && convff_supported(ffp, net_ns)) {
-      pc.ns = n.cfg.precision == CSD_PREC_F16F8 ? 3 : net_ns;      // 3: fp16 hi*hi + fp8 corrections (conv_ff.hip)
+    const int ff_ns = n.cfg.precision == CSD_PREC_F16F8 ? 3 : net_ns;      // 3: fp16 hi*hi + fp8 corrections (conv_ff.hip)
+    if (net_ns && normed && stride1 && (!resample || fir_act_input) && n.cfg.act == CSD_ACT_SWISH && convff_supported(ffp, ff_ns)) {
+      pc.ns = ff_ns;
       pc.ff = true;
       pc.proto.KC = 16;
       pc.w_off = take(convff_packed_bytes(pc.proto, pc.ns) / sizeof(float) + 1);
@@ -1037,12 +1038,13 @@ struct Builder {
     const size_t out_elems = (size_t)B * o.cp.OH * o.cp.OW * o.cp.Cout;
     o.out = external_nchw ? NONE : alloc_(out_elems);
     const int oh_tiled = o.cp.up == 2 ? o.cp.IH : o.cp.OH;         // (the phase form tiles the SOURCE image, four workgroups per tile)
-    if (!pc.pw && !external_nchw && o.cp.taps == 9 && oh_tiled % o.cp.TH == 0 && !CSD_TUNE_ENV("CSD_NO_FUSED_STATS") &&
+    // (pc.ff: the fused-prologue kernels tile every sample on its own - ragged tiles, where they run at all, mask their statistics)
+    if (!pc.pw && !external_nchw && o.cp.taps == 9 && (pc.ff || oh_tiled % o.cp.TH == 0) && !CSD_TUNE_ENV("CSD_NO_FUSED_STATS") &&
         o.cp.up != 2) {     // (phase-decomposed Upsample: its fp64 epilogue statistics cost more than the streaming pass over the output,
                             // and their tile grouping would make a sample's bits depend on the batch size it is run in)
       // every tile lies inside one sample: the epilogue also leaves (sum, sumsq) per (tile, cout) for the next
       // GroupNorm (the fp32 kernel: per (tile, wave, cout))
-      const int tpi = (oh_tiled / o.cp.TH) * o.cp.tiles_x * (pc.q ? 2 : (pc.ns ? 1 : 4)) * (o.cp.up == 2 ? 4 : 1);
+      const int tpi = cdiv(oh_tiled, o.cp.TH) * o.cp.tiles_x * (pc.q ? 2 : (pc.ns ? 1 : 4)) * (o.cp.up == 2 ? 4 : 1);
       o.stats = alloc_((size_t)B * tpi * o.cp.Cout * 2 * 2);      // doubles; never released (small)
       tile_stats[o.out] = TileStats{o.stats, tpi};
     }

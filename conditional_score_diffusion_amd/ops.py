@@ -68,7 +68,7 @@ def conv3x3_block(x0, weight, bias=None, x1=None, nscale=None, nshift=None, temb
     opt = [None if t is None else _c(t, 't') for t in (bias, nscale, nshift, temb, res)]
     bias, nscale, nshift, temb, res = opt
     y = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x0.device)
-    stats = torch.empty(B * (H // 16) * (W // 16), Cout, 2, dtype=torch.float64, device=x0.device) if want_stats else None
+    stats = torch.empty(B * ((H + 15) // 16) * ((W + 15) // 16), Cout, 2, dtype=torch.float64, device=x0.device) if want_stats else None
     sc = _scratch(lib().csd_conv3x3_block_scratch_bytes(C0 + C1, Cout), x0.device)
     check(lib().csd_conv3x3_block(ptr(x0), ptr(x1), ptr(weight), ptr(bias), ptr(nscale), ptr(nshift), ptr(temb),
                                   temb.shape[1] if temb is not None else 0, ptr(res), float(out_scale), ptr(y), ptr(stats),

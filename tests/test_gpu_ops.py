@@ -371,6 +371,48 @@ def test_conv3x3_block_shape_sweep_fp16x3():
     assert n == 36 and worst > 0
 
 
+def test_conv3x3_block_ragged_tiles_fp16x3():
+    """maps that 16 does not divide (the 40^2 level of the 160^2 networks: 8 | H, W) run on ragged 16 x 16 tiles in conv_xk.hip: lanes whose
+    4 x 8-pixel block lies outside the image drop their stores, residual loads and statistics; the patch pads with zeros as at any
+    border.  Output and the per-tile GroupNorm partials (valid pixels only) against fp64 torch"""
+    from conditional_score_diffusion_amd import ops
+    rs = np.random.RandomState(40)
+    d = dev()
+    for (B, H, W, C0, C1, Cout, norm, res) in ((2, 40, 40, 96, 0, 96, True, False), (3, 40, 40, 192, 0, 192, True, True),
+                                               (1, 40, 56, 96, 96, 192, True, False), (2, 56, 40, 64, 0, 96, False, True),
+                                               (1, 40, 40, 192, 96, 192, True, True)):
+        Cin = C0 + C1
+        x = torch.from_numpy(rs.randn(B, H, W, Cin).astype(np.float32) * 2.0 + 0.3)
+        w = torch.from_numpy((rs.randn(Cout, Cin, 3, 3) / (3.0 * Cin ** 0.5)).astype(np.float32))
+        bias = torch.from_numpy(rs.randn(Cout).astype(np.float32))
+        sc = torch.from_numpy((rs.rand(B, Cin) + 0.5).astype(np.float32)) if norm else None
+        sh = torch.from_numpy((rs.randn(B, Cin) * 0.5).astype(np.float32)) if norm else None
+        rv = torch.from_numpy((rs.randn(B, H, W, Cout) * 3.0).astype(np.float32)) if res else None
+        opt = lambda t: None if t is None else t.to(d)      # noqa: E731
+        x0 = x[..., :C0].contiguous().to(d)
+        x1 = x[..., C0:].contiguous().to(d) if C1 else None
+        y, stats = ops.conv3x3_block(x0, w.to(d), bias.to(d), x1=x1, nscale=opt(sc), nshift=opt(sh), res=opt(rv), out_scale=0.75,
+                                     precision='fp16x3', want_stats=True)
+        xd = x.double()
+        if norm:
+            xd = torch.nn.functional.silu(xd * sc.double()[:, None, None, :] + sh.double()[:, None, None, :])
+        ref = torch.nn.functional.conv2d(xd.permute(0, 3, 1, 2), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+        if rv is not None:
+            ref = ref + rv.double()
+        ref = ref * 0.75
+        yc = y.cpu().double()
+        err = (yc - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 3e-6, (B, H, W, C0, C1, Cout, err)
+        ty, tx = (H + 15) // 16, (W + 15) // 16
+        st = stats.cpu().reshape(B, ty, tx, Cout, 2)
+        worst = 0.0
+        for i in range(ty):
+            for j in range(tx):
+                blk = yc[:, 16 * i:16 * i + 16, 16 * j:16 * j + 16, :]
+                worst = max(worst, (st[:, i, j, :, 0] - blk.sum((1, 2))).abs().max().item(), (st[:, i, j, :, 1] - (blk * blk).sum((1, 2))).abs().max().item() * 0.1)
+        assert worst < 1e-5 * float((yc * yc).sum((1, 2)).max()), (B, H, W, worst)
+
+
 def test_conv3x3_block_is_bitwise_repeatable_under_load():
     """conv_xp.hip issues its matrix instructions as asm statements (no compiler-inserted wait states): 30 launches of a chip-filling
     layer (8 x 160^2, 96 -> 96 and 64 + 64 -> 128, GroupNorm prologue + residual; several tiles per workgroup, hot chip) must be
