@@ -76,7 +76,7 @@ __device__ __forceinline__ float xk_lo(int hp, float v) {      // v - (float)hal
 #define XW_PIN(a) asm volatile("" : "+v"(a))
 // tuning aids (never in the product library): XK_ABL bits remove parts of the stream at compile time (results are then garbage):
 // 1 conversion, 2 weight staging, 4 fragment reads, 8 epilogue stores, 16 patch requests, 32 residual requests, 64 barriers,
-// 16384 row-tap barriers without the LDS wait, 128 the epilogue's exchange stores, 65536 its barriers, 131072 its reads (own accumulators instead), 32768 the weight ring's LDS stores (the requests stay), 4096 patch requests confined to the first 256 pixels of the sample (cache hits), 256 patch stores, 512 neighbour exchange (own value instead), 1024 transcendentals (plain multiplies instead), 2048 hi | lo split
+// 16384 row-tap barriers without the LDS wait, 128 the epilogue's exchange stores, 262144 its statistics, 65536 its barriers, 131072 its reads (own accumulators instead), 32768 the weight ring's LDS stores (the requests stay), 4096 patch requests confined to the first 256 pixels of the sample (cache hits), 256 patch stores, 512 neighbour exchange (own value instead), 1024 transcendentals (plain multiplies instead), 2048 hi | lo split
 #ifndef XK_ABL
 #define XK_ABL 0
 #endif
@@ -471,9 +471,13 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xk_kernel(const char* __re
     const int txY0 = C::OFF_Y0 + wave * SLOTB + l16, txY8 = C::OFF_Y8 + wave * SLOTB + l16;
     const int rxX = (wave < 2 ? ex_dead + wave * 4 * SLOTB : C::OFF_X23 + (wave - 2) * 4 * SLOTB) + l16;
     const int rxY = (wave < 2 ? C::OFF_Y0 + wave * 4 * SLOTB : C::OFF_Y8 + (wave - 2) * 4 * SLOTB) + l16;
-    float vs[NT], vq[NT];
+    // statistics: four independent partial sums per cout tile (even | odd column x even | odd pair) - one wave per SIMD has nothing to
+    // cover the latency of a 32-long dependent chain with; folded in a fixed order at the end
+    float ps[NT][4], pq[NT][4];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) vs[nt] = vq[nt] = 0.f;
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ps[nt][q] = pq[nt][q] = 0.f;
     int out_run = 0;
     typedef float xk_f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -510,8 +514,7 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xk_kernel(const char* __re
           if constexpr (RES) v = fmaf(y0, ka, fmaf(rs[row][2 * jj][nt], a_out_scale, bs));
           else v = fmaf(y0, ka, bs);
           if (!(XK_ABL & 8)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), out_r, out_voff + nt * 128, out_run, 0);
-          vs[nt] += v;
-          vq[nt] = fmaf(v, v, vq[nt]);
+          if (!(XK_ABL & 262144)) { ps[nt][(jj & 1) * 2] += v; pq[nt][(jj & 1) * 2] = fmaf(v, v, pq[nt][(jj & 1) * 2]); }
         }
         XW_SADD(out_run, out_col);
 #pragma unroll
@@ -521,8 +524,7 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xk_kernel(const char* __re
           if constexpr (RES) v = fmaf(y1[nt], ka, fmaf(rs[row][2 * jj + 1][nt], a_out_scale, bs));
           else v = fmaf(y1[nt], ka, bs);
           if (!(XK_ABL & 8)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), out_r, out_voff + nt * 128, out_run, 0);
-          vs[nt] += v;
-          vq[nt] = fmaf(v, v, vq[nt]);
+          if (!(XK_ABL & 262144)) { ps[nt][(jj & 1) * 2 + 1] += v; pq[nt][(jj & 1) * 2 + 1] = fmaf(v, v, pq[nt][(jj & 1) * 2 + 1]); }
         }
         if (jj != 3) XW_SADD(out_run, out_col);
         else if (row != 3) XW_SADD(out_run, out_row);
@@ -530,8 +532,11 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xk_kernel(const char* __re
     }
     if (a_stats) {
       const int tidf = wave * 64 + lf;
+      float vs[NT], vq[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
+        vs[nt] = (ps[nt][0] + ps[nt][1]) + (ps[nt][2] + ps[nt][3]);
+        vq[nt] = (pq[nt][0] + pq[nt][1]) + (pq[nt][2] + pq[nt][3]);
         vs[nt] = e_valid ? vs[nt] : 0.f;
         vq[nt] = e_valid ? vq[nt] : 0.f;
         vs[nt] += __shfl_xor(vs[nt], 32);
