@@ -329,13 +329,13 @@ def main():
         modes = {
             'fp32': dict(peak=F32_MFMA_PEAK_TF, mfma_per_product=1.0, operand='fp32 (24 significand bits)',
                          kernel='conv_f32_kernel (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)'),
-            # conv_xw (the 160^2 / 80^2 levels: 78 % of the class's flops at the SR3-160 shape) is 1-D Winograd F(2,3): 4 instead of 6
-            # contractions per output pair, i.e. 3 x 2/3 = 2 MFMAs per algorithmic product; the quad kernel below 80^2 issues 3
-            'fp16x3': dict(peak=F16_MFMA_PEAK_TF, mfma_per_product=0.78 * 2.0 + 0.22 * 3.0, operand='hi + lo fp16 per operand (22 significand bits; the lo*lo term, 2^-22 relative, is dropped)',
-                           kernel='3x3 stride-1 convolution class: conv_xw_kernel (1-D Winograd F(2,3) along the row on the conv_xp structure: fused '
-                                  'GroupNorm+SiLU+transform+split prologue as fillers between the MFMAs of one software-pipelined stream per SIMD, persistent '
-                                  '4-wave workgroup per CU, 2x v_mfma_f32_32x32x16_f16 per algorithmic product; the 160^2 / 80^2 levels) + '
-                                  'conv_f16_q_kernel<NS=2> (40^2 and below, 3x per product)'),
+            # conv_xk (the 160^2 / 80^2 / 40^2 levels: 92 % of the class's flops at the SR3-160 shape) is 1-D Winograd F(2,3): 4 instead of 6
+            # contractions per output pair, i.e. 3 x 2/3 = 2 MFMAs per algorithmic product; the quad kernel below 40^2 issues 3
+            'fp16x3': dict(peak=F16_MFMA_PEAK_TF, mfma_per_product=0.92 * 2.0 + 0.08 * 3.0, operand='hi + lo fp16 per operand (22 significand bits; the lo*lo term, 2^-22 relative, is dropped)',
+                           kernel='3x3 stride-1 convolution class: conv_xk_kernel (1-D Winograd F(2,3) along the row, one transform component per wave: fused '
+                                  'GroupNorm+SiLU+transform+split prologue as fillers between the MFMAs of one software-pipelined stream per SIMD, weights from L2 '
+                                  'straight into registers, persistent 4-wave workgroup per CU, 2x v_mfma_f32_32x32x16_f16 per algorithmic product; the 160^2 / 80^2 '
+                                  'levels and, on ragged 16x16 tiles, 40^2) + conv_f16_q_kernel<NS=2> (20^2 and below, 3x per product)'),
             'fp16f8': dict(peak=F16_MFMA_PEAK_TF, mfma_per_product=2.0, operand='fp16 hi x fp16 hi + two correction products with e4m3 operands (~15 significand bits per operand: '
                                                                                   'NARROWER than the reference\'s fp32)',
                            kernel='3x3 stride-1 convolution class: conv_ff_kernel<NS=2,F8> / conv_fx_kernel (hi*hi on v_mfma_f32_32x32x16_f16, corrections on '

@@ -32,7 +32,7 @@ def main(tag, outpath):
         if name.startswith('conv_f16_q_kernel'):      # <MQ, NS, MASK, PWC, S, NTQ, F8, UP4>: stride-2 / phase-decomposed Upsample = the resample class
             targs = [a.strip() for a in name[name.index('<') + 1:name.rindex('>')].split(',')]
             q_resample = targs[4] != '1' or (len(targs) > 7 and targs[7] == 'true')
-        if (name.startswith(('conv_xw_kernel', 'conv_xp_kernel', 'conv_ff_kernel', 'conv_fx_kernel', 'conv_f16_q_kernel', 'conv_f16_lc_kernel')) or in16_old) and not q_resample:
+        if (name.startswith(('conv_xk_kernel', 'conv_xw_kernel', 'conv_xp_kernel', 'conv_ff_kernel', 'conv_fx_kernel', 'conv_f16_q_kernel', 'conv_f16_lc_kernel')) or in16_old) and not q_resample:
             cls['launches'] += n
             cls['fetch'] += fetch * n
             cls['write'] += write * n

@@ -14,11 +14,11 @@ python $R/tools/prof_summary.py trace $t csd:: > $O/kernel_trace_summary.txt
 rm -rf $O/trace
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/sq -- python $R/bench.py --steps 1 --warmup 0 --no-alt --no-cpu-baseline > /dev/null 2>&1
 f=$(find $O/sq -name '*counter_collection.csv' | head -1)
-python $R/tools/prof_summary.py counters $f csd:: | grep -E "conv_xw|conv_xp|conv_ff|conv_f16_q|gn_apply16|gn_fused16|pw16|attention" > $O/pmc_sq.txt
+python $R/tools/prof_summary.py counters $f csd:: | grep -E "conv_xk|conv_xw|conv_xp|conv_ff|conv_f16_q|gn_apply16|gn_fused16|pw16|attention" > $O/pmc_sq.txt
 rm -rf $O/sq
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/grbm -- python $R/bench.py --steps 1 --warmup 0 --no-alt --no-cpu-baseline > /dev/null 2>&1
 f=$(find $O/grbm -name '*counter_collection.csv' | head -1)
-python $R/tools/prof_summary.py counters $f csd:: | grep -E "conv_xw|conv_xp|conv_f16_q" > $O/pmc_grbm.txt
+python $R/tools/prof_summary.py counters $f csd:: | grep -E "conv_xk|conv_xw|conv_xp|conv_f16_q" > $O/pmc_grbm.txt
 rm -rf $O/grbm
 cd $R
 bash tools/pmc_hbm.sh fp16x3 r05_fp16x3
