@@ -534,9 +534,15 @@ bool convff_pipelined(const ConvPlan& p, int ns) {
 // the pipelined layers that run in the Winograd F(2,3) form (conv_xw.hip: 96-cout groups; transformed weights, 4 components x 3 filter
 // rows instead of 9 taps).  Tuning build: CSD_XW=0 keeps them on conv_xp.
 bool convff_winograd(const ConvPlan& p, int ns) {
-  if (!convff_pipelined(p, ns) || ff_nt(p.Cout) != 3) return false;
+  if (!convff_pipelined(p, ns)) return false;
   const char* xw = CSD_TUNE_ENV("CSD_XW");
-  return !(xw && atoi(xw) == 0);
+  if (xw && atoi(xw) == 0) return false;
+  if (ff_nt(p.Cout) == 3) return true;
+  // 64-cout groups (the nf = 128 nets): conv_xk.hip only (conv_xw's ring of transformed weights was sized for 96-cout groups and measured
+  // no gain there).  Tuning build: CSD_XK=0 or CSD_XK_NT2=0 keeps them on conv_xp
+  const char* xk = CSD_TUNE_ENV("CSD_XK");
+  const char* n2 = CSD_TUNE_ENV("CSD_XK_NT2");
+  return !(xk && atoi(xk) == 0) && !(n2 && atoi(n2) == 0);
 }
 
 size_t convff_packed_bytes(const ConvPlan& p, int ns) {
@@ -714,11 +720,11 @@ int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
   }
   // conv_xw.hip: conv_xp's stream in the Winograd F(2,3) form (the weights were packed for it: convff_winograd is the one switch)
   if (convff_winograd(p, ns)) {
-    CSD_REQUIRE(convxw_supported(k, nt), "convff: Winograd layer outside conv_xw's range");
+    CSD_REQUIRE(convxk_supported(k, nt), "convff: Winograd layer outside conv_xk's range");
     // (conv_xk.hip: the same operator and packed weights, one transform component per wave.  Tuning build: CSD_XK=0 keeps conv_xw)
     const char* xk = CSD_TUNE_ENV("CSD_XK");
     if (convxk_supported(k, nt) && !(xk && atoi(xk) == 0)) return convxk_launch(k, nt, s);
-    CSD_REQUIRE(!ff_ragged(p), "convff: ragged tiles run on conv_xk only");
+    CSD_REQUIRE(!ff_ragged(p) && convxw_supported(k, nt), "convff: ragged tiles and 64-cout groups run on conv_xk only");
     return convxw_launch(k, nt, s);
   }
   // conv_xp.hip (fp16x3: one persistent 4-wave workgroup per CU, the conversion / fragment reads / weight staging placed between

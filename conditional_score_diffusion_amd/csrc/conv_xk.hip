@@ -397,10 +397,15 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xk_kernel(const char* __re
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(acc[m][nt]) : "a"(xl[m]), "v"(w0[2 * nt]));
   };
   auto tie_acc_done = [&]() __attribute__((always_inline)) {
-    static_assert(NT == 3, "conv_xk: 96-cout groups");
-    asm volatile("s_nop 15\n\ts_nop 7"
-                 : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[2][0]),
-                   "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]));
+    static_assert(NT == 3 || NT == 2, "conv_xk: 96- or 64-cout groups");
+    if constexpr (NT == 3)
+      asm volatile("s_nop 15\n\ts_nop 7"
+                   : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[2][0]),
+                     "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]));
+    else
+      asm volatile("s_nop 15\n\ts_nop 7"
+                   : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[3][0]),
+                     "+a"(acc[3][1]));
   };
 
   // ---- epilogue operands of a tile ----
@@ -720,11 +725,16 @@ static int launch_xk(const ConvFFArgs& k, hipStream_t s) {
   return CSD_OK;
 }
 
-// conv_xw's layers (96-cout groups, at least three 16-channel stages; the packed weights are conv_xw's)
-bool convxk_supported(const ConvFFArgs& k, int nt) { return nt == 3 && k.nstage >= 3; }
+// conv_xw's layers (96-cout groups) and the 64-cout groups of the nf = 128 nets; at least three 16-channel stages; the packed weights
+// are conv_xw's Winograd layout
+bool convxk_supported(const ConvFFArgs& k, int nt) { return (nt == 3 || nt == 2) && k.nstage >= 3; }
 
 int convxk_launch(const ConvFFArgs& k, int nt, hipStream_t s) {
   const bool norm = k.a.nscale != nullptr, res = k.a.res != nullptr;
+  if (nt == 2) {
+    if (norm) return res ? launch_xk<2, true, true>(k, s) : launch_xk<2, true, false>(k, s);
+    return res ? launch_xk<2, false, true>(k, s) : launch_xk<2, false, false>(k, s);
+  }
   if (norm) return res ? launch_xk<3, true, true>(k, s) : launch_xk<3, true, false>(k, s);
   return res ? launch_xk<3, false, true>(k, s) : launch_xk<3, false, false>(k, s);
 }
