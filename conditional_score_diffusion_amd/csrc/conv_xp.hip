@@ -26,6 +26,18 @@
 // Tile geometry, LDS patch layout, packed-weight layout (conv_ff.hip's NS = 2 pack) and the per-tile GroupNorm partials are conv_ff's.
 #include "conv_ff.h"
 
+// Product library: every layer this kernel covered runs on conv_xk.hip (same operator, same or - for the 64-cout groups - the Winograd
+// arithmetic); the kernel is compiled in the TUNING build only, where it is conv_xk's A/B partner (CSD_XK=0, CSD_XW=0).
+#ifndef CSD_TUNE
+namespace csd {
+bool convxp_supported(const ConvFFArgs&, int) { return false; }
+int convxp_launch(const ConvFFArgs&, int, hipStream_t) {
+  set_error("conv_xp: a tuning-build kernel (superseded by conv_xk.hip in the product library)");
+  return CSD_ERR_INVALID;
+}
+}  // namespace csd
+#else
+
 namespace csd {
 
 #define XP_THREADS 256
@@ -648,3 +660,4 @@ static int launch_xp_nt(const ConvFFArgs& k, hipStream_t s) {
 int convxp_launch(const ConvFFArgs& k, int nt, hipStream_t s) { return nt == 3 ? launch_xp_nt<3>(k, s) : launch_xp_nt<2>(k, s); }
 
 }  // namespace csd
+#endif  // CSD_TUNE

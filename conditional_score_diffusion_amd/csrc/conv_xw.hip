@@ -27,6 +27,18 @@
 // Packed weights: [cout group][cin / 16][filter row][component][cout tile][hi | lo][64 lanes x 8 halves], x 2^8 like conv_ff's.
 #include "conv_ff.h"
 
+// Product library: every layer this kernel covered runs on conv_xk.hip (same operator, same or - for the 64-cout groups - the Winograd
+// arithmetic); the kernel is compiled in the TUNING build only, where it is conv_xk's A/B partner (CSD_XK=0).
+#ifndef CSD_TUNE
+namespace csd {
+bool convxw_supported(const ConvFFArgs&, int) { return false; }
+int convxw_launch(const ConvFFArgs&, int, hipStream_t) {
+  set_error("conv_xw: a tuning-build kernel (superseded by conv_xk.hip in the product library)");
+  return CSD_ERR_INVALID;
+}
+}  // namespace csd
+#else
+
 #include <utility>
 
 namespace csd {
@@ -715,3 +727,4 @@ int convxw_launch(const ConvFFArgs& k, int nt, hipStream_t s) {
 }
 
 }  // namespace csd
+#endif  // CSD_TUNE
