@@ -27,6 +27,28 @@ def _rendezvous_retry(fn):
     return wrapped
 
 
+def _by_value(o):
+    """tensors cross the result queue BY VALUE (numpy): a torch tensor is pickled as a file descriptor that the parent fetches from the
+    worker's resource-sharer socket - gone if the worker has already exited (FileNotFoundError, seen when the machine is busy)"""
+    if isinstance(o, torch.Tensor):
+        return ('__tensor__', o.detach().cpu().numpy())
+    if isinstance(o, (list, tuple)):
+        return type(o)(_by_value(v) for v in o)
+    if isinstance(o, dict):
+        return {k: _by_value(v) for k, v in o.items()}
+    return o
+
+
+def _from_value(o):
+    if isinstance(o, tuple) and len(o) == 2 and isinstance(o[0], str) and o[0] == '__tensor__':
+        return torch.from_numpy(o[1].copy())
+    if isinstance(o, (list, tuple)):
+        return type(o)(_from_value(v) for v in o)
+    if isinstance(o, dict):
+        return {k: _from_value(v) for k, v in o.items()}
+    return o
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -47,7 +69,7 @@ def _worker(rank, world, port, q):
     from conditional_score_diffusion_amd import distributed as D
     y = torch.arange(8 * 3 * 2 * 2, dtype=torch.float32).reshape(8, 3, 2, 2)
     out, info = D.sample_sharded(_fake_sampler, None, y_global=y, seed=5)
-    q.put((rank, out, info))
+    q.put(_by_value((rank, out, info)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,7 +96,7 @@ def test_two_rank_sharded_sampling_gloo():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([_from_value(q.get(timeout=900)) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
@@ -110,7 +132,7 @@ def _ragged_worker(rank, world, port, q):
     sync.scale_loss((w * x).mean(), local_n=n_local, global_n=5).backward()
     sync.finish()
     res['grad'] = flat.grad.clone()
-    q.put((rank, res))
+    q.put(_by_value((rank, res)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -126,7 +148,7 @@ def test_two_rank_ragged_shards_gloo():
     procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([_from_value(q.get(timeout=900)) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
@@ -185,7 +207,7 @@ def _global_worker(rank, world, port, q):
         out, out_mean = corr.update_fn(x[lo:hi], torch.full((3,), 0.5))
     finally:
         torch.randn_like = orig
-    q.put((rank, out, out_mean))
+    q.put(_by_value((rank, out, out_mean)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -199,7 +221,7 @@ def test_global_norm_langevin_equals_single_process_gloo():
     procs = [ctx.Process(target=_global_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([_from_value(q.get(timeout=900)) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
@@ -243,7 +265,7 @@ def _grad_worker(rank, world, port, q):
         sync.scale_loss(loss).backward()
         sync.finish()
         out.append(flat.grad.clone())
-    q.put((rank, out, len(sync.buckets)))
+    q.put(_by_value((rank, out, len(sync.buckets))))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -258,7 +280,7 @@ def test_two_rank_bucketed_gradient_allreduce_gloo():
     procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([_from_value(q.get(timeout=900)) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
@@ -303,7 +325,7 @@ def _skewed_grad_worker(rank, world, port, q):
         out.append(flat.grad.clone())
         orders.append(list(order))
         del order[:]
-    q.put((rank, out, orders))
+    q.put(_by_value((rank, out, orders)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -321,7 +343,7 @@ def test_two_rank_allreduce_with_unequal_backward_durations_gloo():
     procs = [ctx.Process(target=_skewed_grad_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([_from_value(q.get(timeout=900)) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
