@@ -1,16 +1,16 @@
-"""Build-time check of the generated code of conv_xp.hip and conv_xw.hip (csrc/Makefile, run by __graft_entry__.build()).
+"""Build-time check of the generated code of conv_xk.hip (and, in the tuning build, conv_xp.hip and conv_xw.hip) (csrc/Makefile, run by __graft_entry__.build()).
 
 Both kernels issue their matrix instructions as asm statements, so hipcc inserts none of the wait states an accumulator access needs
 (MI355X: no hardware interlock between a matrix write and a vector read of the same register).  The sources are structured so that
 hipcc never has a reason to touch an accumulator; this script proves it on the ISA of every instantiation:
-  * the matrix instructions use exactly the expected accumulator tuples (conv_xp: 2 NT, conv_xw: 4 NT), the same registers throughout;
+  * the matrix instructions use exactly the expected accumulator tuples (conv_xp: 2 NT, conv_xw and conv_xk: 4 NT), the same registers throughout;
   * no v_accvgpr_mov / v_accvgpr_write (or any other non-matrix instruction) writes an accumulator register;
   * every read of an accumulator register sits behind the epilogue's tied wait (s_nop 15) IN THE SAME BASIC BLOCK with no matrix
     instruction in between: the "behind the wait" state is dropped at every label and after every branch, so a read reached through a
     back edge or a branch target from a block that ends in a matrix instruction cannot pass (round-4 advisor finding).
 conv_xw keeps two operand fragment sets (64 registers) in the accumulator half of the register file as well: those are written by LDS
 reads and read by matrix instructions only, and are not accumulators.
-usage: check_xp_isa.py conv_xp.s | conv_xw.s"""
+usage: check_xp_isa.py conv_xk.s | conv_xp.tune.s | conv_xw.tune.s"""
 import re
 import sys
 

@@ -1,4 +1,4 @@
-"""Tuning aid: per-tile cycle / wall stamps of conv_xw_kernel (tuning build: CSD_FF_ABL bit 7 + csd_debug_ff_timing).  Stamps sit at
+"""Tuning aid: per-tile cycle / wall stamps of conv_xk_kernel (conv_xw_kernel with CSD_XK=0) (tuning build: CSD_FF_ABL bit 7 + csd_debug_ff_timing).  Stamps sit at
 tile boundaries only (see conv_xw.hip: a stamp inside the stream is a control-flow edge with live accumulators).
    CSD_LIB_PATH=.../libcsd_hip_tune.so python tools/xw_timing.py [shape index of tools/ff_probe.py]"""
 import ctypes, os, sys
