@@ -343,12 +343,13 @@ int csd_ema_update(float* ema, const float* param, int64_t n, float decay, void*
  * ---------------------------------------------------------------------------------------- */
 /* The ResnetBlock convolution with its prologue fused (csrc/conv_ff.hip; reference models/layers.py:632-675: Conv(act(GroupNorm(x)))
  * [+ Dense(temb)] [+ x]): 3x3, stride 1, pad 1 on NHWC fp32 tensors.  x0 [B,H,W,C0] (+ x1 [B,H,W,C1] or NULL: virtual concat),
- * H % 16 == 0, W % 16 == 0, C0 / C1 multiples of 32, Cout a multiple of 96 (three 32-cout tiles per workgroup: the nf = 96 nets) or of
+ * H % 16 == 0, W % 16 == 0 (CSD_PREC_F16X3 layers of the Winograd form - an even number >= 4 of 16-channel stages - also H % 8 == 0, W % 8 == 0
+ * with tiles at least 65 % full, e.g. 40 x 40: ragged 16 x 16 tiles, csrc/conv_xk.hip), C0 / C1 multiples of 32, Cout a multiple of 96 (three 32-cout tiles per workgroup: the nf = 96 nets) or of
  * 64 (two: the nf = 128 nets); weight OIHW [Cout, C0+C1, 3, 3]; nscale / nshift
  * [B, C0+C1] = the GroupNorm's per-(sample, channel) rstd*gamma and beta - mean*rstd*gamma, applied as SiLU(x*scale + shift)
  * while the operand is staged (both NULL: the convolution reads x as it is); temb [B, temb_stride] or NULL (column c of sample b
  * is added to cout c), res [B,H,W,Cout] or NULL (added), out_scale multiplies the result.  stats (or NULL):
- * [B*(H/16)*(W/16)][Cout][2] doubles = per-tile (sum, sum of squares) of the written tensor.  precision: CSD_PREC_F16X3, CSD_PREC_F16F8 (the
+ * [B*ceil(H/16)*ceil(W/16)][Cout][2] doubles = per-tile (sum, sum of squares) of the written tensor (valid pixels only).  precision: CSD_PREC_F16X3, CSD_PREC_F16F8 (the
  * split operands with the two correction products on the fp8 matrix cores; 1.3e-5 / 4.5e-5 network error, see csd_precision) or CSD_PREC_F16.  scratch holds the packed weight: csd_conv3x3_block_scratch_bytes(C0 + C1, Cout). */
 size_t csd_conv3x3_block_scratch_bytes(int Cin, int Cout);
 int csd_conv3x3_block(const float* x0, const float* x1, const float* weight, const float* bias, const float* nscale,
