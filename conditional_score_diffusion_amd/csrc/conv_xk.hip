@@ -485,17 +485,22 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xk_kernel(const char* __re
       for (int q = 0; q < 4; ++q) ps[nt][q] = pq[nt][q] = 0.f;
     int out_run = 0;
     typedef float xk_f4 __attribute__((ext_vector_type(4)));
+    auto send_block = [&](int row, int d) __attribute__((always_inline)) {
+      const int tx = (row & 1) ? ((d < 2 ? txY0 : txY8) + (d & 1) * 4 * SLOTB) : ((d < 2 ? txX01 : txX23) + (d & 1) * 4 * SLOTB);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        if (!(XK_ABL & 128))
+          *reinterpret_cast<xk_f4*>(smem + tx + nt * 1024) =
+              xk_f4{acc[d][nt][4 * row], acc[d][nt][4 * row + 1], acc[d][nt][4 * row + 2], acc[d][nt][4 * row + 3]};
+    };
 #pragma unroll
     for (int row = 0; row < 4; ++row) {
-      // every wave's component of row `row` of all four blocks -> LDS
+      // every wave's component of row `row` of all four blocks -> LDS: row 0 here, rows 1 .. 3 block by block between the pairs of the
+      // row before (into the other region): three stores at a time do not fill the wave's LDS queue, and the pipe works on them
+      // while the vector pipe does the arithmetic
+      if (row == 0) {
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const int tx = (row & 1) ? ((d < 2 ? txY0 : txY8) + (d & 1) * 4 * SLOTB) : ((d < 2 ? txX01 : txX23) + (d & 1) * 4 * SLOTB);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          if (!(XK_ABL & 128))
-            *reinterpret_cast<xk_f4*>(smem + tx + nt * 1024) =
-                xk_f4{acc[d][nt][4 * row], acc[d][nt][4 * row + 1], acc[d][nt][4 * row + 2], acc[d][nt][4 * row + 3]};
+        for (int d = 0; d < 4; ++d) send_block(0, d);
       }
       if (!(XK_ABL & 65536)) ff_barrier();
       xk_f4 mv[4][NT];                               // [component][cout tile]: the four pairs of this row
@@ -533,6 +538,9 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xk_kernel(const char* __re
         }
         if (jj != 3) XW_SADD(out_run, out_col);
         else if (row != 3) XW_SADD(out_run, out_row);
+        XW_FENCE();
+        if (row < 3) send_block(row + 1, jj);
+        XW_FENCE();
       }
     }
     if (a_stats) {
