@@ -32,6 +32,9 @@ typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 #define PW_THREADS 256
 #define PW_NTL 6                 // 16-cout tiles per workgroup pass (96 couts)
 #define PW_WSCALE 256.0f         // weights are packed * 2^8 (keeps the lo half of F16X3 out of the subnormals)
+#ifndef PW_DEPTH
+#define PW_DEPTH 2          // K steps of raw rows in flight per wave on the big maps (4: no faster, measured)
+#endif
 
 struct PwKArgs {
   ConvArgs a;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
 
   // load-side pipeline depth in K steps: small maps (one or two tiles per workgroup, MTP = 1) have nothing but their own K loop to
   // cover a global load with - four steps in flight, GroupNorm scale / shift rows included; big ones keep two (registers)
-  constexpr int D = MTP == 1 ? 4 : 2;
+  constexpr int D = MTP == 1 ? 4 : PW_DEPTH;
   float4 raw[D][MTP][2];
   constexpr bool PFN = MTP == 1;          // the scale / shift rows ride with the prefetch (else: loaded at their use, as ever)
   float4 nsc[PFN ? D : 1][MTP][2], nsh[PFN ? D : 1][MTP][2];
