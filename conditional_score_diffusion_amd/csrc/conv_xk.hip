@@ -75,8 +75,11 @@ __device__ __forceinline__ float xk_lo(int hp, float v) {      // v - (float)hal
 #define XW_SADD(x, y) asm volatile("s_add_u32 %0, %0, %1" : "+s"(x) : "s"(y) : "scc")
 #define XW_PIN(a) asm volatile("" : "+v"(a))
 // tuning aids (never in the product library): XK_ABL bits remove parts of the stream at compile time (results are then garbage):
-// 1 conversion, 2 weight staging, 4 fragment reads, 8 epilogue stores, 16 patch requests, 32 residual requests, 64 barriers,
-// 16384 row-tap barriers without the LDS wait, 128 the epilogue's exchange stores, 262144 its statistics, 65536 its barriers, 131072 its reads (own accumulators instead), 32768 the weight ring's LDS stores (the requests stay), 4096 patch requests confined to the first 256 pixels of the sample (cache hits), 256 patch stores, 512 neighbour exchange (own value instead), 1024 transcendentals (plain multiplies instead), 2048 hi | lo split
+// 1 conversion, 2 weight requests, 4 fragment reads, 8 output stores, 16 patch requests, 32 residual requests, 64 the stage barriers,
+// 128 the epilogue's exchange stores, 65536 its barriers, 131072 its reads (own accumulators instead), 262144 its statistics,
+// 256 patch stores, 512 neighbour exchange (own value instead), 1024 transcendentals (plain multiplies instead), 2048 hi | lo split,
+// 4096 patch requests confined to the first 256 pixels of the sample (cache hits), 8192 the same bytes as whole 1 KiB pieces
+// (tools/xk_abl_build.sh builds the libraries, tools/xw_timing.py reads the per-tile stamps)
 #ifndef XK_ABL
 #define XK_ABL 0
 #endif
