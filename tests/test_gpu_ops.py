@@ -413,6 +413,22 @@ def test_conv3x3_block_ragged_tiles_fp16x3():
         assert worst < 1e-5 * float((yc * yc).sum((1, 2)).max()), (B, H, W, worst)
 
 
+def test_conv3x3_block_rejects_maps_outside_the_ragged_domain():
+    """ragged tiles exist for the fp16x3 Winograd layers with 96-cout groups, 8 | H, W and tiles >= 65 % full: anything else that 16 does
+    not divide fails loudly instead of running a kernel that would write outside the image"""
+    from conditional_score_diffusion_amd import ops
+    d = dev()
+    for (H, W, Cin, Cout, prec) in ((24, 24, 96, 96, 'fp16x3'),      # 8 | 24, but 56 % full
+                                    (40, 40, 128, 128, 'fp16x3'),    # 64-cout groups
+                                    (40, 40, 96, 96, 'fp16f8'),      # the fp8-correction form tiles by 16 only
+                                    (36, 40, 96, 96, 'fp16x3')):     # 36 is not a multiple of 8
+        x = torch.randn(1, H, W, Cin, device=d)
+        w = torch.randn(Cout, Cin, 3, 3, device=d) * 0.05
+        b = torch.zeros(Cout, device=d)
+        with pytest.raises(RuntimeError):
+            ops.conv3x3_block(x, w, b, precision=prec)
+
+
 def test_conv3x3_block_is_bitwise_repeatable_under_load():
     """conv_xp.hip issues its matrix instructions as asm statements (no compiler-inserted wait states): 30 launches of a chip-filling
     layer (8 x 160^2, 96 -> 96 and 64 + 64 -> 128, GroupNorm prologue + residual; several tiles per workgroup, hot chip) must be
