@@ -77,6 +77,7 @@ __device__ __forceinline__ float xk_lo(int hp, float v) {      // v - (float)hal
 // tuning aids (never in the product library): XK_ABL bits remove parts of the stream at compile time (results are then garbage):
 // 1 conversion, 2 weight requests, 4 fragment reads, 8 output stores, 16 patch requests, 32 residual requests, 64 the stage barriers,
 // 128 the epilogue's exchange stores, 65536 its barriers, 131072 its reads (own accumulators instead), 262144 its statistics,
+// 524288 the whole row loop of the epilogue (what remains is the tile switch),
 // 256 patch stores, 512 neighbour exchange (own value instead), 1024 transcendentals (plain multiplies instead), 2048 hi | lo split,
 // 4096 patch requests confined to the first 256 pixels of the sample (cache hits), 8192 the same bytes as whole 1 KiB pieces
 // (tools/xk_abl_build.sh builds the libraries, tools/xw_timing.py reads the per-tile stamps)
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xk_kernel(const char* __re
               xk_f4{acc[d][nt][4 * row], acc[d][nt][4 * row + 1], acc[d][nt][4 * row + 2], acc[d][nt][4 * row + 3]};
     };
 #pragma unroll
-    for (int row = 0; row < 4; ++row) {
+    for (int row = 0; row < ((XK_ABL & 524288) ? 0 : 4); ++row) {
       // every wave's component of row `row` of all four blocks -> LDS: row 0 here, rows 1 .. 3 block by block between the pairs of the
       // row before (into the other region): three stores at a time do not fill the wave's LDS queue, and the pipe works on them
       // while the vector pipe does the arithmetic
