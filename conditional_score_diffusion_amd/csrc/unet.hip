@@ -107,7 +107,8 @@ struct Net;
 // execution plan for one batch size
 // ---------------------------------------------------------------------------------------------
 enum OpKind { OP_ASSEMBLE, OP_STEM, OP_TEMB, OP_FOURIER, OP_FIR, OP_FIR2, OP_GN_APPLY32, OP_LINEAR, OP_GN_STATS, OP_GN_FINAL, OP_GN_FINAL_TILES, OP_GN_APPLY16, OP_GN_FUSED16, OP_GN_STATFIN, OP_CONV, OP_ATTN, OP_AVGPOOL,
-              OP_UPNEAR, OP_TO_NCHW, OP_TAPSUM };
+              OP_UPNEAR, OP_TO_NCHW, OP_TAPSUM,
+              OP_FORK, OP_JOIN };     // batch-chunk region (build_plan): the chunk streams start behind / the main stream resumes behind them
 
 static const size_t NONE = (size_t)-1;
 
@@ -124,6 +125,9 @@ struct Op {
   int act = 0;
   int out_external = 0;               // conv writes to the caller's NCHW output
   int side = 0;                       // 1: launched on the side stream (after the main stream's work so far); 2: the main stream waits for it first
+  int nb = 0;                         // batch of THIS launch (0: the plan's) - the ops of a batch chunk carry the chunk's size
+  int stream = 0;                     // 0: the caller's stream; k > 0: chunk stream k - 1 (between an OP_FORK and its OP_JOIN)
+  int chunk = 0;                      // k + 1 for the ops of batch chunk k (chunk 0 runs on the caller's stream)
   float fscale = 1.f;                 // conv: epilogue out_scale
   size_t temb_col = NONE;             // column offset inside dense_all
   int temb_stride = 0;
@@ -141,7 +145,18 @@ struct Plan {
 
 class Arena {
  public:
-  size_t alloc(size_t nfloats) {
+  Arena() {}
+  explicit Arena(size_t base) : base_(base) {}       // a sub-arena: offsets start at `base` (a block reserved in the parent)
+  size_t alloc(size_t nfloats) { return base_ + alloc_local(nfloats); }
+  void release(size_t off) {
+    if (off == NONE || off < base_ || off - base_ >= top_) return;      // (not ours: e.g. a slice of a parent tensor handed into a chunk)
+    release_local(off - base_);
+  }
+  size_t peak() const { return peak_; }
+
+ private:
+  size_t base_ = 0;
+  size_t alloc_local(size_t nfloats) {
     nfloats = (nfloats + 63) / 64 * 64;   // 256-byte granules
     // best fit in the free list
     int best = -1;
@@ -163,8 +178,7 @@ class Arena {
     peak_ = std::max(peak_, top_);
     return off;
   }
-  void release(size_t off) {
-    if (off == NONE) return;
+  void release_local(size_t off) {
     auto it = live_.find(off);
     if (it == live_.end()) return;
     size_t n = it->second;
@@ -177,9 +191,6 @@ class Arena {
     }
     free_.push_back({off, n});
   }
-  size_t peak() const { return peak_; }
-
- private:
   std::vector<std::pair<size_t, size_t>> free_;
   std::map<size_t, size_t> live_;
   size_t top_ = 0, peak_ = 0;
@@ -218,7 +229,24 @@ struct Net {
     }
     return true;
   }
+  // batch-chunk streams (build_plan: the <= 20^2 levels of a big batch run as CHUNKS concurrent sub-batches - their kernels are bound by
+  // per-launch latency, not by throughput, and a sample's bits do not depend on the batch it runs in)
+  static constexpr int MAX_CHUNKS = 4;
+  hipStream_t cstream[MAX_CHUNKS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_cfork = nullptr, ev_cjoin[MAX_CHUNKS] = {nullptr, nullptr, nullptr, nullptr};
+  bool chunks_ready() {
+    if (ev_cfork) return true;
+    for (int k = 0; k < MAX_CHUNKS; ++k)
+      if (hipStreamCreateWithFlags(&cstream[k], hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&ev_cjoin[k], hipEventDisableTiming) != hipSuccess) return false;
+    return hipEventCreateWithFlags(&ev_cfork, hipEventDisableTiming) == hipSuccess;
+  }
   ~Net() {
+    for (int k = 0; k < MAX_CHUNKS; ++k) {
+      if (cstream[k]) { (void)hipStreamSynchronize(cstream[k]); (void)hipStreamDestroy(cstream[k]); }
+      if (ev_cjoin[k]) (void)hipEventDestroy(ev_cjoin[k]);
+    }
+    if (ev_cfork) (void)hipEventDestroy(ev_cfork);
     if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
@@ -835,6 +863,7 @@ struct Builder {
   size_t gn_partial = NONE, nscale = NONE, nshift = NONE;   // shared scratch
   size_t dense_all = NONE;
   float pending_scale = 1.f;          // out_scale of the NEXT conv() (NCSN++ skip_rescale: (x + h)/sqrt(2))
+  size_t next_out = NONE;             // the NEXT conv() writes here instead of allocating (a batch chunk's slice of the region's output tensor)
   int rc = CSD_OK;
   // tensors whose producing conv left per-tile GroupNorm partials behind: workspace offset -> (partials, tiles per sample)
   struct TileStats { size_t off; int tpi; };
@@ -1036,7 +1065,8 @@ struct Builder {
     o.temb_stride = n.dense_total;
     o.out_external = external_nchw ? 1 : 0;
     const size_t out_elems = (size_t)B * o.cp.OH * o.cp.OW * o.cp.Cout;
-    o.out = external_nchw ? NONE : alloc_(out_elems);
+    o.out = external_nchw ? NONE : (next_out != NONE ? next_out : alloc_(out_elems));
+    next_out = NONE;
     const int oh_tiled = o.cp.up == 2 ? o.cp.IH : o.cp.OH;         // (the phase form tiles the SOURCE image, four workgroups per tile)
     // (pc.ff: the fused-prologue kernels tile every sample on its own - ragged tiles, where they run at all, mask their statistics)
     if (!pc.pw && !external_nchw && o.cp.taps == 9 && (pc.ff || oh_tiled % o.cp.TH == 0) && !CSD_TUNE_ENV("CSD_NO_FUSED_STATS") &&
@@ -1080,7 +1110,7 @@ struct Builder {
     return o.out;
   }
 
-  size_t res_block(const Module& m, size_t x0, size_t x1, int c0, int c1, int hw_side) {
+  size_t res_block(const Module& m, size_t x0, size_t x1, int c0, int c1, int hw_side, size_t out_to = NONE) {
     const std::string k = std::to_string(m.idx);
     const int hw = hw_side * hw_side;
     // the shortcut contraction first; with CSD_SIDE_STREAM=1 on the side stream (it only depends on the block's input; Conv_1 joins it).
@@ -1103,6 +1133,7 @@ struct Builder {
     const size_t h1 = conv(k + ".Conv_0", x0, x1, hw_side, hw_side, 1, 1, 0, true, n.cfg.act, NONE, tcol, false);
     gn(h1, NONE, m.cout, 0, hw, mname(m.idx, "GroupNorm_1.weight"), mname(m.idx, "GroupNorm_1.bias"));
     pending_scale = skip_scale();
+    next_out = out_to;
     const size_t out = conv(k + ".Conv_1", h1, NONE, hw_side, hw_side, 1, 1, 0, true, n.cfg.act, shortcut, NONE, false);
     if (side_on && sc_buf != NONE && rc == CSD_OK && out != NONE) pl.ops.back().side = 2;
     ar.release(h1);
@@ -1176,7 +1207,7 @@ struct Builder {
     return out;
   }
 
-  size_t attn_block(const Module& m, size_t x, int hw_side) {
+  size_t attn_block(const Module& m, size_t x, int hw_side, size_t out_to = NONE) {
     const std::string k = std::to_string(m.idx);
     const int C = m.cin, L = hw_side * hw_side;
     gn(x, NONE, C, 0, L, mname(m.idx, "GroupNorm_0.weight"), mname(m.idx, "GroupNorm_0.bias"));
@@ -1189,6 +1220,7 @@ struct Builder {
     pl.ops.push_back(a);
     count(4.0 * B * (double)L * L * C, 0);
     pending_scale = skip_scale();
+    next_out = out_to;
     const size_t o = conv(k + ".NIN_3", a.out, NONE, hw_side, hw_side, 1, 0, 0, false, 0, x, NONE, false);
     ar.release(qkv);
     ar.release(a.out);
@@ -1213,12 +1245,37 @@ static void fold_small_gn_pairs(Plan& pl) {
       o.pk0 = f.pk0; o.pk1 = f.pk1;
       o.out = f.out; o.c = f.b;                       // nscale, nshift
       o.cls = CSD_PROF_GN_STATS; o.bytes = a.bytes;
+      o.nb = a.nb; o.stream = a.stream; o.chunk = a.chunk;
       out.push_back(o);
       pl.launches -= 1;
       ++i;
     } else {
       out.push_back(a);
     }
+  }
+  pl.ops.swap(out);
+}
+
+// the ops of a chunk region are enqueued round robin over the chunks (op j of every chunk, then op j + 1): when the host is the slower
+// side, every chunk stream still advances - chunk after chunk, the last stream would start when the first is nearly done
+static void interleave_chunks(Plan& pl) {
+  std::vector<Op> out;
+  out.reserve(pl.ops.size());
+  for (size_t i = 0; i < pl.ops.size();) {
+    if (pl.ops[i].kind != OP_FORK) { out.push_back(pl.ops[i++]); continue; }
+    out.push_back(pl.ops[i++]);
+    std::vector<std::vector<Op>> per;
+    while (i < pl.ops.size() && pl.ops[i].kind != OP_JOIN) {
+      const int k = pl.ops[i].chunk - 1;
+      if (k < 0) break;
+      if ((int)per.size() <= k) per.resize(k + 1);
+      per[k].push_back(pl.ops[i++]);
+    }
+    size_t longest = 0;
+    for (auto& v : per) longest = std::max(longest, v.size());
+    for (size_t j = 0; j < longest; ++j)
+      for (auto& v : per)
+        if (j < v.size()) out.push_back(v[j]);
   }
   pl.ops.swap(out);
 }
@@ -1494,41 +1551,45 @@ static int build_plan(Net& n, int B, Plan** out) {
     hs.push_back({h0, m.cout});
   }
   int in_ch = nf;
-  for (int l = 0; l < c.n_levels; ++l) {
+  const int last = c.n_levels - 1;
+  size_t h = NONE;
+  // the walk, level by level (models/ddpm.py:149-213): every piece works on the Builder's CURRENT batch (bd.B), skip stack and position
+  auto down_blocks = [&](int l) {
     const int side = S >> l;
     for (int b = 0; b < c.num_res_blocks; ++b) {
       const Module& m = next_mod();
-      size_t h = bd.res_block(m, hs.back().off, NONE, in_ch, 0, side);
+      size_t hb = bd.res_block(m, hs.back().off, NONE, in_ch, 0, side);
       in_ch = m.cout;
       if (is_attn(side)) {
         const Module& am = next_mod();
-        const size_t h2 = bd.attn_block(am, h, side);
-        bd.ar.release(h);
-        h = h2;
+        const size_t h2 = bd.attn_block(am, hb, side);
+        bd.ar.release(hb);
+        hb = h2;
       }
-      hs.push_back({h, in_ch});
+      hs.push_back({hb, in_ch});
     }
-    if (l != c.n_levels - 1) {
-      const Module& m = next_mod();
-      size_t d;
-      if (c.resamp_with_conv) {
-        d = bd.conv(std::to_string(m.idx) + ".Conv_0", hs.back().off, NONE, side, side, 2, 0, 0, false, 0, NONE,
-                    NONE, false);
-      } else {
-        Op p;
-        p.kind = OP_AVGPOOL;
-        p.a = hs.back().off; p.i0 = side; p.i1 = in_ch;
-        p.out = bd.alloc_((size_t)B * (side / 2) * (side / 2) * in_ch);
-        pl.ops.push_back(p);
-        pl.launches += 1;
-        d = p.out;
-      }
-      hs.push_back({d, in_ch});
+  };
+  auto down_sample = [&](int l) {
+    const int side = S >> l;
+    const Module& m = next_mod();
+    size_t d;
+    if (c.resamp_with_conv) {
+      d = bd.conv(std::to_string(m.idx) + ".Conv_0", hs.back().off, NONE, side, side, 2, 0, 0, false, 0, NONE,
+                  NONE, false);
+    } else {
+      Op p;
+      p.kind = OP_AVGPOOL;
+      p.a = hs.back().off; p.i0 = side; p.i1 = in_ch;
+      p.out = bd.alloc_((size_t)bd.B * (side / 2) * (side / 2) * in_ch);
+      pl.ops.push_back(p);
+      pl.launches += 1;
+      d = p.out;
     }
-  }
-  size_t h = hs.back().off;   // stays on the stack: popped by the first up-path block
-  {
-    const int side = S >> (c.n_levels - 1);
+    hs.push_back({d, in_ch});
+  };
+  auto middle = [&]() {
+    h = hs.back().off;   // stays on the stack: popped by the first up-path block
+    const int side = S >> last;
     const Module& r0 = next_mod();
     size_t t0 = bd.res_block(r0, h, NONE, in_ch, 0, side);
     const Module& am = next_mod();
@@ -1538,14 +1599,15 @@ static int build_plan(Net& n, int B, Plan** out) {
     size_t t2 = bd.res_block(r1, t1, NONE, in_ch, 0, side);
     bd.ar.release(t1);
     h = t2;
-  }
-  for (int l = c.n_levels - 1; l >= 0; --l) {
+  };
+  // (out_to: the level's LAST launch writes there instead of into a tensor of its own - a batch chunk's slice of the region's output)
+  auto up_blocks = [&](int l, size_t out_to) {
     const int side = S >> l;
     for (int b = 0; b < c.num_res_blocks + 1; ++b) {
       const Module& m = next_mod();
       const Skip sk = hs.back();
       hs.pop_back();
-      const size_t o = bd.res_block(m, h, sk.off, in_ch, sk.ch, side);
+      const size_t o = bd.res_block(m, h, sk.off, in_ch, sk.ch, side, (b == c.num_res_blocks && !is_attn(side)) ? out_to : NONE);
       bd.ar.release(h);
       bd.ar.release(sk.off);
       h = o;
@@ -1553,26 +1615,159 @@ static int build_plan(Net& n, int B, Plan** out) {
     }
     if (is_attn(side)) {
       const Module& am = next_mod();
-      const size_t o = bd.attn_block(am, h, side);
+      const size_t o = bd.attn_block(am, h, side, out_to);
       bd.ar.release(h);
       h = o;
     }
-    if (l != 0) {
-      const Module& m = next_mod();
-      size_t o;
-      if (c.resamp_with_conv) {
-        o = bd.conv(std::to_string(m.idx) + ".Conv_0", h, NONE, side, side, 1, 1, 1, false, 0, NONE, NONE, false);
-      } else {
-        Op p;
-        p.kind = OP_UPNEAR;
-        p.a = h; p.i0 = side; p.i1 = in_ch;
-        p.out = bd.alloc_((size_t)B * side * 2 * side * 2 * in_ch);
-        pl.ops.push_back(p);
-        pl.launches += 1;
-        o = p.out;
+  };
+  auto up_sample = [&](int l) {
+    const int side = S >> l;
+    const Module& m = next_mod();
+    size_t o;
+    if (c.resamp_with_conv) {
+      o = bd.conv(std::to_string(m.idx) + ".Conv_0", h, NONE, side, side, 1, 1, 1, false, 0, NONE, NONE, false);
+    } else {
+      Op p;
+      p.kind = OP_UPNEAR;
+      p.a = h; p.i0 = side; p.i1 = in_ch;
+      p.out = bd.alloc_((size_t)bd.B * side * 2 * side * 2 * in_ch);
+      pl.ops.push_back(p);
+      pl.launches += 1;
+      o = p.out;
+    }
+    bd.ar.release(h);
+    h = o;
+  };
+  // levels l0 .. last (small maps) down, the middle, and up again to the end of level l0's blocks
+  auto small_levels = [&](int l0, size_t out_to) {
+    for (int l = l0; l <= last; ++l) {
+      down_blocks(l);
+      if (l != last) down_sample(l);
+    }
+    middle();
+    for (int l = last; l >= l0; --l) {
+      up_blocks(l, l == l0 ? out_to : NONE);
+      if (l != l0) up_sample(l);
+    }
+  };
+  // Batch chunks: below CHUNK_SIDE^2 a launch is bound by its own dependent chain (weights -> LDS, K steps of global loads, epilogue), not by
+  // throughput - at 5^2 / 10^2 a kernel takes the same ~20 us for 8 samples as for 64 (profiles/r06_*: timeline by batch).  The levels
+  // l0 .. last therefore run as K independent sub-batches on K streams between the Downsample conv that enters level l0 and the Upsample
+  // conv that leaves it: each chunk walks the same modules with its own temporaries (a private block of the workspace) and reads /
+  // writes its slice of the two full-batch tensors at the region's boundary.  A sample's bits do not depend on the batch it runs in
+  // (tests: B = 64 == B = 1), so the chunked plan returns the bits of the unchunked one.
+  int l0 = c.n_levels, K = 1;
+  {
+    const char* e_side = getenv("CSD_CHUNK_SIDE");
+    const char* e_k = getenv("CSD_CHUNKS");
+    const int chunk_side = e_side ? atoi(e_side) : 20;
+    for (int l = 1; l <= last; ++l)
+      if ((S >> l) <= chunk_side) { l0 = l; break; }
+    K = e_k ? atoi(e_k) : (B >= 32 ? 4 : (B >= 16 ? 2 : 1));
+    K = std::max(1, std::min(K, std::min(B, (int)Net::MAX_CHUNKS)));
+    if (l0 > last) K = 1;
+  }
+  for (int l = 0; l < (K > 1 ? l0 : c.n_levels); ++l) {
+    down_blocks(l);
+    if (l != last) down_sample(l);
+  }
+  if (K == 1) {
+    middle();
+    for (int l = last; l >= 0; --l) {
+      up_blocks(l, NONE);
+      if (l != 0) up_sample(l);
+    }
+  } else {
+    const int side0 = S >> l0, Bc = cdiv(B, K);
+    const Skip in_full = hs.back();                      // [B, side0, side0, ch]: the Downsample output that enters level l0
+    const size_t in_ps = (size_t)side0 * side0 * in_full.ch;
+    const size_t mi0 = mi;
+    const int in_ch0 = in_ch;
+    const size_t dense_full = bd.dense_all, gp_full = bd.gn_partial, ns_full = bd.nscale, nh_full = bd.nshift;
+    std::vector<Skip> hs_main;
+    hs_main.swap(hs);
+    auto tile_stats_main = bd.tile_stats;
+    Arena ar_main = bd.ar;
+    int ch_out = 0;
+    // one chunk's walk in the Builder's current arena; returns false on a builder error
+    auto chunk_walk = [&](int b0, int nb, size_t out_slice) {
+      bd.B = nb;
+      bd.tile_stats.clear();
+      mi = mi0; in_ch = in_ch0;
+      hs.clear();
+      hs.push_back({in_full.off + (size_t)b0 * in_ps, in_full.ch});
+      bd.dense_all = dense_full == NONE ? NONE : dense_full + (size_t)b0 * n.dense_total;
+      {      // the chunk's own GroupNorm scratch
+        GNPlan g;
+        size_t worst = 0;
+        for (int l = l0; l <= last; ++l) {
+          gn_plan(&g, nb, (S >> l) * (S >> l), cmax, 0, 32);
+          worst = std::max(worst, gn_partial_bytes(g));
+        }
+        bd.gn_partial = bd.alloc_(worst / sizeof(float) + 64);
+        bd.nscale = bd.alloc_((size_t)nb * cmax);
+        bd.nshift = bd.alloc_((size_t)nb * cmax);
       }
-      bd.ar.release(h);
-      h = o;
+      small_levels(l0, out_slice);
+      ch_out = in_ch;
+      return bd.rc == CSD_OK && hs.empty();
+    };
+    // dry run of one full-size chunk: the size of a chunk's private block
+    size_t chunk_floats = 0;
+    {
+      const size_t nops = pl.ops.size();
+      const int64_t launches = pl.launches;
+      const double flops = pl.flops, bytes = pl.bytes;
+      bd.ar = Arena(0);
+      const bool ok = chunk_walk(0, Bc, 0);
+      chunk_floats = (bd.ar.peak() + 63) / 64 * 64;
+      pl.ops.resize(nops);
+      pl.launches = launches; pl.flops = flops; pl.bytes = bytes;
+      bd.next_out = NONE;
+      if (!ok) { if (bd.rc) return bd.rc; set_error("unet: chunk walk mismatch"); return CSD_ERR_STATE; }
+    }
+    bd.ar = ar_main;
+    const size_t out_ps = (size_t)side0 * side0 * ch_out;
+    const size_t out_full = bd.alloc_((size_t)B * out_ps);
+    const size_t block = bd.alloc_((size_t)K * chunk_floats);
+    ar_main = bd.ar;
+    {
+      Op f;
+      f.kind = OP_FORK;
+      f.i0 = K;
+      pl.ops.push_back(f);
+    }
+    for (int k = 0; k < K; ++k) {
+      const int b0 = k * Bc, nb = std::min(Bc, B - b0);
+      if (nb <= 0) break;
+      const size_t i0 = pl.ops.size();
+      bd.ar = Arena(block + (size_t)k * chunk_floats);
+      const bool ok = chunk_walk(b0, nb, out_full + (size_t)b0 * out_ps);
+      if (!ok) { if (bd.rc) return bd.rc; set_error("unet: chunk walk mismatch"); return CSD_ERR_STATE; }
+      CSD_REQUIRE(bd.ar.peak() <= chunk_floats, "unet: a chunk outgrew its block");
+      for (size_t i = i0; i < pl.ops.size(); ++i) { pl.ops[i].nb = nb; pl.ops[i].stream = k; pl.ops[i].chunk = k + 1; }
+    }
+    {
+      Op j;
+      j.kind = OP_JOIN;
+      j.i0 = K;
+      pl.ops.push_back(j);
+    }
+    // back in the full batch
+    bd.ar = ar_main;
+    bd.B = B;
+    bd.tile_stats = tile_stats_main;
+    bd.tile_stats.erase(out_full);
+    bd.dense_all = dense_full; bd.gn_partial = gp_full; bd.nscale = ns_full; bd.nshift = nh_full;
+    hs.swap(hs_main);
+    bd.ar.release(block);
+    bd.ar.release(hs.back().off);      // the region's input: consumed by every chunk's last up block
+    hs.pop_back();
+    h = out_full;
+    up_sample(l0);
+    for (int l = l0 - 1; l >= 0; --l) {
+      up_blocks(l, NONE);
+      if (l != 0) up_sample(l);
     }
   }
   {
@@ -1589,6 +1784,7 @@ static int build_plan(Net& n, int B, Plan** out) {
   for (auto& p : n.params) pbytes += 4.0 * p.numel;
   pl.bytes += pbytes;
   fold_small_gn_pairs(pl);
+  if (!getenv("CSD_CHUNK_SEQ")) interleave_chunks(pl);
   pl.ws_floats = bd.ar.peak();
   *out = plp.get();
   n.plans[B] = std::move(plp);
@@ -1604,8 +1800,23 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
   bool side_pending = false;
   for (const Op& o : pl.ops) {
     int rc = CSD_OK;
+    // batch-chunk region: the chunk streams start behind everything enqueued so far; the caller's stream resumes behind all of them
+    if (o.kind == OP_FORK) {
+      if (!n.chunks_ready()) { set_error("unet: cannot create the chunk streams"); return CSD_ERR_HIP; }
+      CSD_CHECK_HIP(hipEventRecord(n.ev_cfork, s));
+      for (int k = 0; k + 1 < o.i0; ++k) CSD_CHECK_HIP(hipStreamWaitEvent(n.cstream[k], n.ev_cfork, 0));
+      continue;
+    }
+    if (o.kind == OP_JOIN) {
+      for (int k = 0; k + 1 < o.i0; ++k) {
+        CSD_CHECK_HIP(hipEventRecord(n.ev_cjoin[k], n.cstream[k]));
+        CSD_CHECK_HIP(hipStreamWaitEvent(s, n.ev_cjoin[k], 0));
+      }
+      continue;
+    }
+    const int Bo = o.nb ? o.nb : B;
     // side-stream ops: fork after everything enqueued so far, join before the op that consumes the result
-    hipStream_t so = s;
+    hipStream_t so = o.stream ? n.cstream[o.stream - 1] : s;
     if (o.side == 1 && n.side_ready()) {
       CSD_CHECK_HIP(hipEventRecord(n.ev_fork, s));
       CSD_CHECK_HIP(hipStreamWaitEvent(n.side, n.ev_fork, 0));
@@ -1617,52 +1828,52 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
     ProfScope prof(o.cls, o.flops, o.bytes, so);
     switch (o.kind) {
       case OP_ASSEMBLE:
-        rc = assemble_input_launch(x, y, y_noise, y_sigma, W(o.out), B, c.x_channels, c.y_channels, S * S,
-                                   n.in_cpad, c.centered, s);
+        rc = assemble_input_launch(x, y, y_noise, y_sigma, W(o.out), Bo, c.x_channels, c.y_channels, S * S,
+                                   n.in_cpad, c.centered, so);
         break;
       case OP_STEM:
-        rc = stem_launch(x, y, y_noise, y_sigma, pk + o.pk0, pk + o.pk1, W(o.out), reinterpret_cast<double*>(W(o.stats)), B,
-                         c.x_channels, c.y_channels, o.i0, S, c.centered, o.i4, s);
+        rc = stem_launch(x, y, y_noise, y_sigma, pk + o.pk0, pk + o.pk1, W(o.out), reinterpret_cast<double*>(W(o.stats)), Bo,
+                         c.x_channels, c.y_channels, o.i0, S, c.centered, o.i4, so);
         break;
       case OP_TEMB:
-        rc = timestep_embedding_launch(labels, W(o.out), B, o.i0, s);
+        rc = timestep_embedding_launch(labels, W(o.out), Bo, o.i0, so);
         break;
       case OP_FOURIER:
-        rc = fourier_embedding_launch(labels, pk + o.pk0, W(o.out), B, o.i0, s);
+        rc = fourier_embedding_launch(labels, pk + o.pk0, W(o.out), Bo, o.i0, so);
         break;
       case OP_FIR:
-        rc = fir_resample_nhwc_launch(W(o.a), W(o.out), B, o.i0, o.i0, o.i1, c.fir_kernel, o.i2, s);
+        rc = fir_resample_nhwc_launch(W(o.a), W(o.out), Bo, o.i0, o.i0, o.i1, c.fir_kernel, o.i2, so);
         break;
       case OP_FIR2:
-        rc = fir_resample2_nhwc_launch(W(o.a), W(o.d), W(o.e), W(o.c), W(o.out), B, o.i0, o.i0, o.i1, c.fir_kernel, o.i2, o.act, s);
+        rc = fir_resample2_nhwc_launch(W(o.a), W(o.d), W(o.e), W(o.c), W(o.out), Bo, o.i0, o.i0, o.i1, c.fir_kernel, o.i2, o.act, so);
         break;
       case OP_GN_APPLY32:
-        rc = gn_apply_launch(W(o.a), W(o.d), W(o.e), W(o.out), B, o.i1, o.i0, o.act, s);
+        rc = gn_apply_launch(W(o.a), W(o.d), W(o.e), W(o.out), Bo, o.i1, o.i0, o.act, so);
         break;
       case OP_LINEAR:
-        rc = linear_launch(W(o.a), pk + o.pk0, pk + o.pk1, W(o.out), B, o.i0, o.i1, o.act, s, o.i2);
+        rc = linear_launch(W(o.a), pk + o.pk0, pk + o.pk1, W(o.out), Bo, o.i0, o.i1, o.act, so, o.i2);
         break;
       case OP_GN_STATS:
-        rc = gn_stats_launch(o.gp, W(o.a), W(o.b), reinterpret_cast<double*>(W(o.out)), s, o.i0);
+        rc = gn_stats_launch(o.gp, W(o.a), W(o.b), reinterpret_cast<double*>(W(o.out)), so, o.i0);
         break;
       case OP_GN_FINAL:
         rc = gn_finalize_launch(o.gp, reinterpret_cast<const double*>(W(o.a)), pk + o.pk0, pk + o.pk1, 1e-6f,
-                                W(o.out), W(o.b), s);
+                                W(o.out), W(o.b), so);
         break;
       case OP_GN_FINAL_TILES:
         rc = gn_finalize_tiles_launch(reinterpret_cast<const double*>(W(o.a)), o.i0, o.i1,
-                                      reinterpret_cast<const double*>(W(o.b)), o.i2, o.i3, B, o.i4, o.gp.G, pk + o.pk0,
-                                      pk + o.pk1, 1e-6f, W(o.out), W(o.c), s);
+                                      reinterpret_cast<const double*>(W(o.b)), o.i2, o.i3, Bo, o.i4, o.gp.G, pk + o.pk0,
+                                      pk + o.pk1, 1e-6f, W(o.out), W(o.c), so);
         break;
       case OP_GN_STATFIN:
-        rc = gn_fused16_launch(W(o.a), W(o.b), o.gp.C0, o.gp.C1, pk + o.pk0, pk + o.pk1, 1e-6f, nullptr, nullptr, B, o.gp.HW, o.gp.G,
-                               CSD_ACT_NONE, s, 0, W(o.out), W(o.c));
+        rc = gn_fused16_launch(W(o.a), W(o.b), o.gp.C0, o.gp.C1, pk + o.pk0, pk + o.pk1, 1e-6f, nullptr, nullptr, Bo, o.gp.HW, o.gp.G,
+                               CSD_ACT_NONE, so, 0, W(o.out), W(o.c));
         break;
       case OP_GN_FUSED16:
-        rc = gn_fused16_launch(W(o.a), W(o.b), o.i0, o.i1, pk + o.pk0, pk + o.pk1, 1e-6f, W(o.out), W(o.c), B, o.i2, o.gp.G, o.act, s, o.i3);
+        rc = gn_fused16_launch(W(o.a), W(o.b), o.i0, o.i1, pk + o.pk0, pk + o.pk1, 1e-6f, W(o.out), W(o.c), Bo, o.i2, o.gp.G, o.act, so, o.i3);
         break;
       case OP_GN_APPLY16:
-        rc = gn_apply16_launch(W(o.a), W(o.b), o.i0, o.i1, W(o.d), W(o.e), W(o.out), W(o.c), B, o.i2, o.act, s, o.i3);
+        rc = gn_apply16_launch(W(o.a), W(o.b), o.i0, o.i1, W(o.d), W(o.e), W(o.out), W(o.c), Bo, o.i2, o.act, so, o.i3);
         break;
       case OP_CONV: {
         ConvArgs a;
@@ -1683,7 +1894,7 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
         rc = o.i2 == 3 ? convff_launch(o.cp, o.i4, a, so)
            : o.i2 == 2 ? conv16q_launch(o.cp, o.i4, a, so, o.i3 == 2)
            : o.i2 ? pw16_launch(o.cp, o.i4, a, so) : (o.i4 ? conv16_launch(o.cp, o.i4, a, so, o.i3 != 0) : conv_launch(o.cp, a, so));
-        if (so != s && rc == CSD_OK) {
+        if (so == n.side && n.side != nullptr && rc == CSD_OK) {
           CSD_CHECK_HIP(hipEventRecord(n.ev_join, n.side));
           side_pending = true;
         }
@@ -1692,17 +1903,17 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
       case OP_ATTN:
         // fp16 arithmetic modes: the split-operand kernel on the fp16 matrix cores (fp32-class in the split modes); fp32 mode: the fp32 MFMA one
         rc = (precision_ns(c.precision) && !CSD_TUNE_ENV("CSD_ATTN_F32"))
-                 ? attention16_launch(W(o.a), 3 * o.i1, W(o.out), B, o.i0, o.i1, precision_ns(c.precision) >= 2 ? 2 : 1, s)
-                 : attention_launch(W(o.a), 3 * o.i1, W(o.out), B, o.i0, o.i1, s);
+                 ? attention16_launch(W(o.a), 3 * o.i1, W(o.out), Bo, o.i0, o.i1, precision_ns(c.precision) >= 2 ? 2 : 1, so)
+                 : attention_launch(W(o.a), 3 * o.i1, W(o.out), Bo, o.i0, o.i1, so);
         break;
       case OP_AVGPOOL:
-        rc = avgpool2_launch(W(o.a), W(o.out), B, o.i0, o.i0, o.i1, s);
+        rc = avgpool2_launch(W(o.a), W(o.out), Bo, o.i0, o.i0, o.i1, so);
         break;
       case OP_UPNEAR:
-        rc = nearest_up2_nhwc_launch(W(o.a), W(o.out), B, o.i0, o.i0, o.i1, s);
+        rc = nearest_up2_nhwc_launch(W(o.a), W(o.out), Bo, o.i0, o.i0, o.i1, so);
         break;
       case OP_TAPSUM:
-        rc = tapsum_launch(W(o.a), pk + o.pk1, W(o.c), o.out_external ? out : W(o.out), B, o.i0, o.i1, o.i2, o.out_external, o.fscale, s);
+        rc = tapsum_launch(W(o.a), pk + o.pk1, W(o.c), o.out_external ? out : W(o.out), Bo, o.i0, o.i1, o.i2, o.out_external, o.fscale, so);
         break;
       default:
         set_error("unet: unknown op");

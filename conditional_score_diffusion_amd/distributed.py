@@ -60,17 +60,37 @@ def sample_sharded(sampler, model, y_global=None, n_total=None, seed=None, group
             raise ValueError('global-norm mode: %d images leave a rank of %d without work (it would miss the per-step all-reduce)'
                              % (n_global, world))
         sampler_kw['global_norm'] = (lambda sums: dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group), int(n_global))
-    if y_global is not None:
-        lo, hi = shard_bounds(n_global, rank, world)
-        if hi > lo:
-            x_local, info = sampler(model, y_global[lo:hi].contiguous(), seed=rank_seed(seed, rank), **sampler_kw)
-        else:               # an empty ragged shard: nothing to sample, an all-zero block for the gather
-            x_local, info = None, {}
-    else:
-        lo, hi = 0, None
-        x_local, info = sampler(model, seed=rank_seed(seed, rank), **sampler_kw)
+    # A shard whose state leaves the finite range raises NonFiniteError on ITS rank only (the finiteness contract of csd_pc_sample is
+    # per call).  Raised here, in front of the gather, it would leave the healthy ranks blocked in the collective until the RCCL
+    # timeout: the failure is carried across the group first (one MAX all-reduce of a flag) and then raised on EVERY rank.
+    from ._lib import NonFiniteError
+    failure, x_local, info = None, None, {}
+    try:
+        if y_global is not None:
+            lo, hi = shard_bounds(n_global, rank, world)
+            if hi > lo:
+                x_local, info = sampler(model, y_global[lo:hi].contiguous(), seed=rank_seed(seed, rank), **sampler_kw)
+            # (else: an empty ragged shard - nothing to sample, an all-zero block for the gather)
+        else:
+            lo, hi = 0, None
+            x_local, info = sampler(model, seed=rank_seed(seed, rank), **sampler_kw)
+    except NonFiniteError as e:
+        if not grouped or global_norm:      # (global-norm mode: every rank sees the same global norms and fails in the same step)
+            raise
+        failure = e
     if not grouped:
         return x_local, info
+    if not global_norm:
+        fdev = x_local.device if x_local is not None else (y_global.device if y_global is not None else torch.device('cpu'))
+        if dist.get_backend(group) == 'nccl' and fdev.type != 'cuda':
+            fdev = torch.device('cuda', torch.cuda.current_device())
+        flag = torch.tensor([1.0 if failure is not None else 0.0], dtype=torch.float32, device=fdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if failure is not None:
+            raise failure
+        if float(flag.item()) > 0:
+            raise NonFiniteError('sample_sharded: the shard of another rank left the finite range (its rank raises the details); '
+                                 'csd_precision = \'fp32\' is the escape')
     if y_global is not None:
         per = shard_size(n_global, world)
         if x_local is None or x_local.shape[0] < per:           # pad the ragged shard to the common gather size
@@ -150,9 +170,11 @@ class GradSync:
         self._pending = [len(b[2]) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._handles = []
+        self._closed = False
+        self._hook_handles = []     # removed by close(): a GradSync that is replaced must not keep reducing the shared buffer
         if self.grouped:
             for i, p in enumerate(flat.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                self._hook_handles.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
     def attach_planned(self, model):
         """Planned training graph (the whole backward is ONE csd_unet_backward call: no autograd hooks fire): register one
@@ -180,6 +202,9 @@ class GradSync:
         ev = (ctypes.c_void_p * len(first))(*self._events)
         check(lib().csd_unet_backward_marks(model._h, fm, ev, len(first)), 'unet_backward_marks')
         self._model = model
+        # the handle has ONE set of marks: whoever attached last owns it.  A GradSync that was replaced on the same model (a second
+        # Trainer built before the first is finalized) finds another owner in detach_planned() and leaves the marks alone
+        model._marks_owner = self
         self._comm = torch.cuda.Stream(device=self.flat.grad.device)
         self._epoch = int(lib().csd_unet_backward_marks_epoch(model._h))
         self.overlapped_launches = 0      # buckets launched from their event (statistics for tests / logs)
@@ -187,14 +212,27 @@ class GradSync:
 
     def __del__(self):
         try:
-            self.detach_planned()
+            self.close()
         except Exception:
             pass
+
+    def close(self):
+        """Retire this GradSync: its autograd hooks are removed (they would otherwise launch a second all-reduce of the shared flat
+        gradient next to the successor's), its gradient-ready events are destroyed, and the network handle's marks are erased
+        only if they are still THIS object's (round-5 advisor finding).  Idempotent."""
+        self._closed = True
+        for h in getattr(self, '_hook_handles', []):
+            h.remove()
+        self._hook_handles = []
+        self.detach_planned()
 
     def detach_planned(self):
         if getattr(self, '_events', None):
             from ._lib import lib
-            lib().csd_unet_backward_marks(self._model._h, None, None, 0)
+            model = self._model
+            if getattr(model, '_marks_owner', None) is self:
+                lib().csd_unet_backward_marks(model._h, None, None, 0)
+                model._marks_owner = None
             for e in self._events:
                 lib().csd_event_destroy(e)
         self._events = None
@@ -208,6 +246,8 @@ class GradSync:
 
     def _make_hook(self, i):
         def hook(param):
+            if self._closed:
+                return
             if getattr(self, '_events', None):        # planned graph: nothing was accumulated (the hook fires for an undefined
                 return                                # gradient too); finish() launches every bucket from its gradient-ready event
             b = self._bucket_of[i]

@@ -54,8 +54,9 @@ class Trainer:
         self.step = 0                     # completed optimizer steps (the warm-up factor of step k is k / warmup)
 
     def close(self):
-        """drop the gradient-ready events registered on the network handle (a Trainer rebuilt on the same model registers its own)"""
-        self.sync.detach_planned()
+        """retire the gradient synchronisation: autograd hooks removed, gradient-ready events destroyed, the network handle's marks
+        erased if they are still this Trainer's (a Trainer rebuilt on the same model registers its own and keeps them)"""
+        self.sync.close()
 
     def __del__(self):
         try:

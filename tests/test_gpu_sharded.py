@@ -261,6 +261,26 @@ def _planned_overlap_worker(port, q):
 
             a, b = run(True), run(False)
             same = bool(torch.equal(a.flat.data, b.flat.data)) and bool(torch.equal(a.ema.shadow, b.ema.shadow))
+            if case == 'sr3_tiny':
+                # a Trainer REBUILT on the same model while the first is alive, the first retired afterwards (round-5 advisor: the old
+                # GradSync's finalizer erased the new one's marks - the overlap was silently lost - and its hooks stayed registered)
+                import gc
+                torch.manual_seed(3)
+                _, _, _, model = bld_case(cfg)
+                tr1 = train.Trainer(cfg, model, sde_of(cfg), bucket_bytes=256 << 10)
+                torch.manual_seed(10)
+                tr1.train_step(batch)
+                tr2 = train.Trainer(cfg, model, sde_of(cfg), bucket_bytes=256 << 10)
+                old_sync = tr1.sync
+                del tr1
+                gc.collect()
+                for i in range(2):
+                    torch.manual_seed(11 + i)
+                    tr2.train_step(batch)
+                torch.cuda.synchronize()
+                res['rebuilt'] = dict(buckets=len(tr2.sync.buckets), overlapped=tr2.sync.overlapped_launches,
+                                      old_hooks=len(old_sync._hook_handles), old_closed=bool(old_sync._closed),
+                                      owner_is_new=getattr(model, '_marks_owner', None) is tr2.sync)
             if case.startswith('ncsnpp'):
                 res[case] = dict(buckets=len(a.sync.buckets), overlapped=a.sync.overlapped_launches, same=same,
                                  direct=bool(getattr(a.model, '_last_backward_direct', False)),
@@ -311,6 +331,9 @@ def test_planned_backward_records_gradient_ready_events_for_the_all_reduce():
     pr.join(timeout=120)
     assert err is None, err
     assert 'sr3_tiny' in res and 'ncsnpp_paired_skip' in res
+    rb = res.pop('rebuilt')
+    # the second Trainer keeps its gradient-ready events after the first one is finalized: every bucket of both steps launched from its event
+    assert rb['overlapped'] == 2 * rb['buckets'] and rb['old_hooks'] == 0 and rb['old_closed'] and rb['owner_is_new'], rb
     nc = res.pop('ncsnpp_paired_skip')
     # the planned NCSN++ graph: identical parameters with and without the event-driven launches - whether the backward could write the
     # gradient views itself (then every bucket is launched from its event) or not (then none may be)

@@ -72,7 +72,9 @@ def main(path):
             if t.startswith('s_endpgm'):
                 kernels[name] = cur
                 cur = None
-            elif t and not t.startswith((';', '.')):
+            elif t and not t.startswith(';') and (not t.startswith('.') or t.split(';')[0].strip().endswith(':')):
+                # directives (.p2align, .loc ...) are dropped; LABELS (.LBB0_3:) are kept - they are the basic-block boundaries check()
+                # drops its "behind the wait" state at (round-5 advisor finding: they used to be filtered with the directives)
                 cur.append(t.split(';')[0].strip())
     if not kernels:
         print('check_xp_isa: no conv_xp / conv_xw kernel in', path)
