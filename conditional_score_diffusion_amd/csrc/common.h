@@ -81,6 +81,31 @@ static inline int device_cu_count8() {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+#ifdef __HIPCC__
+// Workgroup copy global -> LDS of `bytes` (a multiple of 16): DEPTH 16-byte loads per thread IN FLIGHT before the first store.  The plain
+// loop `for (i = tid * 16; i < bytes; i += THREADS * 16) lds[i] = src[i]` compiles to load / s_waitcnt vmcnt(0) / ds_write per
+// iteration - one L2 round trip (~0.7 us) per 4 KiB of the workgroup: the 72 - 144 KiB weight copy of a pw16 workgroup was 12 - 25 us of
+// every launch, and the whole ~20 us floor of its launches on the small maps (NOTEBOOK round 6).  Addresses are clamped, not branched
+// around: a guarded load sits in its own basic block behind a wait.
+template <int THREADS, int DEPTH = 8>
+__device__ __forceinline__ void wg_copy_to_lds(char* __restrict__ dst, const char* __restrict__ src, int bytes, int tid) {
+  typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+  for (int i0 = tid * 16; i0 < bytes; i0 += THREADS * 16 * DEPTH) {
+    u4_t v[DEPTH];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      const int i = i0 + u * THREADS * 16;
+      v[u] = *reinterpret_cast<const u4_t*>(src + (i < bytes ? i : i0));
+    }
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      const int i = i0 + u * THREADS * 16;
+      if (i < bytes) *reinterpret_cast<u4_t*>(dst + i) = v[u];
+    }
+  }
+}
+#endif
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---------------------------------------------------------------------------------------

@@ -121,11 +121,7 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
   for (int u = 0; u < D; ++u) issue(raw[u], nsc[PFN ? u : 0], nsh[PFN ? u : 0]);
 
   // ---- this cout group's weights -> LDS, once per workgroup (behind the first activation requests: their latency overlaps the copy) ----
-  {
-    const char* wsrc = g_wpack + (size_t)ng * wbytes;
-    for (int i = tid * 16; i < wbytes; i += PW_THREADS * 16)
-      *reinterpret_cast<uint4*>(smem + i) = *reinterpret_cast<const uint4*>(wsrc + i);
-  }
+  wg_copy_to_lds<PW_THREADS, 9>(smem, g_wpack + (size_t)ng * wbytes, wbytes, tid);      // (9 x 4 KiB per round: a 288-channel layer's 108 KiB in three)
   if (tid < PW_NTL * 16) {                                // (zero where the cout does not exist)
     const int c = ng * (PW_NTL * 16) + tid;
     lds_bias[tid] = (k.a.bias && c < k.Cout) ? k.a.bias[c] : 0.f;

@@ -71,8 +71,7 @@ __global__ __launch_bounds__(256, 4) void stem_kernel(const StemArgs k) {
   // 1.5 GB per launch, more than twice the layer's output)
   {
     const int n16 = n_groups * ST_KSTEPS * NT * NS * 64;
-    const half8* const wg = reinterpret_cast<const half8*>(k.w);
-    for (int i = tid; i < n16; i += 256) wl[i] = wg[i];
+    wg_copy_to_lds<256, 8>(reinterpret_cast<char*>(wl), reinterpret_cast<const char*>(k.w), n16 * 16, tid);
   }
 
   // the assembled values of a patch pixel (thread t < 184 owns patch pixel t of every tile).  Straight-line on purpose: every load is

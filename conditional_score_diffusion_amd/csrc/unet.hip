@@ -1658,12 +1658,12 @@ static int build_plan(Net& n, int B, Plan** out) {
   // (tests: B = 64 == B = 1), so the chunked plan returns the bits of the unchunked one.
   int l0 = c.n_levels, K = 1;
   {
-    const char* e_side = getenv("CSD_CHUNK_SIDE");
-    const char* e_k = getenv("CSD_CHUNKS");
+    const char* e_side = CSD_TUNE_ENV("CSD_CHUNK_SIDE");
+    const char* e_k = CSD_TUNE_ENV("CSD_CHUNKS");
     const int chunk_side = e_side ? atoi(e_side) : 20;
     for (int l = 1; l <= last; ++l)
       if ((S >> l) <= chunk_side) { l0 = l; break; }
-    K = e_k ? atoi(e_k) : (B >= 32 ? 4 : (B >= 16 ? 2 : 1));
+    K = e_k ? atoi(e_k) : (B >= 32 ? 2 : 1);      // measured at B = 64 (NOTEBOOK round 6): 2 chunks -0.4 ms per PC step, 3 neutral, 4 +0.3 ms
     K = std::max(1, std::min(K, std::min(B, (int)Net::MAX_CHUNKS)));
     if (l0 > last) K = 1;
   }
@@ -1784,7 +1784,7 @@ static int build_plan(Net& n, int B, Plan** out) {
   for (auto& p : n.params) pbytes += 4.0 * p.numel;
   pl.bytes += pbytes;
   fold_small_gn_pairs(pl);
-  if (!getenv("CSD_CHUNK_SEQ")) interleave_chunks(pl);
+  if (!CSD_TUNE_ENV("CSD_CHUNK_SEQ")) interleave_chunks(pl);
   pl.ws_floats = bd.ar.peak();
   *out = plp.get();
   n.plans[B] = std::move(plp);
