@@ -195,7 +195,7 @@ def main():
             @staticmethod
             def profile_start(): pass
             @staticmethod
-            def profile_stop(): return {'conv3x3': {'ms': 0.0, 'launches': 0, 'flops': 0.0, 'bytes': 0.0}}
+            def profile_stop(): return {'conv3x3': {'ms': 0.0, 'launches': 0, 'flops': 0.0, 'bytes': 0.0, 'alg_bytes': 0.0}}
         _lib = _NoProfile
         x = torch.full((B, 3, 8, 8), float(rank))
 
@@ -287,7 +287,7 @@ def main():
         prof_all_ms = (time.perf_counter() - t1) / n2 * 1e3
         prof_all = _lib.profile_stop()
         prof_all = {k: dict(v, ms=v['ms'] * K / n2, launches=v['launches'] * K // n2, flops=v['flops'] * K / n2,
-                            bytes=v['bytes'] * K / n2) for k, v in prof_all.items()}
+                            bytes=v['bytes'] * K / n2, alg_bytes=v['alg_bytes'] * K / n2) for k, v in prof_all.items()}
     # diagnostic for the first multi-GPU run (never part of `value`): every rank's own step time and what the all-gather cost it
     per_rank = {'ms_per_step': [t_steps / K * 1e3], 'all_gather_ms': [t_gather * 1e3]}
     if grouped:
@@ -329,13 +329,14 @@ def main():
         modes = {
             'fp32': dict(peak=F32_MFMA_PEAK_TF, mfma_per_product=1.0, operand='fp32 (24 significand bits)',
                          kernel='conv_f32_kernel (3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)'),
-            # conv_xk (the 160^2 / 80^2 / 40^2 levels: 92 % of the class's flops at the SR3-160 shape) is 1-D Winograd F(2,3): 4 instead of 6
-            # contractions per output pair, i.e. 3 x 2/3 = 2 MFMAs per algorithmic product; the quad kernel below 40^2 issues 3
-            'fp16x3': dict(peak=F16_MFMA_PEAK_TF, mfma_per_product=0.92 * 2.0 + 0.08 * 3.0, operand='hi + lo fp16 per operand (22 significand bits; the lo*lo term, 2^-22 relative, is dropped)',
-                           kernel='3x3 stride-1 convolution class: conv_xk_kernel (1-D Winograd F(2,3) along the row, one transform component per wave: fused '
-                                  'GroupNorm+SiLU+transform+split prologue as fillers between the MFMAs of one software-pipelined stream per SIMD, weights from L2 '
-                                  'straight into registers, persistent 4-wave workgroup per CU, 2x v_mfma_f32_32x32x16_f16 per algorithmic product; the 160^2 / 80^2 '
-                                  'levels and, on ragged 16x16 tiles, 40^2) + conv_f16_q_kernel<NS=2> (20^2 and below, 3x per product)'),
+            # class 'conv3x3' in this mode = the conv_xk launches only (the 160^2 / 80^2 / 40^2 levels: 92 % of the 3x3 stride-1 flops of the
+            # SR3-160 shape): 1-D Winograd F(2,3), 4 instead of 6 contractions per output pair, i.e. 3 x 2/3 = 2 MFMAs per algorithmic
+            # product.  The first layer and the quad kernel below 40^2 report as 'conv3x3_other' (kernel_classes_ms_per_step)
+            'fp16x3': dict(peak=F16_MFMA_PEAK_TF, mfma_per_product=2.0, operand='hi + lo fp16 per operand (22 significand bits; the lo*lo term, 2^-22 relative, is dropped)',
+                           kernel='conv_xk_kernel: every 3x3 stride-1 convolution of the 160^2 / 80^2 / 40^2 levels (1-D Winograd F(2,3) along the row, one transform '
+                                  'component per wave: fused GroupNorm+SiLU+transform+split prologue as fillers between the MFMAs of one software-pipelined stream '
+                                  'per SIMD, weights from L2 straight into registers, persistent 4-wave workgroup per CU, 2x v_mfma_f32_32x32x16_f16 per '
+                                  'algorithmic product; ragged 16x16 tiles at 40^2)'),
             'fp16f8': dict(peak=F16_MFMA_PEAK_TF, mfma_per_product=2.0, operand='fp16 hi x fp16 hi + two correction products with e4m3 operands (~15 significand bits per operand: '
                                                                                   'NARROWER than the reference\'s fp32)',
                            kernel='3x3 stride-1 convolution class: conv_ff_kernel<NS=2,F8> / conv_fx_kernel (hi*hi on v_mfma_f32_32x32x16_f16, corrections on '
@@ -344,8 +345,12 @@ def main():
                          kernel='3x3 stride-1 convolution class: conv_ff_kernel<NS=1> + conv_f16_lc_kernel<NS=1>'),
         }[args.precision]
         dom_kernel, dom_peak = modes['kernel'], modes['peak']
-        dom_gbs = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9 if dom['ms'] > 0 else 0.0
-        dom_ai = dom['flops'] / max(dom['bytes'], 1.0)
+        # the kernel's ALGORITHMIC bytes are input + output tensor of the layer in fp32 - nothing else.  What the kernel
+        # itself has to move on top of that (the residual read of a block's second convolution) is reported beside it as
+        # kernel_bytes_per_launch and is NOT part of `achieved` / `frac`
+        dom_alg = dom.get('alg_bytes', dom['bytes'])
+        dom_gbs = dom_alg / (dom['ms'] * 1e-3) / 1e9 if dom['ms'] > 0 else 0.0
+        dom_ai = dom['flops'] / max(dom_alg, 1.0)
         ridge = dom_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
         if dom_ai < ridge:
             roof = {'bound': 'hbm', 'achieved': dom_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dom_gbs / HBM_PEAK_GBS}
@@ -354,7 +359,7 @@ def main():
         # HBM traffic of the same kernel class from PMC counters (a separate rocprofv3 pass cannot run inside this
         # process): the committed summary of tools/pmc_hbm.sh for this mode, bytes per launch like `achieved`
         traffic, traffic_src = None, None
-        for rnd in ('r05', 'r04', 'r03'):
+        for rnd in ('r06', 'r05', 'r04', 'r03'):
             tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', '%s_hbm_traffic_%s.json' % (rnd, args.precision))
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
@@ -363,7 +368,11 @@ def main():
                 break
         roof.update({'kernel': dom_kernel, 'traffic': traffic, 'traffic_unit': 'bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)',
                      'traffic_source': traffic_src,
-                     'algorithmic_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
+                     'algorithmic_bytes_per_launch': dom_alg / max(dom['launches'], 1),
+                     'algorithmic_bytes_definition': 'SURVEY.md 8(d): (input + output tensor of the layer) x 4 B, summed over the launches of the class and '
+                                                     'divided by their count; `achieved` = these bytes / the event-measured duration of the same launches',
+                     'kernel_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
+                     'kernel_bytes_definition': 'what the kernel has to move: algorithmic bytes + the residual tensor the second convolution of a block reads',
                      'peak_note': 'guide peaks: HBM3E 8000 GB/s; dense MFMA %.1f TFLOP/s for this mode\'s matrix instruction' % dom_peak,
                      'arithmetic_intensity_flop_per_byte': dom_ai, 'ridge_flop_per_byte': ridge,
                      'achieved_TFLOPs': dom_tf, 'achieved_GBs': dom_gbs,
@@ -423,6 +432,27 @@ def main():
                 except Exception as e:      # a side measurement must never break the bench line
                     alt[mode] = {'error': str(e)[:200]}
             res['other_precision_modes'] = alt
+            # what ONE GPU can show of strong scaling: the same loop at the per-GPU batch of a global batch of 64 sharded
+            # over 8 / 4 / 2 GPUs.  predictor(N) = N x value(B = 64 / N) / value(B = 64): the speed-up N GPUs would reach on a global batch
+            # of 64 with a free all-gather.  (bench.py --gpus N itself is WEAK scaling: 64 images per GPU.)
+            try:
+                import subprocess
+                if B != 64:
+                    raise ValueError('measured for the default per-GPU batch (64) only')
+                ss = {}
+                for bb in (8, 16, 32):
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--precision', args.precision, '--steps', '20', '--warmup', '5',
+                                        '--no-cpu-baseline', '--no-alt', '--no-profile', '--batch', str(bb)], capture_output=True, text=True, timeout=600)
+                    j = json.loads(r.stdout.strip().splitlines()[-1])
+                    ss['B%d' % bb] = {'value': j['value'], 'ms_per_step': j['ms_per_step']}
+                res['strong_scaling_predictor'] = dict(
+                    ss, global_batch=64, value_B64=value,
+                    predicted_speedup={'8_gpus': 8 * ss['B8']['value'] / value, '4_gpus': 4 * ss['B16']['value'] / value,
+                                       '2_gpus': 2 * ss['B32']['value'] / value},
+                    note='one-GPU measurement of the per-GPU share of a global batch of 64; no communication term (the single all-gather of '
+                         '64 x 3 x 160 x 160 floats is < 0.1 ms over xGMI)')
+            except Exception as e:
+                res['strong_scaling_predictor'] = {'error': str(e)[:200]}
             # SURVEY 8(d) "config 4": one data-parallel training step (loss + HIP backward + gradient all-reduce + fused
             # clip/Adam/EMA) of the VS-CMDE edges2shoes-64 shape, measured by tools/bench_train.py - a side figure, not the headline
             try:

@@ -68,6 +68,8 @@ SIGNATURES = {
     'csd_profile_select': (_i, [ctypes.c_uint, _i]),
     'csd_profile_stop': (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),
                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    'csd_profile_stop_ex': (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double),
+                                 ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     'csd_unet_create': (_i, [ctypes.POINTER(UNetConfig), ctypes.POINTER(_vp)]),
     'csd_unet_destroy': (None, [_vp]),
     'csd_unet_num_params': (_i, [_vp]),
@@ -166,7 +168,8 @@ def lib():
     return _lib
 
 
-PROF_CLASSES = ['conv3x3', 'conv3x3_resample', 'conv1x1', 'gn_stats', 'gn_finalize', 'attention', 'sampler', 'other', 'gn_apply16']
+PROF_CLASSES = ['conv3x3', 'conv3x3_resample', 'conv1x1', 'gn_stats', 'gn_finalize', 'attention', 'sampler', 'other', 'gn_apply16',
+                'conv3x3_other']
 
 
 def profile_start():
@@ -180,12 +183,13 @@ def profile_select(classes=None, step_stride=1):
 
 
 def profile_stop():
-    """-> {class: {'ms', 'launches', 'flops', 'bytes'}} for the launches since profile_start()."""
+    """-> {class: {'ms', 'launches', 'flops', 'bytes', 'alg_bytes'}} for the launches since profile_start(): `bytes` = what the kernels
+    have to move (operand planes, residual reads), `alg_bytes` = SURVEY.md 8(d): input + output tensor of the layer, fp32."""
     n = len(PROF_CLASSES)
-    ms, fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
+    ms, fl, by, ab = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
     la = (ctypes.c_int64 * n)()
-    check(lib().csd_profile_stop(n, ms, la, fl, by), 'profile_stop')
-    return {PROF_CLASSES[i]: {'ms': ms[i], 'launches': la[i], 'flops': fl[i], 'bytes': by[i]} for i in range(n)}
+    check(lib().csd_profile_stop_ex(n, ms, la, fl, by, ab), 'profile_stop')
+    return {PROF_CLASSES[i]: {'ms': ms[i], 'launches': la[i], 'flops': fl[i], 'bytes': by[i], 'alg_bytes': ab[i]} for i in range(n)}
 
 
 ERR_NONFINITE = -6            # include/csd.h CSD_ERR_NONFINITE

@@ -369,13 +369,21 @@ __global__ __launch_bounds__(GNFU_THREADS) void gn_fused16_kernel(
   double s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0; q[j] = 0; }
+  // every sweep's two loads are requested before the first is used: clamped addresses, no branch around a load (a guarded load sits in
+  // its own basic block behind an s_waitcnt - six dependent L2 round trips per thread, ~5 us of a launch that moves 2 MB; round 6)
+  float4 ld0[GNFU_MAXS], ld1[GNFU_MAXS];
 #pragma unroll
   for (int k = 0; k < GNFU_MAXS; ++k) {
-    const int p = pr + k * rows;
-    if (active && p < HW) {
-      const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)p * Cs);
-      const float4 a1 = *reinterpret_cast<const float4*>(src + (size_t)p * Cs + 4);
-      v[k][0] = a0.x; v[k][1] = a0.y; v[k][2] = a0.z; v[k][3] = a0.w; v[k][4] = a1.x; v[k][5] = a1.y; v[k][6] = a1.z; v[k][7] = a1.w;
+    const int p = min(pr + k * rows, HW - 1);
+    ld0[k] = *reinterpret_cast<const float4*>(src + (size_t)p * Cs);
+    ld1[k] = *reinterpret_cast<const float4*>(src + (size_t)p * Cs + 4);
+  }
+#pragma unroll
+  for (int k = 0; k < GNFU_MAXS; ++k) {
+    const bool valid = active && pr + k * rows < HW;
+    v[k][0] = ld0[k].x; v[k][1] = ld0[k].y; v[k][2] = ld0[k].z; v[k][3] = ld0[k].w;
+    v[k][4] = ld1[k].x; v[k][5] = ld1[k].y; v[k][6] = ld1[k].z; v[k][7] = ld1[k].w;
+    if (valid) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { s[j] += v[k][j]; q[j] += (double)v[k][j] * v[k][j]; }
     }
@@ -385,9 +393,17 @@ __global__ __launch_bounds__(GNFU_THREADS) void gn_fused16_kernel(
     for (int j = 0; j < 8; ++j) { sred[0][pr * cb + u * 8 + j] = s[j]; sred[1][pr * cb + u * 8 + j] = q[j]; }
   }
   __syncthreads();
-  if (t < cb) {                                      // rows folded per channel, in row order
+  if (t < cb) {                                      // rows folded per channel, in row order (eight LDS reads in flight, the adds in order)
     double a = 0, bq = 0;
-    for (int r = 0; r < rows; ++r) { a += sred[0][r * cb + t]; bq += sred[1][r * cb + t]; }
+    int r = 0;
+    for (; r + 8 <= rows; r += 8) {
+      double x0[8], x1[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { x0[i] = sred[0][(r + i) * cb + t]; x1[i] = sred[1][(r + i) * cb + t]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { a += x0[i]; bq += x1[i]; }
+    }
+    for (; r < rows; ++r) { a += sred[0][r * cb + t]; bq += sred[1][r * cb + t]; }
     chs[0][t] = a;
     chs[1][t] = bq;
   }

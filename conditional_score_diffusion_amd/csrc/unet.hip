@@ -33,7 +33,7 @@ const char* get_error() { return g_err; }
 // in-library profiler: HIP events around every launch of the network / sampler, recorded on the
 // SAME stream the kernels run on (bench.py's roofline numbers come from here)
 // ---------------------------------------------------------------------------------------------
-struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes, abytes; };
 struct Profiler {
   bool on = false;
   unsigned mask = ~0u;        // launch classes that get events (bit = CSD_PROF_* id)
@@ -49,7 +49,7 @@ static thread_local Profiler g_prof;
 struct ProfScope {
   hipStream_t s;
   hipEvent_t b = nullptr;
-  ProfScope(int cls, double flops, double bytes, hipStream_t s_) : s(s_) {
+  ProfScope(int cls, double flops, double bytes, hipStream_t s_, double abytes = -1.0) : s(s_) {
     if (!g_prof.on || !g_prof.step_on || !((g_prof.mask >> cls) & 1u)) return;
     if (g_prof.used == g_prof.pool.size()) {
       hipEvent_t e0, e1;
@@ -59,7 +59,7 @@ struct ProfScope {
     auto& pr = g_prof.pool[g_prof.used++];
     (void)hipEventRecord(pr.first, s);
     b = pr.second;
-    g_prof.recs.push_back({pr.first, pr.second, cls, flops, bytes});
+    g_prof.recs.push_back({pr.first, pr.second, cls, flops, bytes, abytes < 0 ? bytes : abytes});
   }
   ~ProfScope() {
     if (b) (void)hipEventRecord(b, s);
@@ -132,7 +132,8 @@ struct Op {
   size_t temb_col = NONE;             // column offset inside dense_all
   int temb_stride = 0;
   int cls = CSD_PROF_OTHER;           // profiling class
-  double flops = 0, bytes = 0;        // algorithmic work of this launch
+  double flops = 0, bytes = 0;        // algorithmic flops of this launch; bytes THIS kernel has to move
+  double abytes = -1;                 // SURVEY 8(d) bytes of the layer (input + output tensor, fp32) where they differ from `bytes`
 };
 
 struct Plan {
@@ -1086,6 +1087,7 @@ struct Builder {
     count(2.0 * out_elems * cin * o.cp.taps, ((double)B * ih * iw * cin + (double)out_elems) * 4);
     // the profiler's per-launch bytes are what THIS kernel has to move (fp16 planes in, fp32 out, residual in);
     // the plan totals above stay the SURVEY 8(d) algorithmic figures
+    pl.ops.back().abytes = pl.ops.back().bytes;
     pl.ops.back().bytes = (double)B * ih * iw * (o.cp.C0 + o.cp.C1) * (o.i3 ? 2.0 * pc.ns : 4.0) +
                           (double)out_elems * 4 * (res != NONE ? 2 : 1);
     return o.out;
@@ -1254,6 +1256,17 @@ static void fold_small_gn_pairs(Plan& pl) {
     }
   }
   pl.ops.swap(out);
+}
+
+// profiling classes: when the plan runs its big 3x3 stride-1 layers on the fused-prologue kernel (conv_xk / conv_ff: OP_CONV with i2 == 3),
+// class CSD_PROF_CONV3X3 is THAT kernel's launches - the bench's roofline object prices the dominant kernel, SURVEY 8(d) - and the
+// other 3x3 stride-1 launches (the first layer, the quad kernel on the small maps) report as CSD_PROF_CONV3X3_OTHER
+static void split_conv3x3_classes(Plan& pl) {
+  bool any_ff = false;
+  for (const Op& o : pl.ops) any_ff = any_ff || (o.kind == OP_CONV && o.i2 == 3);
+  if (!any_ff) return;
+  for (Op& o : pl.ops)
+    if (o.cls == CSD_PROF_CONV3X3 && !(o.kind == OP_CONV && o.i2 == 3)) o.cls = CSD_PROF_CONV3X3_OTHER;
 }
 
 // the ops of a chunk region are enqueued round robin over the chunks (op j of every chunk, then op j + 1): when the host is the slower
@@ -1483,6 +1496,7 @@ static int build_plan(Net& n, int B, Plan** out) {
     for (auto& p : n.params) pbytes1 += 4.0 * p.numel;
     pl.bytes += pbytes1;
     fold_small_gn_pairs(pl);
+    split_conv3x3_classes(pl);
     pl.ws_floats = bd.ar.peak();
     *out = plp.get();
     n.plans[B] = std::move(plp);
@@ -1784,6 +1798,7 @@ static int build_plan(Net& n, int B, Plan** out) {
   for (auto& p : n.params) pbytes += 4.0 * p.numel;
   pl.bytes += pbytes;
   fold_small_gn_pairs(pl);
+  split_conv3x3_classes(pl);
   if (!CSD_TUNE_ENV("CSD_CHUNK_SEQ")) interleave_chunks(pl);
   pl.ws_floats = bd.ar.peak();
   *out = plp.get();
@@ -1825,7 +1840,7 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
       CSD_CHECK_HIP(hipStreamWaitEvent(s, n.ev_join, 0));
       side_pending = false;
     }
-    ProfScope prof(o.cls, o.flops, o.bytes, so);
+    ProfScope prof(o.cls, o.flops, o.bytes, so, o.abytes);
     switch (o.kind) {
       case OP_ASSEMBLE:
         rc = assemble_input_launch(x, y, y_noise, y_sigma, W(o.out), Bo, c.x_channels, c.y_channels, S * S,
@@ -2022,11 +2037,15 @@ extern "C" int csd_profile_start(void) {
 }
 
 extern "C" int csd_profile_stop(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes) {
+  return csd_profile_stop_ex(n_classes, ms, launches, flops, bytes, nullptr);
+}
+
+extern "C" int csd_profile_stop_ex(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes, double* alg_bytes) {
   g_prof.on = false;
   CSD_REQUIRE(n_classes >= CSD_PROF_NUM_CLASSES && ms && launches && flops && bytes, "profile_stop: bad arguments");
-  for (int i = 0; i < n_classes; ++i) { ms[i] = 0; launches[i] = 0; flops[i] = 0; bytes[i] = 0; }
+  for (int i = 0; i < n_classes; ++i) { ms[i] = 0; launches[i] = 0; flops[i] = 0; bytes[i] = 0; if (alg_bytes) alg_bytes[i] = 0; }
   if (g_prof.recs.empty()) return CSD_OK;
-  CSD_CHECK_HIP(hipEventSynchronize(g_prof.recs.back().b));
+  for (auto& r : g_prof.recs) CSD_CHECK_HIP(hipEventSynchronize(r.b));      // (the records may sit on several streams: batch chunks)
   for (auto& r : g_prof.recs) {
     float t = 0.f;
     CSD_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
@@ -2034,6 +2053,7 @@ extern "C" int csd_profile_stop(int n_classes, double* ms, int64_t* launches, do
     launches[r.cls] += 1;
     flops[r.cls] += r.flops;
     bytes[r.cls] += r.bytes;
+    if (alg_bytes) alg_bytes[r.cls] += r.abytes;
   }
   g_prof.recs.clear();
   g_prof.used = 0;

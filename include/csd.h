@@ -55,11 +55,13 @@ const char* csd_version(void);
 const char* csd_last_error(void);
 
 /* In-library profiler: while enabled, every kernel launch of csd_unet_forward / csd_pc_sample is
- * bracketed by HIP events on the caller's stream.  csd_profile_stop synchronises the last event
- * and returns, per launch class, total milliseconds, launch count and the ALGORITHMIC flops/bytes
- * of those launches (flops = 2*MACs; bytes = input + output tensor of the launch, fp32). */
+ * bracketed by HIP events on the stream the kernel runs on.  csd_profile_stop synchronises the last event
+ * and returns, per launch class, total milliseconds, launch count, the algorithmic flops (2 * MACs) and the bytes
+ * THE KERNEL has to move (its operand planes in, fp32 out, a residual read where it has one); csd_profile_stop_ex
+ * also returns the ALGORITHMIC bytes of SURVEY.md 8(d): input + output tensor of the layer, fp32, nothing else. */
 enum {
-  CSD_PROF_CONV3X3 = 0,           /* 3x3 stride-1 convolutions (the dominant kernel)        */
+  CSD_PROF_CONV3X3 = 0,           /* 3x3 stride-1 convolutions on the mode's dominant kernel (fp16x3: conv_xk_kernel;
+                                     a mode without a fused-prologue kernel: every 3x3 stride-1 convolution)             */
   CSD_PROF_CONV3X3_RESAMPLE = 1,  /* stride-2 / nearest-x2-fused 3x3 convolutions            */
   CSD_PROF_CONV1X1 = 2,           /* NIN / 1x1 contractions                                   */
   CSD_PROF_GN_STATS = 3,
@@ -68,7 +70,8 @@ enum {
   CSD_PROF_SAMPLER = 6,           /* predictor / corrector updates (+ norms)                  */
   CSD_PROF_OTHER = 7,             /* input assembly, time embedding, dense layers             */
   CSD_PROF_GN_APPLY = 8,          /* GroupNorm+activation+fp16 split pass (fp16 conv modes)   */
-  CSD_PROF_NUM_CLASSES = 9
+  CSD_PROF_CONV3X3_OTHER = 9,     /* 3x3 stride-1 convolutions NOT on the dominant kernel: the first layer, the <= 20^2 levels */
+  CSD_PROF_NUM_CLASSES = 10
 };
 /* Restrict the events to the launch classes whose bit (1u << CSD_PROF_*) is set and, inside csd_pc_sample, to every
  * step_stride-th PC step (defaults: all classes, every step).  An event pair costs ~5-15 us of stream time (the records
@@ -77,6 +80,7 @@ enum {
 int csd_profile_select(unsigned class_mask, int step_stride);
 int csd_profile_start(void);
 int csd_profile_stop(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes);
+int csd_profile_stop_ex(int n_classes, double* ms, int64_t* launches, double* flops, double* bytes, double* alg_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * Score network (U-Net) - replaces models/ddpm.py:80-213 (DDPM), :275-298 (DDPM_paired_SR3,
