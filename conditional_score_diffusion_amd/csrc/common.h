@@ -191,7 +191,7 @@ size_t convff_packed_bytes(const ConvPlan& p, int ns);
 int convff_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, int cin_src, int cout_src, int cout_off,
                        void* wpack, hipStream_t s);
 int convff_plan_tiles(ConvPlan* p, int ns);
-// the layers conv_ff runs as the software-pipelined stream of conv_xp.hip (fp32-class operands, an even number >= 4 of 16-channel stages)
+// the layers conv_ff runs as the software-pipelined stream of conv_xk.hip (fp32-class operands, an even number >= 4 of 16-channel stages)
 bool convff_pipelined(const ConvPlan& p, int ns);
 int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s);
 // pointwise (1x1) layers on the fp16 MFMA path (conv_pw16.hip): fp32 NHWC in / out, optional GroupNorm affine on the

@@ -508,7 +508,7 @@ __global__ __launch_bounds__(192, 2) void conv_f16_kernel(const void* __restrict
   // (the hardware returns 0 for the load and drops the store).  Per-element `if`s here made the compiler
   // put each access in its own basic block behind an s_waitcnt vmcnt(0) - on gfx9 that counter also
   // tracks stores, so the 64 stores of a wave completed one HBM round trip at a time and the epilogue
-  // was 60% of the kernel (tools/phase_timing.py).
+  // was 60% of the kernel (tools/probes/phase_timing.py).
   const int ohw = k.OH * k.OW;
   const float wunscale = 1.0f / C16_WSCALE;
   const int col = (ng * k.nw + wave) * 32 + (lane & 31);

@@ -2,7 +2,7 @@
 // (same arithmetic, fragment layouts, LDS patch layout and epilogue as conv_f16_kernel.h; reference
 // layers: models/layers.py:ddpm_conv3x3 inside ResnetBlockDDPM, models/ddpm.py:149-213).
 //
-// Why a second schedule.  tools/phase_timing.py + an ablation (profiles/) showed two things about the
+// Why a second schedule.  tools/probes/phase_timing.py + an ablation (profiles/) showed two things about the
 // single-role kernel at 160x160:
 //   * a wave's VMEM loads return IN ORDER (one vmcnt), so the burst that fetches the next K stage's patch
 //     (HBM latency) blocks every later weight-fragment load (L2 latency) of the same wave: each stage
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_lc_kernel(const void* __restr
       const int pix0 = (int)(o_base - (size_t)b0 * ohw);
       // EVERY global read of the epilogue is issued before the first store: vmcnt retires in order and counts
       // stores too, so a load issued after a store cannot be consumed before that store is acknowledged by
-      // memory - measured (tools/phase_timing_lc.py): the second half of a two-batch epilogue sat 30k cycles
+      // memory - measured (tools/probes/phase_timing_lc.py): the second half of a two-batch epilogue sat 30k cycles
       // behind the first half's 32 stores.
       auto PIX = [&](int mt, int r) { return mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg; };
       float addv[MT][16];

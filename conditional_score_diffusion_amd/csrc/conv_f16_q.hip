@@ -28,7 +28,7 @@ typedef unsigned int uint4q __attribute__((ext_vector_type(4)));
 
 // sum of a double over the 16 lanes of a DPP row, result in every lane: quad_perm xor 1, xor 2, then row rotations by 4
 // and 8 - VALU-rate data movement (a ds_bpermute butterfly of 24 doubles cost 8.6k cycles per workgroup, 15 % of the
-// kernel: tools/phase_timing_q.py)
+// kernel: tools/probes/phase_timing_q.py)
 __device__ __forceinline__ double dpp_row16_sum(double v) {
 #define CSD_DPP_STEP(CTRL)                                                                                   \
   {                                                                                                          \

@@ -69,13 +69,7 @@ struct FFCfg {
 
 // conv_fx.hip: the fp16f8 form with one workgroup per CU (whole-stage weight buffers, one barrier per stage)
 int convfx_launch(const ConvFFArgs& k, int nt, hipStream_t s);
-// conv_xp.hip: the fp16x3 form as one software-pipelined stream per SIMD (one 4-wave workgroup per CU, persistent)
-bool convxp_supported(const ConvFFArgs& k, int nt);
-int convxp_launch(const ConvFFArgs& k, int nt, hipStream_t s);
-// conv_xw.hip: conv_xp's stream in the 1-D Winograd F(2,3) form (4 instead of 6 contractions per output pair; its own packed weights)
-bool convxw_supported(const ConvFFArgs& k, int nt);
-int convxw_launch(const ConvFFArgs& k, int nt, hipStream_t s);
-// conv_xk.hip: conv_xw's operator with one transform component per wave (weights from L2 straight into registers, no LDS ring)
+// conv_xk.hip: the fp16x3 form - 1-D Winograd F(2,3), one software-pipelined stream per SIMD, one transform component per wave
 bool convxk_supported(const ConvFFArgs& k, int nt);
 int convxk_launch(const ConvFFArgs& k, int nt, hipStream_t s);
 

@@ -12,7 +12,7 @@
 //   * MFMA: v_mfma_f32_32x32x16_f16 with A = pixels, B = weights: a lane's 16 results are ONE cout of 16 pixels, so a residual load /
 //     output store of a wave is two whole 128-byte lines per instruction and the GroupNorm partials are in-lane sums (the
 //     weights-as-M order gave each lane 4 x 4 consecutive couts of one pixel - 16-byte stores whose 32-byte pieces reach L2 as four
-//     partial-line writes: 3.3 TB/s against 5.4 TB/s in tools/store_probe.hip, and -6..8 % on the 160^2 layers).  Wave w owns pixel
+//     partial-line writes: 3.3 TB/s against 5.4 TB/s in tools/probes/store_probe.hip, and -6..8 % on the 160^2 layers).  Wave w owns pixel
 //     rows 4w..4w+3 as two 4 x 8 M tiles (that lane->pixel map + a 1168-byte LDS row pitch makes every ds_read_b128 of a tap
 //     conflict-free) and ALL NT cout tiles: 2*NT accumulators, 2 + NT fragment reads per K step.
 //   * weights: through LDS, shared by the four waves (each wave pulling its own fragments from L2 saturates the
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
   constexpr float acc_in = NORM ? C16_WSCALE * FF_NLOG2E : C16_WSCALE;         // = 2^8 / -ln2
   constexpr float acc_out = NORM ? -0.6931471805599453f / C16_WSCALE : 1.0f / C16_WSCALE;
   // convert + write the prefetched stage: GroupNorm affine + SiLU + split, ~40 vector instructions per 4 channels (every one of
-  // them is matrix-pipe time on this chip: tools/mfma_valu_overlap.hip, tools/mfma_valu_prio.hip - a partner wave's VALU stream
+  // them is matrix-pipe time on this chip: tools/probes/mfma_valu_overlap.hip, tools/probes/mfma_valu_prio.hip - a partner wave's VALU stream
   // overlaps a dense MFMA stream by 15-20 % whatever the age / s_setprio of the two waves).  Per element: fma, v_exp, add, v_rcp,
   // mul (SiLU), select (zero padding of the ACTIVATED tensor), half a packed f32 -> f16 conversion, ONE mixed-precision fma for
   // lo = v - hi (reads the fp16 half directly), and in the F8 form half an e4m3 conversion each for lo * 2^11 and for v.
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
         const float l0 = ff_lo<false>(hp0, v[0]), l1 = ff_lo<true>(hp0, v[1]), l2 = ff_lo<false>(hp1, v[2]), l3 = ff_lo<true>(hp1, v[3]);
         if constexpr (F8) {
           // e4m3 has no infinity: beyond 448 a conversion produces NaN - unless MODE.FP16_OVFL is set (kernel entry), which makes
-          // every fp8 conversion saturate at +-448 (tools/cvt_probe.hip): no clamp instructions.  The 2^11 scaling of the lo part
+          // every fp8 conversion saturate at +-448 (tools/probes/cvt_probe.hip): no clamp instructions.  The 2^11 scaling of the lo part
           // is the scale operand of v_cvt_scalef32_pk_fp8_f32 (it divides by the scale); the e4m3 "hi" operand is taken from v
           // itself (3 mantissa bits either way).  The conversions' pass-through operand is dead data (both halves are written).
           short2v l8 = __builtin_bit_cast(short2v, __float_as_int(h[0]));
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
   // ---- accumulators: (bias + temb + residual) * 2^8 ----
   // The PIXELS are the MFMA's M operand, the couts its N operand: a lane holds ONE cout (nt*32 + p32) of 16 pixels of each M tile -
   // register r = pixel 8 (r / 4) + 4 kh + r % 4 of the tile's 32 (4 rows x 8 columns) - so every residual load and output store of a
-  // wave covers whole 128-byte lines (tools/store_probe.hip: 5.4 TB/s against 3.3 TB/s for the weights-as-M layout, whose lanes own
+  // wave covers whole 128-byte lines (tools/probes/store_probe.hip: 5.4 TB/s against 3.3 TB/s for the weights-as-M layout, whose lanes own
   // 16-byte pieces that four different instructions assemble into a line), and the GroupNorm partials are in-lane sums.
   // The residual (the block's shortcut) is requested FIRST, straight into the accumulator registers, before the weight DMAs and the
   // first patch: ONE HBM round trip for all three (it used to be loaded one M tile at a time behind the patch: two more round trips,
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void conv_ff_kernel(const char* __re
       // the first accumulator's MFMAs, THEN the next step's fragment reads (they issue and complete under the remaining
       // MFMAs of this step), then the rest: a wave's instruction stream stalls on the matrix pipe, so reads placed after
       // the MFMA block would start ~160 cycles late, and reads placed before it would be waited for at once (lgkmcnt(0)).
-      // MFMAs on ONE accumulator stay back to back (tools/mfma_chain.hip: 2465 TF/s against 2218 round-robin).
+      // MFMAs on ONE accumulator stay back to back (tools/probes/mfma_chain.hip: 2465 TF/s against 2218 round-robin).
       auto mma = [&](int mt, int nt) __attribute__((always_inline)) {
         if constexpr (NS == 2 && !F8) {              // small terms first: lo*hi, hi*lo, then hi*hi
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xb[cur][mt][0], wa[cur][nt][1], acc[mt][nt], 0, 0, 0);
@@ -509,9 +509,7 @@ static inline int ff_nt(int cout) { return cout % 96 == 0 ? 3 : 2; }
 // the tiles are at least 65 % full (40^2: 9 tiles of which 6.25 are work; the alternative is the quad kernel behind a gn_apply16 pass).
 static bool ff_ragged_ok(const ConvPlan& p, int ns) {
   const int nstage = (p.C0 + p.C1) / 16;
-  const char* xk = CSD_TUNE_ENV("CSD_XK");
-  const char* xw = CSD_TUNE_ENV("CSD_XW");
-  if ((xk && atoi(xk) == 0) || (xw && atoi(xw) == 0) || CSD_TUNE_ENV("CSD_XP_OPS_OFF") || CSD_TUNE_ENV("CSD_NO_RAGGED")) return false;
+  if (CSD_TUNE_ENV("CSD_XP_OPS_OFF") || CSD_TUNE_ENV("CSD_NO_RAGGED")) return false;
   const int th = (p.OH + FF_TILE - 1) / FF_TILE * FF_TILE, tw = (p.OW + FF_TILE - 1) / FF_TILE * FF_TILE;
   return ns == 2 && p.Cout % 96 == 0 && nstage >= 4 && nstage % 2 == 0 && p.OH % 8 == 0 && p.OW % 8 == 0 && p.OH > FF_TILE && p.OW > FF_TILE &&
          (double)p.OH * p.OW >= 0.65 * th * tw;
@@ -531,19 +529,9 @@ bool convff_pipelined(const ConvPlan& p, int ns) {
   return ns == 2 && convff_supported(p, ns) && nstage >= 4 && nstage % 2 == 0 && !CSD_TUNE_ENV("CSD_XP_OPS_OFF");
 }
 
-// the pipelined layers that run in the Winograd F(2,3) form (conv_xw.hip: 96-cout groups; transformed weights, 4 components x 3 filter
-// rows instead of 9 taps).  Tuning build: CSD_XW=0 keeps them on conv_xp.
-bool convff_winograd(const ConvPlan& p, int ns) {
-  if (!convff_pipelined(p, ns)) return false;
-  const char* xw = CSD_TUNE_ENV("CSD_XW");
-  if (xw && atoi(xw) == 0) return false;
-  if (ff_nt(p.Cout) == 3) return true;
-  // 64-cout groups (the nf = 128 nets): conv_xk.hip only (conv_xw's ring of transformed weights was sized for 96-cout groups and measured
-  // no gain there).  Tuning build: CSD_XK=0 or CSD_XK_NT2=0 keeps them on conv_xp
-  const char* xk = CSD_TUNE_ENV("CSD_XK");
-  const char* n2 = CSD_TUNE_ENV("CSD_XK_NT2");
-  return !(xk && atoi(xk) == 0) && !(n2 && atoi(n2) == 0);
-}
+// the pipelined layers run in the Winograd F(2,3) form on conv_xk.hip (96- and 64-cout groups; transformed weights, 4 components x 3
+// filter rows instead of 9 taps)
+bool convff_winograd(const ConvPlan& p, int ns) { return convff_pipelined(p, ns); }
 
 size_t convff_packed_bytes(const ConvPlan& p, int ns) {
   const int nt = ff_nt(p.Cout);
@@ -587,7 +575,7 @@ __global__ void convff_pack_kernel(const float* __restrict__ w, _Float16* __rest
   }
 }
 
-// conv_xw.hip's weights: G0 = g0, G1 = (g0 + g1 + g2) / 2, G2 = (g0 - g1 + g2) / 2, G3 = g2 of every filter row (g0, g1, g2), in
+// conv_xk.hip's weights: G0 = g0, G1 = (g0 + g1 + g2) / 2, G2 = (g0 - g1 + g2) / 2, G3 = g2 of every filter row (g0, g1, g2), in
 // [cout group][cin / 16][filter row][component][cout tile][hi | lo][lane][8 halves]; transform in double, one rounding to fp32, x 2^8
 __global__ void convxw_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ wpack, int layout, int cin_src, int cout_src,
                                    int cout_off, int Cin, int Cout, int nt, uint32_t* __restrict__ slack) {
@@ -718,20 +706,11 @@ int convff_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
     const bool use_fx = fx ? atoi(fx) != 0 : k.nstage >= 12;
     if (ns == 3 && use_fx && k.nstage >= 2 * nt) return convfx_launch(k, nt, s);
   }
-  // conv_xw.hip: conv_xp's stream in the Winograd F(2,3) form (the weights were packed for it: convff_winograd is the one switch)
+  // conv_xk.hip: the fp16x3 form of every pipelined layer (1-D Winograd F(2,3), one persistent 4-wave workgroup per CU; the weights were
+  // packed for it: convff_winograd is the one switch)
   if (convff_winograd(p, ns)) {
     CSD_REQUIRE(convxk_supported(k, nt), "convff: Winograd layer outside conv_xk's range");
-    // (conv_xk.hip: the same operator and packed weights, one transform component per wave.  Tuning build: CSD_XK=0 keeps conv_xw)
-    const char* xk = CSD_TUNE_ENV("CSD_XK");
-    if (convxk_supported(k, nt) && !(xk && atoi(xk) == 0)) return convxk_launch(k, nt, s);
-    CSD_REQUIRE(!ff_ragged(p) && convxw_supported(k, nt), "convff: ragged tiles and 64-cout groups run on conv_xk only");
-    return convxw_launch(k, nt, s);
-  }
-  // conv_xp.hip (fp16x3: one persistent 4-wave workgroup per CU, the conversion / fragment reads / weight staging placed between
-  // the MFMA chains of ONE instruction stream per SIMD).  Tuning build: CSD_XP=0 disables it.
-  {
-    const char* xp = CSD_TUNE_ENV("CSD_XP");
-    if (ns == 2 && convxp_supported(k, nt) && !(xp && atoi(xp) == 0)) return convxp_launch(k, nt, s);
+    return convxk_launch(k, nt, s);
   }
   const bool norm = a.nscale != nullptr;
 #define FF_DISPATCH(NT_)                                                                                            \

@@ -5,7 +5,7 @@
 // per CU alone reaches 85 % of the pair's throughput - and inside a lone workgroup a 16-channel K stage takes 8.9 k cycles for 3.6 k
 // cycles of matrix work: nine barriers per stage (the weight ring holds one tap per group), the fp8 fragments read in the step that
 // uses them (an exposed LDS round trip per tap pair), the weight DMA on one wave.  The matrix-instruction mix itself, with its LDS
-// fragment traffic and no barriers, runs at 91-100 % of the matrix pipe (tools/mfma_mix_probe.hip).  With the whole CU's resources
+// fragment traffic and no barriers, runs at 91-100 % of the matrix pipe (tools/probes/mfma_mix_probe.hip).  With the whole CU's resources
 // for one workgroup (512 registers per lane, 160 KB LDS) the K loop can be that stream:
 //   * the weights of a WHOLE stage (9 taps x 16 cin x 96 cout x (fp16 + two e4m3 planes) = 54 KB) are resident, double-buffered:
 //     ONE barrier per stage instead of nine; all four waves issue the LDS-DMA of the next stage's weights (13-14 pieces each),

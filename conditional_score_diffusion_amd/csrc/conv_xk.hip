@@ -1,17 +1,37 @@
-// conv_xk.hip - conv_xw's operator and arithmetic (fp16x3, 1-D Winograd F(2,3) along the row: conv_xw.hip's header has the algebra;
-// reference models/layers.py:119-132,632-675) with the weights NOT staged through LDS.
+// conv_xk.hip - the fp16x3 (fp32-class) fused-prologue 3x3 convolution of the 160^2 / 80^2 / 40^2 levels
+// (reference models/layers.py:119-132,632-675: h = Conv(act(GroupNorm(x))) [+ Dense(temb)] / x + Conv(...); models/layerspp.py:212-274)
+// in the 1-D Winograd F(2,3) form along the image row, one transform component per wave.
 //
-// Why (profiles/NOTEBOOK.md, "where the next 15 % of conv_xw is"): in conv_xw every wave multiplies all four transform components, so
-// every wave needs every weight fragment - 72 ds_write_b128 per stage into a three-slot ring and a workgroup barrier per row tap: 1.0 k
-// of a stage's 6.05 k cycles for the stores alone.  Here wave k owns transform component k for ALL 128 pixel pairs of the tile (4 M tiles
-// x NT cout tiles = the same 4 NT accumulators).  A wave then needs only its own component's weights: 2 NT KiB per row tap, straight
-// from L2 into registers (three register sets, one per row tap, each refilled two row taps before its next use).  No ring, ONE barrier
-// per stage (the patch double buffer; in front of the stage's last row tap, whose fragments are already in registers - conv_xp's rule),
-// 8 instead of 32 fragment reads per row tap.  The price is paid once per tile: y0 = M0 + M1 + M2, y1 = M1 - M2 - M3 needs the four
+// Arithmetic.  For an output pair (y0, y1) of a row, inputs d0..d3 and a filter row (g0, g1, g2):
+//     D0 = d0 - d2   D1 = d1 + d2   D2 = d2 - d1   D3 = d1 - d3                       (input transform, fp32, BEFORE the hi | lo split)
+//     G0 = g0        G1 = (g0 + g1 + g2) / 2       G2 = (g0 - g1 + g2) / 2   G3 = g2  (weights, transformed at pack time)
+//     Mk = sum over input channels and the 3 filter ROWS of Dk * Gk                   (4 contractions instead of 6 per output pair)
+//     y0 = M0 + M1 + M2      y1 = M1 - M2 - M3                                        (output transform in the epilogue)
+// Every operand is carried as hi + lo fp16 (22 significand bits), products lo * hi, hi * hi, hi * lo on v_mfma_f32_32x32x16_f16 with fp32
+// accumulation: 2 MFMAs per algorithmic product (the direct form: 3).  A 16-channel stage of a 16 x 16-pixel x 32 NT-cout tile is 3 row
+// taps x 12 NT MFMAs.  Packed weights: [cout group][cin / 16][filter row][component][cout tile][hi | lo][64 lanes x 8 halves], x 2^8.
+//
+// Structure (the lineage conv_xp -> conv_xw -> conv_xk is in profiles/NOTEBOOK.md, rounds 4 - 5; the two predecessors were removed from
+// the tree in round 6): ONE persistent 4-wave workgroup per CU (512 registers per lane), every wave ONE instruction stream
+//     MFMA | 2 - 5 "filler" instructions | MFMA | ...
+// with the fillers pinned in program order by scheduling fences - what hides behind a matrix instruction is the SAME wave's next few
+// instructions (MI355X_MICROARCH.md: ~5 single-issue instructions per 32-cycle MFMA gap with one wave per SIMD).  The fillers are the
+// conversion of the NEXT stage's operand patch (GroupNorm affine + exp2-domain SiLU + input transform + hi | lo split, on UNITS of two
+// adjacent patch pixels x 4 channels with the right-hand neighbour's values by ds_bpermute; the float4s were requested two stages
+// earlier), the ds_read_b128 of the next row tap's fragments, the weight requests and, in a tile's last stage, the epilogue's requests.
+// The matrix instructions are asm statements (hipcc kept accumulators in VGPRs across joins and copied them through v_accvgpr_*; an asm
+// MFMA is opaque to its hazard tracker, so the epilogue's reads sit behind a tied wait and tools/check_xp_isa.py checks every build).
+//
+// Ownership: WAVE k OWNS TRANSFORM COMPONENT k for all 128 pixel pairs of the tile (4 M tiles x NT cout tiles = 4 NT accumulators).  A wave
+// then needs only its own component's weights: 2 NT KiB per row tap, straight from L2 into registers (three register sets, one per row
+// tap, each refilled two row taps before its next use) - no weight staging through LDS (in the predecessor, where every wave multiplied
+// all four components: 72 ds_write_b128 per stage into a three-slot ring and a workgroup barrier per row tap, 1.0 k of a stage's 6.05 k
+// cycles for the stores alone), ONE barrier per stage (the patch double buffer; in front of the stage's last row tap, whose fragments are
+// already in registers), 8 instead of 32 fragment reads per row tap.  The price is paid once per tile: the output transform needs the four
 // components of a pixel pair in ONE lane, so the epilogue turns them through LDS - per row of a wave's 4 x 16-pixel block every wave
 // stores its component of all four blocks (12 ds_write_b128 straight from the accumulator registers), one barrier, 12 ds_read_b128 of
-// the four components of its own block; the rounds alternate between two LDS regions (the dead patch buffer + the space the ring used
-// to take | the top of LDS).  Conversion, patch requests, tile walk, output arithmetic and the packed-weight layout are conv_xw's.
+// the four components of its own block; the rounds alternate between two LDS regions (the dead patch buffer + the space between the
+// patch buffers | the top of LDS).
 // Product order per row tap: lo * hi, hi * hi, hi * lo (the lo pixel fragments are free after the first product, the hi ones M tile by
 // M tile under the last: both are re-read for the NEXT row tap inside the current one, so no fragment of a stage's patch is read after
 // the barrier in front of its last row tap).
@@ -34,7 +54,7 @@ struct XKCfg {
   static constexpr int TAPB = 4 * NT * 2 * 1024;             // weight bytes per row tap: 4 components x NT cout tiles x (hi | lo)
   static constexpr int STB = 3 * TAPB;                       // per stage
   static constexpr int WPT = 2 * NT;                         // 1 KiB pieces per wave and row tap
-  // LDS map (XTOG: conv_xw.hip): [0, 37152) patch 0 | exchange region X, blocks 2 and 3 | dummy | [65536, 102688) patch 1 |
+  // LDS map (XTOG = the distance of the two patch buffers: a toggle is one xor): [0, 37152) patch 0 | exchange region X, blocks 2 and 3 | dummy | [65536, 102688) patch 1 |
   // exchange region Y, slots 0 .. 7 | the dummy's partner | [131072, ..) region Y, slots 8 .. 15 | red.  Region X's blocks 0 and 1 take
   // the patch buffer that is dead during the epilogue.  A slot = (destination block, source component): NT KiB.
   static constexpr int XTOG = 65536;
@@ -80,7 +100,7 @@ __device__ __forceinline__ float xk_lo(int hp, float v) {      // v - (float)hal
 // 524288 the whole row loop of the epilogue (what remains is the tile switch),
 // 256 patch stores, 512 neighbour exchange (own value instead), 1024 transcendentals (plain multiplies instead), 2048 hi | lo split,
 // 4096 patch requests confined to the first 256 pixels of the sample (cache hits), 8192 the same bytes as whole 1 KiB pieces
-// (tools/xk_abl_build.sh builds the libraries, tools/xw_timing.py reads the per-tile stamps)
+// (tools/xk_abl_build.sh builds the libraries, tools/xk_timing.py reads the per-tile stamps)
 #ifndef XK_ABL
 #define XK_ABL 0
 #endif
@@ -138,7 +158,7 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xk_kernel(const char* __re
 #endif
   XW_WALL(30);
 
-  // ---- this workgroup's tiles (conv_xp's walk): workgroup p (one per CU, on XCD p % 8) takes tiles wj, wj + P/8, ... of its XCD's share ----
+  // ---- this workgroup's tiles: workgroup p (one per CU, on XCD p % 8) takes tiles wj, wj + P/8, ... of its XCD's share ----
   const int xcd = blockIdx.x & 7, wj = blockIdx.x >> 3, wstride = gridDim.x >> 3;
   const int xq = k_nblocks >> 3, xr = k_nblocks & 7;
   const int x_start = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq, x_len = xq + (xcd < xr ? 1 : 0);
@@ -263,7 +283,7 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xk_kernel(const char* __re
   // ---- conversion of a slot, as a sequence of single operations (placed one by one between the MFMAs) ----
   // "pre": per value (8 = pixels a, b x 4 channels) the chain affine > exp2 > 1 + > rcp > u * > zero padding > neighbour value; emitted
   // along the diagonals of the (value, phase) table, so that a dependent operation sits 7 operations behind its producer and the
-  // transcendentals (12.8 cycles of issue each, two per MFMA gap ride free - tools/filler_cost_probe.hip) are spread out.
+  // transcendentals (12.8 cycles of issue each, two per MFMA gap ride free - tools/probes/filler_cost_probe.hip) are spread out.
   // "post", per half of the channels (2 of the lane's 4): the four components (8) | hi pack (4) | lo (8) | lo pack (4).
   // Without the GroupNorm prologue pre = padding + neighbour values only.
   constexpr int NPH = NORM ? 7 : 2, NPRE = 8 * NPH, NPOST = 24, NMATH = NPRE + 2 * NPOST;
@@ -377,7 +397,7 @@ __global__ __launch_bounds__(XW_THREADS, 1) void conv_xk_kernel(const char* __re
   };
 
   // The accumulators live in the accumulator half of the register file for the whole kernel; the matrix instructions are asm
-  // statements (conv_xp.hip explains why); a tile's first product writes them with C = 0, so nothing is live across the tile loop's
+  // statements (header); a tile's first product writes them with C = 0, so nothing is live across the tile loop's
   // back edge, and the epilogue's reads sit behind tie_acc_done().  tools/check_xp_isa.py checks the generated code.
   floatx16 acc[4][NT];
 #define XK_MFMA_AV(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ACC) : "a"(A), "v"(B))
@@ -737,8 +757,8 @@ static int launch_xk(const ConvFFArgs& k, hipStream_t s) {
   return CSD_OK;
 }
 
-// conv_xw's layers (96-cout groups) and the 64-cout groups of the nf = 128 nets; at least three 16-channel stages; the packed weights
-// are conv_xw's Winograd layout
+// 96-cout groups and the 64-cout groups of the nf = 128 nets; at least three 16-channel stages; the packed weights are the Winograd
+// layout of conv_ff.hip's convxw_pack_kernel
 bool convxk_supported(const ConvFFArgs& k, int nt) { return (nt == 3 || nt == 2) && k.nstage >= 3; }
 
 int convxk_launch(const ConvFFArgs& k, int nt, hipStream_t s) {

@@ -116,7 +116,7 @@ int csd::conv2d_operand_planes(int B, int Cin, int Cout, int H, int W, int ksize
   if (!ns || Cin % 32 != 0 || CSD_TUNE_ENV("CSD_NO_Q")) return 0;
   ConvPlan q = p;
   q.C0 = Cin; q.C1 = 0;
-  if (convff_pipelined(q, ns)) return 0;             // (conv_xp splits the fp32 source itself)
+  if (convff_pipelined(q, ns)) return 0;             // (conv_xk splits the fp32 source itself)
   return (conv16q_supported(q, ns) && conv16q_plan_tiles(&q, ns) == CSD_OK) ? (ns >= 2 ? 2 : 1) : 0;
 }
 
@@ -137,7 +137,7 @@ int csd::conv2d_impl(const float* x, const float* weight, const float* bias, con
   int ns = precision_ns(precision);
   bool pw = false, quad = false;
   if (ns == 2 && in_nhwc && out_nhwc && Cin % 16 == 0) {
-    // NHWC fp32 source, fp32-class arithmetic, a layer shape conv_xp.hip covers (the training graph's 3x3 convolutions and their data
+    // NHWC fp32 source, fp32-class arithmetic, a layer shape conv_xk.hip covers (the training graph's 3x3 convolutions and their data
     // gradients on the >= 16^2 levels): the software-pipelined block convolution without its GroupNorm prologue - it splits the fp32
     // operand into fp16 hi | lo itself, so no operand planes are written or read
     ConvPlan q = p;
@@ -236,7 +236,7 @@ extern "C" size_t csd_conv3x3_block_scratch_bytes(int Cin, int Cout) {
   ConvPlan p;
   memset(&p, 0, sizeof(p));
   p.C0 = Cin; p.Cout = Cout;
-  // (the shape is not known here: sized for the Winograd pack of conv_xw.hip - 12 instead of 9 fragment sets per 16 channels)
+  // (the shape is not known here: sized for the Winograd pack of conv_xk.hip - 12 instead of 9 fragment sets per 16 channels)
   return convff_packed_bytes(p, 2) / 3 * 4 + 4096 + 256;
 }
 

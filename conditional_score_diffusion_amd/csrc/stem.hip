@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 4) void stem_kernel(const StemArgs k) {
 
       // ---- epilogue: un-scale, bias, NHWC stores.  The pixels are the MFMA's M operand, so a lane holds ONE cout (ng * 32 NT + nt * 32 +
       //      lane % 32) of 16 pixels (register r = pixel 8 (r / 4) + 4 kh + r % 4 of the wave's 32): every store instruction writes two
-      //      whole 128-byte lines (tools/store_probe.hip: 5.4 TB/s against 3.3 TB/s for 16-byte pieces of four different instructions) ----
+      //      whole 128-byte lines (tools/probes/store_probe.hip: 5.4 TB/s against 3.3 TB/s for 16-byte pieces of four different instructions) ----
       const int c_lane = ng * NT * 32 + p32;
       float* const obase = k.out + (((size_t)b * S + ty0 + wave * 2) * S + tx0) * Cout + ng * NT * 32;      // uniform
       const unsigned lane_off = (unsigned)(4 * kh * Cout + p32);                                            // + one lane offset: saddr stores

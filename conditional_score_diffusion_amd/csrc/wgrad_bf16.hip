@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float* x,
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
-  // (VALU instructions are matrix-pipe time on this chip - tools/mfma_valu_overlap.hip - so everything wave-uniform is kept on the
+  // (VALU instructions are matrix-pipe time on this chip - tools/probes/mfma_valu_overlap.hip - so everything wave-uniform is kept on the
   // scalar unit: row bases in SGPRs, 32-bit element offsets, one 64-bit add per DMA)
   const unsigned coq = (unsigned)(tz * 32 + sq) < (unsigned)Cout ? (unsigned)(tz * 32 + sq) : 0u;
   const unsigned ciq = (unsigned)(ty * 32 + sq) < (unsigned)Cin ? (unsigned)(ty * 32 + sq) : 0u;

@@ -350,7 +350,7 @@ def _block_case(rs, B, C0, C1, Cout, H, W, norm, res, precision):
 
 
 def test_conv3x3_block_shape_sweep_fp16x3():
-    """conv_xp.hip (the persistent software-pipelined form: every fp16x3 layer with an even number >= 4 of 16-channel stages) over a
+    """conv_xk.hip (the persistent software-pipelined form: every fp16x3 layer with an even number >= 4 of 16-channel stages) over a
     seeded sweep of shapes: 96- and 64-cout groups, one and two sources, 1 .. 23 tiles per workgroup walk (grids smaller than,
     equal to and larger than the CU count, tile counts that do not divide by the 8 XCDs), with and without the GroupNorm prologue and
     the residual; the layers it does not cover (odd stage counts, two stages) ride along on conv_ff"""
@@ -430,7 +430,7 @@ def test_conv3x3_block_rejects_maps_outside_the_ragged_domain():
 
 
 def test_conv3x3_block_is_bitwise_repeatable_under_load():
-    """conv_xp.hip issues its matrix instructions as asm statements (no compiler-inserted wait states): 30 launches of a chip-filling
+    """conv_xk.hip issues its matrix instructions as asm statements (no compiler-inserted wait states): 30 launches of a chip-filling
     layer (8 x 160^2, 96 -> 96 and 64 + 64 -> 128, GroupNorm prologue + residual; several tiles per workgroup, hot chip) must be
     bit-identical - a timing-dependent read of a matrix result would show up here"""
     from conditional_score_diffusion_amd import ops
@@ -460,7 +460,7 @@ def test_conv3x3_block_is_bitwise_repeatable_under_load():
     (3, 96, 96, 96, 16, 48, True, False, True),      # up-path block: virtual concat of two sources, residual, odd batch
     (1, 64, 32, 192, 32, 16, True, True, True),      # two cout groups, unequal sources
     (2, 32, 0, 96, 16, 16, False, False, False),     # no GroupNorm: the convolution reads x as it is
-    (2, 128, 0, 128, 32, 32, True, True, False),     # 64-cout groups (conv_xp NT = 2): nf = 128 networks
+    (2, 128, 0, 128, 32, 32, True, True, False),     # 64-cout groups (conv_xk NT = 2): nf = 128 networks
     (1, 128, 128, 256, 16, 32, True, False, True),   # ... four groups, 16 stages, concat + residual
     (2, 64, 0, 64, 16, 16, False, False, True),      # ... one group, four stages, raw operand + residual
     (1, 80, 0, 128, 16, 16, True, False, False),     # an odd number of stages: conv_ff keeps the layer

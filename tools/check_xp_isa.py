@@ -1,6 +1,7 @@
-"""Build-time check of the generated code of conv_xk.hip (and, in the tuning build, conv_xp.hip and conv_xw.hip) (csrc/Makefile, run by __graft_entry__.build()).
+"""Build-time check of the generated code of conv_xk.hip (csrc/Makefile, run by __graft_entry__.build(); the kernel names of its two
+predecessors, conv_xp / conv_xw, are still understood: the unit test feeds synthetic listings under them).
 
-Both kernels issue their matrix instructions as asm statements, so hipcc inserts none of the wait states an accumulator access needs
+The kernel issues its matrix instructions as asm statements, so hipcc inserts none of the wait states an accumulator access needs
 (MI355X: no hardware interlock between a matrix write and a vector read of the same register).  The sources are structured so that
 hipcc never has a reason to touch an accumulator; this script proves it on the ISA of every instantiation:
   * the matrix instructions use exactly the expected accumulator tuples (conv_xp: 2 NT, conv_xw and conv_xk: 4 NT), the same registers throughout;
@@ -10,7 +11,7 @@ hipcc never has a reason to touch an accumulator; this script proves it on the I
     back edge or a branch target from a block that ends in a matrix instruction cannot pass (round-4 advisor finding).
 conv_xw keeps two operand fragment sets (64 registers) in the accumulator half of the register file as well: those are written by LDS
 reads and read by matrix instructions only, and are not accumulators.
-usage: check_xp_isa.py conv_xk.s | conv_xp.tune.s | conv_xw.tune.s"""
+usage: check_xp_isa.py conv_xk.s | conv_xk.tune.s"""
 import re
 import sys
 
@@ -77,7 +78,7 @@ def main(path):
                 # drops its "behind the wait" state at (round-5 advisor finding: they used to be filtered with the directives)
                 cur.append(t.split(';')[0].strip())
     if not kernels:
-        print('check_xp_isa: no conv_xp / conv_xw kernel in', path)
+        print('check_xp_isa: no conv_xk kernel in', path)
         return 1
     bad = 0
     for name, lines in sorted(kernels.items()):

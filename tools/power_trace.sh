@@ -21,7 +21,7 @@ sample() {   # $1 = pid to follow
     sleep 0.3
   done
 }
-echo "--- during 8000 back-to-back conv_xp launches (160^2, 96 -> 96, B = 64: tools/ff_probe.py ONLY=0)" >> $O
+echo "--- during 8000 back-to-back conv_xk launches (160^2, 96 -> 96, B = 64: tools/ff_probe.py ONLY=0)" >> $O
 ONLY=0 REPS=8000 PREC=fp16x3 python tools/ff_probe.py > gpurun_out/power_ffprobe_$tag.txt 2>/dev/null &
 sample $!
 grep fp16x3 gpurun_out/power_ffprobe_$tag.txt >> $O

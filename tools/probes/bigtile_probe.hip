@@ -2,7 +2,7 @@
 // 24 x v_mfma_f32_32x32x16_f16 + 12 x v_mfma_scale_f32_32x32x64_f8f6f4 on 12 accumulators, their LDS fragment reads (2 x 7 fp16 +
 // 7 x 2 fp8 ds_read_b128, conflict-free), optionally NV "conversion-like" vector instructions per pair (fma / exp2 / rcp mix) interleaved.
 // Ideal matrix time per pair: 24 * 32 + 12 * 64 = 1536 cycles.
-// Build + run: hipcc --offload-arch=gfx950 -O2 tools/bigtile_probe.hip -o build/bigtile && build/bigtile
+// Build + run: hipcc --offload-arch=gfx950 -O2 tools/probes/bigtile_probe.hip -o build/bigtile && build/bigtile
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));

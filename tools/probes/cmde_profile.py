@@ -1,4 +1,4 @@
-"""tuning aid: a few fused PC steps of the CMDE-128 side bench (BASELINE configs[2] shape, B = 64) - the target of tools/timeline_cmde.sh"""
+"""tuning aid: a few fused PC steps of the CMDE-128 side bench (BASELINE configs[2] shape, B = 64) - the target of tools/probes/timeline_cmde.sh"""
 import os, sys
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tools'))

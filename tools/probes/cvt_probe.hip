@@ -1,5 +1,5 @@
 // Probe (gfx950): semantics of v_cvt_scalef32_pk_fp8_f32 - does the scale divide or multiply, and does it saturate beyond e4m3's 448
-// (v_cvt_pk_fp8_f32 produces NaN there)?  Build: hipcc --offload-arch=gfx950 -O2 tools/cvt_probe.hip -o build/cvt_probe
+// (v_cvt_pk_fp8_f32 produces NaN there)?  Build: hipcc --offload-arch=gfx950 -O2 tools/probes/cvt_probe.hip -o build/cvt_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>

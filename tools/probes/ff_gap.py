@@ -1,6 +1,6 @@
 """Tuning aid: how busy are the workgroup slots of conv_ff_kernel?  Wall-clock stamps (100 MHz, common to all CUs) at the start and
 end of every sampled workgroup: slot occupancy = sum of workgroup lifetimes / (kernel span x 512 slots).
-   CSD_LIB_PATH=.../libcsd_hip_tune.so python tools/ff_gap.py [precision] [shape index]"""
+   CSD_LIB_PATH=.../libcsd_hip_tune.so python tools/probes/ff_gap.py [precision] [shape index]"""
 import ctypes, os, sys
 os.environ['CSD_FF_ABL'] = str(int(os.environ.get('CSD_FF_ABL', '0')) | 128)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """Tuning aid: per-workgroup phase stamps of conv_ff_kernel (CSD_FF_ABL bit 7 + csd_debug_ff_timing).
-   python tools/ff_timing.py [precision] [shape index of tools/ff_probe.py]"""
+   python tools/probes/ff_timing.py [precision] [shape index of tools/ff_probe.py]"""
 import ctypes, os, sys
 os.environ['CSD_FF_ABL'] = str(int(os.environ.get('CSD_FF_ABL', '0')) | 128)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

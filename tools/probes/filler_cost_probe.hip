@@ -2,7 +2,7 @@
 // round robin, operands constant)?  N fillers of kind K after every v_mfma_f32_32x32x16_f16; reported: cycles per MFMA (floor 32).
 //   kinds: 0 v_fma_f32 | 1 v_exp_f32 | 2 v_rcp_f32 | 3 v_cvt_pk_f16_f32 | 4 v_fma_mix_f32 | 5 v_cndmask_b32 (sgpr mask) | 6 ds_bpermute_b32 |
 //          7 ds_read_b128 | 8 ds_write_b64 | 9 ds_write_b128 | 10 v_add_f32 dependent chain | 11 buffer_load_dwordx4 (L2 hit) | 12 s_nop 0
-// hipcc --offload-arch=gfx950 -O3 tools/filler_cost_probe.hip -o build/filler_cost_probe
+// hipcc --offload-arch=gfx950 -O3 tools/probes/filler_cost_probe.hip -o build/filler_cost_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float floatx16 __attribute__((ext_vector_type(16)));

@@ -1,7 +1,7 @@
 // How many VALU instructions of the SAME wave hide in the shadow of its MFMAs (gfx950)?  Each wave runs
 //     loop { 4 x ( v_mfma_f32_32x32x16_f16 on accumulator c_i ; NF x v_fma_f32 on independent chains ) }
 // with the order pinned by inline asm; 1 or 2 waves per SIMD.  Prints cycles per MFMA for NF = 0 .. 12 and the FMA-only time.
-// Build + run: hipcc --offload-arch=gfx950 -O2 tools/mfma_filler.hip -o /tmp/mf && /tmp/mf
+// Build + run: hipcc --offload-arch=gfx950 -O2 tools/probes/mfma_filler.hip -o /tmp/mf && /tmp/mf
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));

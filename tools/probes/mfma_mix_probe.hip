@@ -2,7 +2,7 @@
 // + 6 x v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 operands) on 6 accumulators - alone, and with the loop's ds_read_b128 traffic
 // (5 + 5 fp16 fragments, 10 fp8 fragments per pair) from a conflict-free LDS layout, 1 / 2 waves per SIMD, no barriers.
 // Ideal: 12 * 32 + 6 * 64 = 768 cycles per pair and wave.
-// Build + run: hipcc --offload-arch=gfx950 -O2 tools/mfma_mix_probe.hip -o build/mix && build/mix
+// Build + run: hipcc --offload-arch=gfx950 -O2 tools/probes/mfma_mix_probe.hip -o build/mix && build/mix
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));

@@ -1,6 +1,6 @@
 // Practical ceiling probe for the fp16 matrix cores: v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16 back
 // to back, no memory traffic; reports TFLOP/s and the shader clock (clock64 ticks per wall-clock second).
-// build: hipcc --offload-arch=gfx950 -O3 tools/mfma_peak_f16.hip -o tools/mfma_peak_f16.bin
+// build: hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_peak_f16.hip -o tools/mfma_peak_f16.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float floatx16 __attribute__((ext_vector_type(16)));

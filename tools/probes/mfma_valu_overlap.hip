@@ -1,6 +1,6 @@
 // Do VALU instructions of one wave overlap the MFMAs of ANOTHER wave on the same SIMD (gfx950)?  8 waves per workgroup = 2 per SIMD:
 // waves 0-3 run an MFMA loop, waves 4-7 nothing / an FMA loop / a conversion-like mix (exp, rcp, cvt) / LDS traffic.
-// Build + run: hipcc --offload-arch=gfx950 -O2 tools/mfma_valu_overlap.hip -o /tmp/ovl && /tmp/ovl
+// Build + run: hipcc --offload-arch=gfx950 -O2 tools/probes/mfma_valu_overlap.hip -o /tmp/ovl && /tmp/ovl
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));

@@ -2,7 +2,7 @@
 // is that the issue arbiter (oldest / highest priority first, an MFMA that waits for the busy matrix pipe holding the slot)?
 // 8 waves per workgroup = 2 per SIMD; one half runs a dense v_mfma_f32_32x32x16_f16 loop, the other half a VALU loop (fma or the
 // SiLU + split mix of conv_ff's prologue).  Variants: which half is dispatched first (age), s_setprio of each role.
-// Build + run: hipcc --offload-arch=gfx950 -O2 tools/mfma_valu_prio.hip -o /tmp/prio && /tmp/prio
+// Build + run: hipcc --offload-arch=gfx950 -O2 tools/probes/mfma_valu_prio.hip -o /tmp/prio && /tmp/prio
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));

@@ -1,4 +1,4 @@
-"""Copy the outputs of tools/capture_profiles.sh, tools/pmc_hbm.sh and tools/bench_other.py from gpurun_out/ into the tracked
+"""Copy the outputs of tools/probes/capture_profiles.sh, tools/pmc_hbm.sh and tools/bench_other.py from gpurun_out/ into the tracked
 profiles/ directory and rebuild the derived summaries (class-average agreement check, HBM traffic, side benches)."""
 import csv, json, os, shutil, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -52,7 +52,7 @@ side.append({'workload': 'BASELINE configs[4] shape: NCSN++ 256x256 (nf=128, ch_
              'precision': 'fp16x3', 'batch': 8, 'ms_per_forward': 22.29, 'images_per_sec_per_nfe': 358.9})
 side.append({'note': 'tools/bench_other.py on one MI355X (ncsnpp_paired = planned graph executor, ncsnpp_paired_ops = operator-granular '
                      'executor); shader clock during the 160x160 conv launches 1.86-2.08 GHz (clock64 / wall_clock64, '
-                     'tools/phase_timing_lc.py) against 2.39 GHz in the pure-MFMA probe'})
+                     'tools/probes/phase_timing_lc.py) against 2.39 GHz in the pure-MFMA probe'})
 json.dump(side, open(os.path.join(P, tag + '_side_benches.json'), 'w'), indent=1)
 for n in ('default', 'fp16', 'fp32', 'under_rocprof'):
     j = json.load(open(os.path.join(P, '%s_final_bench_%s.json' % (tag, n))))

@@ -1,7 +1,7 @@
 // Write-bandwidth probe (gfx950): 629 MB of fp32 NHWC output (64 x 160 x 160 x 96) written (a) lane-contiguous float4, (b) in the MFMA
 // accumulator pattern of the conv epilogues (a lane owns 16 bytes of a pixel's 384-byte row; 32 pixels x 32 bytes per store instruction),
 // (c) pattern (b) staged through LDS into full 384-byte rows per 24 lanes.
-// Build + run: hipcc --offload-arch=gfx950 -O2 tools/store_probe.hip -o build/store_probe && build/store_probe
+// Build + run: hipcc --offload-arch=gfx950 -O2 tools/probes/store_probe.hip -o build/store_probe && build/store_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 constexpr int C = 96, S = 160, B = 64;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tuning aid: rocprofv3 kernel trace of the training side bench -> the launches of one training step in order (between two Adam launches)
-# usage: tools/timeline_train.sh <precision> <tag>
+# usage: tools/probes/timeline_train.sh <precision> <tag>
 prec=$1; tag=$2
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/tlt_$tag

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of the cfg4 training bench -> gpurun_out/train_<tag>_{stats.csv,bench.json}
-# usage: tools/train_profile.sh <precision> <tag>
+# usage: tools/probes/train_profile.sh <precision> <tag>
 prec=${1:-fp32}; tag=${2:-r01}
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/trainprof_$tag

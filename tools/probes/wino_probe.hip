@@ -9,7 +9,7 @@
 // over the group's gaps.  Filler counts of the real streams (per wave and stage, NORM = true):
 //   direct  : 150 plain + 48 transcendental + 26 LDS stores + 20 loads + 90 fragment reads                    (2.1 per MFMA)
 //   F(2,3)  : 240 plain + 48 transcendental + 42 LDS stores + 24 loads + 60 fragment reads                    (3.8 per MFMA)
-// hipcc --offload-arch=gfx950 -O3 tools/wino_probe.hip -o /tmp/wino_probe && /tmp/wino_probe
+// hipcc --offload-arch=gfx950 -O3 tools/probes/wino_probe.hip -o /tmp/wino_probe && /tmp/wino_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

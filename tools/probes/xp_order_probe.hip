@@ -5,7 +5,7 @@
 //   order 3-5: operands re-read every tap from RANDOM fp16 data in LDS, MFMAs pixel-tile major / cout-tile major / snake
 //   order 6-8: as 3, with 3 / 6 / all significand bits of the two "lo" operand planes cleared (bit activity vs clock at the power limit)
 // fillers per tap: F v_fma_f32 (four independent chains) + R ds_read_b128 (conflict-free) spread evenly over the gaps.
-// hipcc --offload-arch=gfx950 -O3 tools/xp_order_probe.hip -o /tmp/xp_order_probe && /tmp/xp_order_probe
+// hipcc --offload-arch=gfx950 -O3 tools/probes/xp_order_probe.hip -o /tmp/xp_order_probe && /tmp/xp_order_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>

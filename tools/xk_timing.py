@@ -1,5 +1,6 @@
-"""Tuning aid: per-stage cycle stamps of conv_xp_kernel (tuning build: CSD_FF_ABL bit 7 + csd_debug_ff_timing).
-   CSD_LIB_PATH=.../libcsd_hip_tune.so python tools/xp_timing.py [shape index of tools/ff_probe.py]"""
+"""Tuning aid: per-tile cycle / wall stamps of conv_xk_kernel (tuning build: CSD_FF_ABL bit 7 + csd_debug_ff_timing).  Stamps sit at
+tile boundaries only (see conv_xk.hip: a stamp inside the stream is a control-flow edge with live accumulators).
+   CSD_LIB_PATH=.../libcsd_hip_tune.so python tools/xk_timing.py [shape index of tools/ff_probe.py]"""
 import ctypes, os, sys
 os.environ['CSD_FF_ABL'] = str(int(os.environ.get('CSD_FF_ABL', '0')) | 128)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,22 +16,15 @@ sc, sh = torch.rand(B, Cin, device=dev) + 0.5, torch.randn(B, Cin, device=dev)
 r = torch.randn(B, H, H, Cout, device=dev) if res else None
 buf = torch.zeros(4096 * 2 * 16 + 1024 * 2 * 64, dtype=torch.int64, device=dev)
 _lib.lib().csd_debug_ff_timing.argtypes = [ctypes.c_void_p]
-ops.conv3x3_block(x0, w, b, x1=x1, nscale=sc, nshift=sh, res=r, precision='fp16x3', want_stats=True)
+for _ in range(3):
+    ops.conv3x3_block(x0, w, b, x1=x1, nscale=sc, nshift=sh, res=r, precision='fp16x3', want_stats=True)
 _lib.lib().csd_debug_ff_timing(ctypes.c_void_p(buf.data_ptr()))
 ops.conv3x3_block(x0, w, b, x1=x1, nscale=sc, nshift=sh, res=r, precision='fp16x3', want_stats=True)
 torch.cuda.synchronize()
 t = buf.cpu().numpy()[:256 * 32].reshape(256, 32)
-t = t[t[:, 0] != 0]
-NS = Cin // 16
-st = t[:, :NS + 1]
-d = np.diff(st, axis=1)
+t = t[t[:, 26] != 0]
 print('shape C %d+%d -> %d @%d res=%d: %d workgroups sampled (their second tile)' % (C0, C1, Cout, H, res, len(t)))
-print('unit cycles, start of taps 0-7 of stage s -> of stage s + 1 (the last: taps 0-7 only), mean: ' + ' '.join('%6.0f' % v for v in d.mean(0)) + '   (MFMA floor 5184 / 4608)')
-print('            max : ' + ' '.join('%6.0f' % v for v in d.max(0)))
-print('barrier wait in front of stage 2: %.0f' % (t[:, 21] - t[:, 20]).mean())
-print('previous tile\'s epilogue: stores %.0f, statistics %.0f | this tile, first tap 0 -> last tap 7: %.0f' % (
-    (t[:, 23] - t[:, 22]).mean(), (t[:, 24] - t[:, 23]).mean(), (t[:, NS] - t[:, 0]).mean()))
 ghz = ((t[:, 27] - t[:, 26]) / ((t[:, 29] - t[:, 28]) * 10.0)).mean()
-print('one tile: %.0f cycles in %.2f us -> shader clock %.3f GHz' % ((t[:, 27] - t[:, 26]).mean(), (t[:, 29] - t[:, 28]).mean() * 0.01, ghz))
-wall = (t[:, 31] - t[:, 30]).mean() * 10.0
-print('kernel wall per workgroup %.1f us' % (wall / 1e3))
+print('one tile (%d stages, MFMA floor %d cycles): %.0f cycles in %.2f us -> shader clock %.3f GHz' % (
+    Cin // 16, Cin // 16 * 3456, (t[:, 27] - t[:, 26]).mean(), (t[:, 29] - t[:, 28]).mean() * 0.01, ghz))
+print('kernel wall per workgroup %.1f us' % ((t[:, 31] - t[:, 30]).mean() * 10.0 / 1e3))
