@@ -180,6 +180,7 @@ int conv16q_pack_weight(const ConvPlan& p, int ns, const float* w, int layout, i
 int conv16q_plan_tiles(ConvPlan* p, int ns);
 // phase-decomposed Upsample on the quad schedule (ConvPlan.up == 2; conv_f16_q.hip)
 bool conv16q_up4_supported(const ConvPlan& p, int ns);
+bool conv16q_up4_stats_ok(const ConvPlan& p);      // (after conv16q_plan_tiles) its epilogue statistics are a function of the sample alone
 size_t conv16q_up4_packed_bytes(const ConvPlan& p, int ns);
 int conv16q_pack_weight_up4(const ConvPlan& p, int ns, const float* w, void* wpack, hipStream_t s);
 // raw: src0 is the fp32 NHWC source itself (ns = 2, a layer without a GroupNorm in front: the kernel's staging does the hi | lo split)

@@ -16,6 +16,7 @@
 // the arithmetic (NS = 2: hi/lo split operands, 3 MFMAs per product; NS = 1: plain fp16) are those of
 // conv_f16_kernel.h.  Weights: [Cout/96][N half][Cin/32][tap][16-cout tile 0..2][plane][lane][8 halves].
 #include <stdlib.h>
+#include <type_traits>
 
 #include "conv_f16_kernel.h"
 
@@ -41,6 +42,15 @@ __device__ __forceinline__ double dpp_row16_sum(double v) {
   CSD_DPP_STEP(0x124)     // row_ror:4
   CSD_DPP_STEP(0x128)     // row_ror:8
 #undef CSD_DPP_STEP
+  return v;
+}
+__device__ __forceinline__ float dpp_row16_sum(float v) {
+#define CSD_DPP_STEP_F(CTRL) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+  CSD_DPP_STEP_F(0xB1)
+  CSD_DPP_STEP_F(0x4E)
+  CSD_DPP_STEP_F(0x124)
+  CSD_DPP_STEP_F(0x128)
+#undef CSD_DPP_STEP_F
   return v;
 }
 
@@ -428,11 +438,15 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
       }
     }
   }
-  double st_s[NTQ][4], st_q[NTQ][4];              // GroupNorm partials of this lane's 12 columns over its MQ pixels
+  // GroupNorm partials of this lane's 12 columns over its MQ pixels.  The phase-decomposed Upsample (UP4) keeps them in fp32: a partial
+  // covers 16 MQ pixels and is widened to fp64 where it is stored - the finalize kernel folds the (tile, phase) partials in fp64 as
+  // ever.  (In fp64 the statistics cost that kernel more than the streaming pass over its output they replace: round 5.)
+  using st_t = typename std::conditional<UP4, float, double>::type;
+  st_t st_s[NTQ][4], st_q[NTQ][4];
 #pragma unroll
   for (int t = 0; t < NTQ; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { st_s[t][i] = 0.0; st_q[t][i] = 0.0; }
+    for (int i = 0; i < 4; ++i) { st_s[t][i] = 0; st_q[t][i] = 0; }
 #pragma unroll
   for (int j = 0; j < MQ; ++j)
 #pragma unroll
@@ -444,7 +458,7 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
       for (int i = 0; i < 4; ++i) {
         // (acc*2^-8 + bias) + temb + residual: same association as the reference's h + Dense(temb), x + h
         o4[i] = ((acc[j][t][i] * wunscale + b4[i]) + a4[i]) * k.a.out_scale;
-        const double dv = oidx[j] >= 0 ? (double)o4[i] : 0.0;
+        const st_t dv = oidx[j] >= 0 ? (st_t)o4[i] : (st_t)0;
         st_s[t][i] += dv;
         st_q[t][i] = fma(dv, dv, st_q[t][i]);
       }
@@ -460,12 +474,9 @@ __global__ __launch_bounds__(C16Q_THREADS, 2) void conv_f16_q_kernel(const void*
     for (int t = 0; t < NTQ; ++t)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const double s = dpp_row16_sum(st_s[t][i]), q = dpp_row16_sum(st_q[t][i]);
-        if (l16 == 0) {
-          double* dst = k.a.stats + (((size_t)tile4 * 2 + mi) * k.Cout + c_base + t * 16 + i) * 2;
-          dst[0] = s;
-          dst[1] = q;
-        }
+        const double s = (double)dpp_row16_sum(st_s[t][i]), q = (double)dpp_row16_sum(st_q[t][i]);
+        if (l16 == 0)      // (one 16-byte store per pair)
+          *reinterpret_cast<double2*>(k.a.stats + (((size_t)tile4 * 2 + mi) * k.Cout + c_base + t * 16 + i) * 2) = make_double2(s, q);
       }
   }
   Q_TSTAMP();
@@ -479,6 +490,10 @@ bool conv16q_supported(const ConvPlan& p, int ns) {
          p.C1 == 0 && p.C0 % 32 == 0 &&
          (p.qnt == 1 ? (p.Cout % 32 == 0 && ns >= 2 && p.stride == 1 && p.up == 0) : (p.Cout % 96 == 0 || (p.Cout % 128 == 0 && ns != 3)));
 }
+
+// the phase-decomposed Upsample layers whose tile shape does not depend on the batch (conv16q_plan_tiles): their epilogue statistics
+// are a function of the sample alone
+bool conv16q_up4_stats_ok(const ConvPlan& p) { return p.up == 2 && (long)p.IH * p.IW >= 1600 && p.IH % p.TH == 0; }
 
 // ConvPlan.up == 2 selects the phase-decomposed Upsample (UP4): same source / output sizes as up == 1
 bool conv16q_up4_supported(const ConvPlan& p, int ns) {
@@ -653,6 +668,10 @@ int conv16q_plan_tiles(ConvPlan* p, int ns) {
     // CU.  128-pixel tiles halve that traffic as soon as they still put a workgroup on every CU: measured at the 20^2 level (B = 64:
     // 400 instead of 800 workgroups) -0.6 ms per PC step; at 10^2 (162 workgroups) the 64-pixel tiles stay ahead.)
     static const long min_wg = CSD_TUNE_ENV("CSD_Q_MINWG") ? atol(CSD_TUNE_ENV("CSD_Q_MINWG")) : 300;
+    // (a phase-decomposed Upsample of a source of >= 40^2 pixels keeps the tile it gets at a large batch WHATEVER the batch: its epilogue
+    // leaves the next GroupNorm's statistics per (tile, M half, phase) - unet.hip reads up_stats_ok() - and a sample's bits must not
+    // depend on the batch it is run in.  At B = 1 such a layer then puts 120 - 200 workgroups on the chip instead of 240 - 400.)
+    if (up4 && (long)OHt * OWt >= 1600) break;
     if (nwg >= min_wg || mq == 2) break;
   }
   CSD_REQUIRE(best_tw > 0, "conv16q: no feasible tile for OW=%d", p->OW);

@@ -1071,8 +1071,9 @@ struct Builder {
     const int oh_tiled = o.cp.up == 2 ? o.cp.IH : o.cp.OH;         // (the phase form tiles the SOURCE image, four workgroups per tile)
     // (pc.ff: the fused-prologue kernels tile every sample on its own - ragged tiles, where they run at all, mask their statistics)
     if (!pc.pw && !external_nchw && o.cp.taps == 9 && (pc.ff || oh_tiled % o.cp.TH == 0) && !CSD_TUNE_ENV("CSD_NO_FUSED_STATS") &&
-        o.cp.up != 2) {     // (phase-decomposed Upsample: its fp64 epilogue statistics cost more than the streaming pass over the output,
-                            // and their tile grouping would make a sample's bits depend on the batch size it is run in)
+        (o.cp.up != 2 || (conv16q_up4_stats_ok(o.cp) && !CSD_TUNE_ENV("CSD_NO_UP4_STATS")))) {
+      // (phase-decomposed Upsample: fp32 partials per (tile, M half, phase) - in fp64 they cost the kernel more than the streaming pass
+      // over its output that they replace - and only where its tile shape does not depend on the batch: conv16q_plan_tiles)
       // every tile lies inside one sample: the epilogue also leaves (sum, sumsq) per (tile, cout) for the next
       // GroupNorm (the fp32 kernel: per (tile, wave, cout))
       const int tpi = cdiv(oh_tiled, o.cp.TH) * o.cp.tiles_x * (pc.q ? 2 : (pc.ns ? 1 : 4)) * (o.cp.up == 2 ? 4 : 1);
