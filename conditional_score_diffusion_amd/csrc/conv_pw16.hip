@@ -42,7 +42,6 @@ struct PwKArgs {
   int npix;        // B*OH*OW
   int hw;          // pixels per sample (row of the GroupNorm scale/shift table)
   int ks;          // K steps of 32 channels
-  int kc;          // K steps per weight chunk in LDS (ks: the whole cout group's weights stay resident; less: they are re-copied chunk by chunk)
   int ntiles;      // pixel tiles
 };
 
@@ -66,9 +65,7 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
   const int ng = blockIdx.y;
   const int Cin = k.C0 + k.C1;
 
-  constexpr int STEPB = PW_NTL * NS * 1024;              // weight bytes of one K step
-  const int wbytes = k.kc * STEPB;                       // LDS holds ONE chunk of kc K steps (kc == ks: all of them, copied once)
-  const bool chunked = k.kc < k.ks;
+  const int wbytes = k.ks * PW_NTL * NS * 1024;
   float* const lds_bias = reinterpret_cast<float*>(smem + wbytes);      // bias of this group's 96 couts behind the weights
   const int col_base = ng * (PW_NTL * 16) + kq * 4;       // this lane's first cout of tile 0
 
@@ -124,8 +121,7 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
   for (int u = 0; u < D; ++u) issue(raw[u], nsc[PFN ? u : 0], nsh[PFN ? u : 0]);
 
   // ---- this cout group's weights -> LDS, once per workgroup (behind the first activation requests: their latency overlaps the copy) ----
-  const char* const wgroup = g_wpack + (size_t)ng * k.ks * STEPB;
-  wg_copy_to_lds<PW_THREADS, 9>(smem, wgroup, wbytes < k.ks * STEPB ? wbytes : k.ks * STEPB, tid);      // (9 x 4 KiB per round: a 288-channel layer's 108 KiB in three)
+  wg_copy_to_lds<PW_THREADS, 9>(smem, g_wpack + (size_t)ng * wbytes, wbytes, tid);      // (9 x 4 KiB per round: a 288-channel layer's 108 KiB in three)
   if (tid < PW_NTL * 16) {                                // (zero where the cout does not exist)
     const int c = ng * (PW_NTL * 16) + tid;
     lds_bias[tid] = (k.a.bias && c < k.Cout) ? k.a.bias[c] : 0.f;
@@ -170,17 +166,8 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
           }
         }
         issue(raw[u], nsc[PFN ? u : 0], nsh[PFN ? u : 0]);       // this slot is free again: request K step it + u + D
-        // ---- a layer whose cout group's weights exceed the LDS (480 / 576 input channels: 180 - 216 KiB in the split mode) keeps ONE
-        // chunk of kc K steps there: at a chunk boundary the workgroup meets, copies the next chunk and meets again (small maps: one
-        // or two tiles per workgroup, so a chunk is copied once or twice; the fp32 kernel these layers ran on took 31 - 40 us) ----
-        if (chunked && c_kk % k.kc == 0 && (c_kk != 0 || it + u != 0)) {
-          __syncthreads();
-          const int left = k.ks - c_kk;
-          wg_copy_to_lds<PW_THREADS, 9>(smem, wgroup + (size_t)c_kk * STEPB, (left < k.kc ? left : k.kc) * STEPB, tid);
-          __syncthreads();
-        }
         // ---- MFMAs: 6 cout tiles x MTP pixel tiles ----
-        const char* wk = smem + (size_t)(chunked ? c_kk % k.kc : c_kk) * STEPB + lane * 16;
+        const char* wk = smem + (size_t)c_kk * PW_NTL * NS * 1024 + lane * 16;
 #pragma unroll
         for (int nt = 0; nt < PW_NTL; ++nt) {
           if (nt >= ntl) continue;             // (uniform: a 28-cout layer runs 2 of the 6 tiles)
@@ -245,18 +232,11 @@ __global__ __launch_bounds__(PW_THREADS, OCC) void pw16_kernel(const float* __re
 // host side
 // ---------------------------------------------------------------------------------------------
 static size_t pw16_w_bytes(const ConvPlan& p, int ns) { return (size_t)((p.C0 + p.C1) / 32) * PW_NTL * ns * 1024; }
-// K steps of a cout group's weights that stay in LDS at a time: all of them while they fit 144 KiB, else chunks of that size
-static int pw16_chunk_steps(const ConvPlan& p, int ns) {
-  const int ks = (p.C0 + p.C1) / 32, fit = (144 * 1024) / (PW_NTL * ns * 1024);
-  return ks <= fit ? ks : fit;
-}
-static size_t pw16_lds_bytes(const ConvPlan& p, int ns) {
-  return (size_t)pw16_chunk_steps(p, ns) * PW_NTL * ns * 1024 + PW_NTL * 16 * sizeof(float);
-}
+static size_t pw16_lds_bytes(const ConvPlan& p, int ns) { return pw16_w_bytes(p, ns) + PW_NTL * 16 * sizeof(float); }
 
 bool pw16_supported(const ConvPlan& p, int ns) {
   return p.taps == 1 && p.stride == 1 && p.up == 0 && p.C0 > 0 && p.C0 % 32 == 0 && p.C1 % 32 == 0 && p.Cout % 4 == 0 &&
-         (ns == 1 || ns == 2) && (pw16_w_bytes(p, ns) + PW_NTL * 16 * sizeof(float) <= 150 * 1024 || !CSD_TUNE_ENV("CSD_PW16_NO_CHUNKS"));
+         (ns == 1 || ns == 2) && pw16_lds_bytes(p, ns) <= 150 * 1024;
 }
 
 size_t pw16_packed_bytes(const ConvPlan& p, int ns) {
@@ -466,7 +446,6 @@ int pw16_launch(const ConvPlan& p, int ns, const ConvArgs& a, hipStream_t s) {
   k.npix = p.B * p.OH * p.OW;
   k.hw = p.OH * p.OW;
   k.ks = (p.C0 + p.C1) / 32;
-  k.kc = pw16_chunk_steps(p, ns);
   // big layers: 128-pixel tiles (2 x 16 pixels per wave) - 150 registers, three workgroups per CU measured
   // fastest (more waves in flight beat more bytes per wave); small layers: 64-pixel tiles to fill the chip
   const bool big = cdiv(k.npix, 128) >= 768;
