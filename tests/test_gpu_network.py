@@ -459,6 +459,33 @@ def test_batch_independence_of_network():
     assert torch.equal(full[3:4], one)
 
 
+@pytest.mark.parametrize('case,B', [('sr3_tiny', 33), ('cmde_tiny', 32), ('uncond_tiny', 37)])
+def test_batch_chunk_plan_returns_the_bits_of_the_unchunked_plan(case, B):
+    """from 32 images on the planned executor runs the levels of <= 20^2 pixels as two batch chunks on two streams (csrc/unet.hip
+    build_plan: OP_FORK / OP_JOIN, a private workspace block per chunk, slices of the full-batch tensors at the region's boundary):
+    ragged chunk sizes (17 + 16, 19 + 18) included, every sample's output must be bit-identical to the same sample evaluated in a
+    batch below the threshold (the unchunked plan), and a second call must not be disturbed by the first one's streams"""
+    cfg, nc, p, model = build(case, precision='fp16x3')
+    shape_x = tuple(cfg.data.shape_x) if hasattr(cfg.data, 'shape_x') else (cfg.data.num_channels, cfg.data.image_size, cfg.data.image_size)
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn((B,) + shape_x, generator=g) * 20).to(dev())
+    lab = (torch.rand(B, generator=g) * 900 + 50).to(dev())
+    if cfg.model.name == 'ddpm':
+        inp = lambda sl: x[sl].contiguous()      # noqa: E731
+    else:
+        y = cases.case_y(case, B=B).to(dev())
+        inp = lambda sl: {'x': x[sl].contiguous(), 'y': y[sl].contiguous()}      # noqa: E731
+    flat = lambda r: torch.cat([r['x'], r['y']], 1) if isinstance(r, dict) else r      # noqa: E731
+    with torch.no_grad():
+        full = flat(model(inp(slice(0, B)), lab))
+        again = flat(model(inp(slice(0, B)), lab))
+        parts = [flat(model(inp(slice(i, min(i + 8, B))), lab[i:i + 8].contiguous())) for i in range(0, B, 8)]
+    assert torch.equal(full, again)
+    assert torch.equal(full, torch.cat(parts))
+    launches_full, launches_small = model.stats(B)[0], model.stats(8)[0]
+    assert launches_full > launches_small + 20      # the region's launches appear once per chunk: the chunked plan IS what ran
+
+
 def test_errors_are_loud():
     from conditional_score_diffusion_amd.models import utils as mutils
     cfg, nc, p, model = build('sr3_tiny')
