@@ -213,6 +213,10 @@ struct Net {
   int dense_total = 0;
   std::map<int, int> dense_col;                      // module idx -> first column
   bool packed_once = false;
+  struct CopyDesc* copy_tab = nullptr;      // device table of pack_all's raw copies (+ its host copy and the event behind the upload)
+  size_t copy_tab_cap = 0;
+  std::vector<struct CopyDesc> copy_host;
+  hipEvent_t copy_ev = nullptr;
   std::map<int, std::unique_ptr<Plan>> plans;
   int in_cpad = 8;
   // second stream for the ResnetBlock shortcut contraction (independent of the block's GroupNorm -> conv chain until the second conv
@@ -243,6 +247,8 @@ struct Net {
     return hipEventCreateWithFlags(&ev_cfork, hipEventDisableTiming) == hipSuccess;
   }
   ~Net() {
+    if (copy_ev) { (void)hipEventSynchronize(copy_ev); (void)hipEventDestroy(copy_ev); }
+    if (copy_tab) (void)hipFree(copy_tab);
     for (int k = 0; k < MAX_CHUNKS; ++k) {
       if (cstream[k]) { (void)hipStreamSynchronize(cstream[k]); (void)hipStreamDestroy(cstream[k]); }
       if (ev_cjoin[k]) (void)hipEventDestroy(ev_cjoin[k]);
@@ -1966,12 +1972,26 @@ static int dev_fill(float* dst, float v, size_t nfl, hipStream_t s) {
   return CSD_OK;
 }
 
+// every raw fp32 copy of a pack (GroupNorm affine, Linear / Dense weights, conv biases: ~480 of them at the SR3-160 shape) in ONE launch:
+// a table of (source, destination offset, count) in device memory, one workgroup row per entry.  As separate launches they were 900
+// kernel dispatches per pack - a third of the launches of a four-forward profile of NCSN++-256.
+struct CopyDesc { const float* src; float* dst; unsigned long long n; };
+__global__ void copy_table_kernel(const CopyDesc* __restrict__ tab) {
+  const CopyDesc d = tab[blockIdx.y];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (size_t)gridDim.x * blockDim.x) d.dst[i] = d.src[i];
+}
+// the host copy of the table belongs to the handle: the upload is stream-ordered and may still be in flight when pack returns, so the
+// next pack waits for the event behind the previous upload before it rewrites the vector (no stream synchronisation in a pack)
+static int run_copy_table(Net& n, hipStream_t s);
+
 static int pack_all(Net& n, float* pk, hipStream_t s) {
   for (auto& p : n.params)
     CSD_REQUIRE(p.ptr != nullptr, "pack: parameter '%s' was never registered (csd_unet_set_param)", p.name.c_str());
   int rc;
-  for (auto& cp : n.copies)
-    if ((rc = dev_copy(n.params[cp.param].ptr, pk + cp.off, (size_t)n.params[cp.param].numel, s))) return rc;
+  if (n.copy_ev) CSD_CHECK_HIP(hipEventSynchronize(n.copy_ev));      // (the previous pack's table upload has left the host vector)
+  n.copy_host.clear();
+  struct { Net& n; void add(const float* src, float* dst, size_t nfl) { if (nfl) n.copy_host.push_back(CopyDesc{src, dst, (unsigned long long)nfl}); } } batch{n};
+  for (auto& cp : n.copies) batch.add(n.params[cp.param].ptr, pk + cp.off, (size_t)n.params[cp.param].numel);
   for (auto& pc : n.pconvs) {
     if ((rc = dev_fill(pk + pc.b_off, 0.f, (size_t)pc.proto.CoutPad, s))) return rc;
     for (auto& src : pc.srcs) {   // sources are listed with ascending cout_off, first one clears the tensor
@@ -1992,7 +2012,7 @@ static int pack_all(Net& n, float* pk, hipStream_t s) {
                  : conv_pack_weight(pc.proto, n.params[src.param_w].ptr, src.layout, cin_src, src.cout_src,
                                     src.cout_off, pk + pc.w_off, s);
       if (rc) return rc;
-      if ((rc = dev_copy(n.params[src.param_b].ptr, pk + pc.b_off + src.cout_off, (size_t)src.cout_src, s))) return rc;
+      batch.add(n.params[src.param_b].ptr, pk + pc.b_off + src.cout_off, (size_t)src.cout_src);      // (behind the fill above: same stream)
     }
   }
   if (n.cfg.conditional) {
@@ -2000,13 +2020,31 @@ static int pack_all(Net& n, float* pk, hipStream_t s) {
     for (auto& m : n.mods) {
       if (m.kind != M_RES) continue;
       const int col = n.dense_col.at(m.idx);
-      if ((rc = dev_copy(n.params[n.P(mname(m.idx, "Dense_0.weight"))].ptr, pk + n.dense_all_off + (size_t)col * K,
-                         (size_t)m.cout * K, s))) return rc;
-      if ((rc = dev_copy(n.params[n.P(mname(m.idx, "Dense_0.bias"))].ptr, pk + n.dense_all_bias_off + col,
-                         (size_t)m.cout, s))) return rc;
+      batch.add(n.params[n.P(mname(m.idx, "Dense_0.weight"))].ptr, pk + n.dense_all_off + (size_t)col * K, (size_t)m.cout * K);
+      batch.add(n.params[n.P(mname(m.idx, "Dense_0.bias"))].ptr, pk + n.dense_all_bias_off + col, (size_t)m.cout);
     }
   }
+  if ((rc = run_copy_table(n, s))) return rc;
   n.packed_once = true;
+  return CSD_OK;
+}
+
+static int run_copy_table(Net& n, hipStream_t s) {
+  if (n.copy_host.empty()) return CSD_OK;
+  if (n.copy_tab_cap < n.copy_host.size()) {
+    if (n.copy_tab) (void)hipFree(n.copy_tab);
+    n.copy_tab = nullptr;
+    CSD_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&n.copy_tab), n.copy_host.size() * sizeof(CopyDesc)));
+    n.copy_tab_cap = n.copy_host.size();
+  }
+  if (!n.copy_ev) CSD_CHECK_HIP(hipEventCreateWithFlags(&n.copy_ev, hipEventDisableTiming));
+  CSD_CHECK_HIP(hipMemcpyAsync(n.copy_tab, n.copy_host.data(), n.copy_host.size() * sizeof(CopyDesc), hipMemcpyHostToDevice, s));
+  CSD_CHECK_HIP(hipEventRecord(n.copy_ev, s));
+  size_t longest = 0;
+  for (auto& d : n.copy_host) longest = std::max<size_t>(longest, d.n);
+  const unsigned gx = (unsigned)std::min<size_t>(cdiv64(longest, 256), 64);
+  hipLaunchKernelGGL(copy_table_kernel, dim3(gx, (unsigned)n.copy_host.size()), dim3(256), 0, s, n.copy_tab);
+  CSD_LAUNCH_CHECK();
   return CSD_OK;
 }
 
