@@ -261,10 +261,22 @@ def main():
         _lib.profile_select(['conv3x3'], PROF_STRIDE)
         _lib.profile_start()
     t0 = time.perf_counter()
-    run_steps(W, K, 2000 + rank)
+    failure = None
+    try:
+        run_steps(W, K, 2000 + rank)
+    except FloatingPointError as e:      # NonFiniteError of csd_pc_sample's finiteness contract: carried across the group before the gather,
+        failure = e                      # so that no rank is left waiting in the collective (round-5 advisor)
     if not stub:
         torch.cuda.synchronize()      # (this rank's steps are done: the per-rank figure below; csd_pc_sample has synchronised already)
     t_steps = time.perf_counter() - t0
+    if grouped:
+        bad = torch.tensor([1.0 if failure is not None else 0.0], device=dev)
+        torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
+        if float(bad.item()) > 0:
+            torch.distributed.destroy_process_group()
+            raise failure if failure is not None else FloatingPointError('bench: the sampler state of another rank left the finite range')
+    elif failure is not None:
+        raise failure
     if grouped:     # the one collective of the sampling path: gather the finished samples
         out = torch.empty((world * B,) + tuple(x.shape[1:]), dtype=torch.float32, device=dev)
         torch.distributed.all_gather_into_tensor(out, x)

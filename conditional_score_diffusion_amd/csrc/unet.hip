@@ -239,12 +239,13 @@ struct Net {
   static constexpr int MAX_CHUNKS = 4;
   hipStream_t cstream[MAX_CHUNKS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_cfork = nullptr, ev_cjoin[MAX_CHUNKS] = {nullptr, nullptr, nullptr, nullptr};
-  bool chunks_ready() {
-    if (ev_cfork) return true;
-    for (int k = 0; k < MAX_CHUNKS; ++k)
-      if (hipStreamCreateWithFlags(&cstream[k], hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&ev_cjoin[k], hipEventDisableTiming) != hipSuccess) return false;
-    return hipEventCreateWithFlags(&ev_cfork, hipEventDisableTiming) == hipSuccess;
+  bool chunks_ready(int n_extra) {      // the first n_extra chunk streams exist (created on demand: a stream occupies a hardware queue)
+    for (int k = 0; k < n_extra && k < MAX_CHUNKS; ++k) {
+      if (cstream[k]) continue;
+      if (hipStreamCreateWithFlags(&cstream[k], hipStreamNonBlocking) != hipSuccess) { cstream[k] = nullptr; return false; }
+      if (hipEventCreateWithFlags(&ev_cjoin[k], hipEventDisableTiming) != hipSuccess) return false;
+    }
+    return ev_cfork != nullptr || hipEventCreateWithFlags(&ev_cfork, hipEventDisableTiming) == hipSuccess;
   }
   ~Net() {
     if (copy_ev) { (void)hipEventSynchronize(copy_ev); (void)hipEventDestroy(copy_ev); }
@@ -1824,7 +1825,7 @@ static int run_plan(Net& n, const Plan& pl, const float* pk, float* ws, const fl
     int rc = CSD_OK;
     // batch-chunk region: the chunk streams start behind everything enqueued so far; the caller's stream resumes behind all of them
     if (o.kind == OP_FORK) {
-      if (!n.chunks_ready()) { set_error("unet: cannot create the chunk streams"); return CSD_ERR_HIP; }
+      if (!n.chunks_ready(o.i0 - 1)) { set_error("unet: cannot create the chunk streams"); return CSD_ERR_HIP; }
       CSD_CHECK_HIP(hipEventRecord(n.ev_cfork, s));
       for (int k = 0; k + 1 < o.i0; ++k) CSD_CHECK_HIP(hipStreamWaitEvent(n.cstream[k], n.ev_cfork, 0));
       continue;
