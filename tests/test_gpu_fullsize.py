@@ -282,3 +282,31 @@ def test_config3_cmde_128_batch_64_equals_batch_1(precision):
         full = model({'x': x.to(dev()), 'y': y.to(dev())}, lab.to(dev()))
         one = model({'x': x[k:k + 1].to(dev()), 'y': y[k:k + 1].to(dev())}, lab[:1].to(dev()))
     assert torch.equal(full['x'][k:k + 1], one['x']) and torch.equal(full['y'][k:k + 1], one['y'])
+
+
+def test_profiler_prices_the_dominant_kernel_on_survey_8d_bytes():
+    """the in-library profiler's class 'conv3x3' is the conv_xk launches alone (30 per evaluation of the SR3-160 network; the first layer
+    and the quad kernel's 3x3 launches report as 'conv3x3_other'), and csd_profile_stop_ex returns for it the SURVEY.md 8(d) bytes -
+    (input + output tensor) x 4 B = 19.98 GB per evaluation at B = 64, i.e. 312.2 MB per image - next to the bytes the kernels have to
+    move (larger: every block's second convolution also reads a residual).  bench.py's roofline.frac is computed from the former."""
+    from conditional_score_diffusion_amd import _lib
+    cfg, nc, p, model = build_sr3_160('fp16x3')
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(B, 3, 160, 160, generator=g) * 30).to(dev())
+    y = cases.sr3_160_y(B).to(dev())
+    lab = torch.full((B,), 500.0, device=dev())
+    with torch.no_grad():
+        model({'x': x, 'y': y}, lab)                     # (packs the weights, builds the plan)
+        _lib.profile_select(None, 1)
+        _lib.profile_start()
+        model({'x': x, 'y': y}, lab)
+        torch.cuda.synchronize()
+        prof = _lib.profile_stop()
+    dom, other = prof['conv3x3'], prof['conv3x3_other']
+    assert dom['launches'] == 30 and other['launches'] > 20
+    assert abs(dom['alg_bytes'] / B - 19.98e9 / 64) < 0.01 * 19.98e9 / 64
+    assert dom['bytes'] > 1.15 * dom['alg_bytes']         # 15 of the 30 launches read a residual of their output's size
+    assert dom['flops'] > 0.9 * (dom['flops'] + other['flops'])      # 92 % of the 3x3 stride-1 flops of this shape
+    for k, v in prof.items():
+        assert v['alg_bytes'] <= v['bytes'] * (1 + 1e-9) or k in ('conv3x3_other', 'conv3x3_resample', 'conv1x1'), k
