@@ -1685,7 +1685,7 @@ static int build_plan(Net& n, int B, Plan** out) {
     const int chunk_side = e_side ? atoi(e_side) : 20;
     for (int l = 1; l <= last; ++l)
       if ((S >> l) <= chunk_side) { l0 = l; break; }
-    K = e_k ? atoi(e_k) : (B >= 32 ? 2 : 1);      // measured at B = 64 (NOTEBOOK round 6): 2 chunks -0.4 ms per PC step, 3 neutral, 4 +0.3 ms
+    K = e_k ? atoi(e_k) : (B >= 64 ? 2 : 1);      // measured (NOTEBOOK round 6): B = 64: 2 chunks -0.24 ms per PC step, 3 chunks +0.25; B = 16 .. 48: 2 chunks +0.05 .. +0.23 ms
     K = std::max(1, std::min(K, std::min(B, (int)Net::MAX_CHUNKS)));
     if (l0 > last) K = 1;
   }

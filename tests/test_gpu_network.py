@@ -459,11 +459,11 @@ def test_batch_independence_of_network():
     assert torch.equal(full[3:4], one)
 
 
-@pytest.mark.parametrize('case,B', [('sr3_tiny', 33), ('cmde_tiny', 32), ('uncond_tiny', 37)])
+@pytest.mark.parametrize('case,B', [('sr3_tiny', 65), ('cmde_tiny', 64), ('uncond_tiny', 69)])
 def test_batch_chunk_plan_returns_the_bits_of_the_unchunked_plan(case, B):
-    """from 32 images on the planned executor runs the levels of <= 20^2 pixels as two batch chunks on two streams (csrc/unet.hip
+    """from 64 images on the planned executor runs the levels of <= 20^2 pixels as two batch chunks on two streams (csrc/unet.hip
     build_plan: OP_FORK / OP_JOIN, a private workspace block per chunk, slices of the full-batch tensors at the region's boundary):
-    ragged chunk sizes (17 + 16, 19 + 18) included, every sample's output must be bit-identical to the same sample evaluated in a
+    ragged chunk sizes (33 + 32, 35 + 34) included, every sample's output must be bit-identical to the same sample evaluated in a
     batch below the threshold (the unchunked plan), and a second call must not be disturbed by the first one's streams"""
     cfg, nc, p, model = build(case, precision='fp16x3')
     shape_x = tuple(cfg.data.shape_x) if hasattr(cfg.data, 'shape_x') else (cfg.data.num_channels, cfg.data.image_size, cfg.data.image_size)
